@@ -1,0 +1,163 @@
+"""Deterministic synthetic depth-map scenes (inputs for tests, smoke and bench).
+
+The reference ships no sample data, so every input is generated:
+a voxel cube [-1,1]^3, a sphere of radius 0.6 at the origin, pinhole cameras on
+a ring / Fibonacci sphere of radius 3 looking at the origin, K = [[f,0,W/2],
+[0,f,H/2],[0,0,1]] with f = 0.9 W, depth = camera-space z of the first ray /
+sphere intersection (the quantity the reference compares against,
+Reconstruction/CudaReconstruction.cu:207), -1 where the ray misses (the
+reference's "no depth" sentinel, cu:202 and Sources/ReconstructionData.cxx:164).
+
+Conventions reproduced from the reference:
+  * depth tables are stored in vtkImageData order: row 0 is the BOTTOM image row,
+    so image pixel (px, py) lives at index W*(H-1-py)+px (cu:141-149);
+  * x_cam = R x_world + T, RT = [R|T; 0 0 0 1] (Sources/Helper.h:134-165);
+  * K4 = 3x3 K in the top-left of a 4x4 identity (ReconstructionData.cxx:192-212).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class GridDesc:
+    """Voxel grid = the cells of the reference's input vtkImageData (filt.cxx:121-126)."""
+    cell_dims: tuple  # (nx, ny, nz) voxels; vtk point dims are these + 1
+    origin: tuple
+    spacing: tuple
+    grid_matrix: np.ndarray = field(default_factory=lambda: np.eye(4))  # rows = gridVecX/Y/Z (main.cxx:345-359)
+
+    @property
+    def n_voxels(self) -> int:
+        return int(self.cell_dims[0]) * int(self.cell_dims[1]) * int(self.cell_dims[2])
+
+
+@dataclass
+class RayPotential:
+    """The four TSDF parameters (cu:60-63; README 'TSDF')."""
+    thickness: float
+    rho: float
+    eta: float
+    delta: float
+
+
+@dataclass
+class Views:
+    """A batch of depth maps with their cameras, as ReconstructionData exposes them."""
+    depth: np.ndarray  # [n, H, W] f64, vtk row order, -1 = no depth
+    K4: np.ndarray  # [n, 4, 4]
+    RT4: np.ndarray  # [n, 4, 4]
+    best_cost: np.ndarray | None = None  # [n, H, W] f64 or None
+
+    @property
+    def n(self) -> int:
+        return int(self.depth.shape[0])
+
+    @property
+    def width(self) -> int:
+        return int(self.depth.shape[2])
+
+    @property
+    def height(self) -> int:
+        return int(self.depth.shape[1])
+
+    def subset(self, lo: int, hi: int) -> "Views":
+        return Views(self.depth[lo:hi], self.K4[lo:hi], self.RT4[lo:hi],
+                     None if self.best_cost is None else self.best_cost[lo:hi])
+
+
+def default_grid(n: int | tuple, rotated: bool = False) -> GridDesc:
+    """Cube [-1,1]^3 with n^3 (or nx,ny,nz) voxels."""
+    dims = (n, n, n) if isinstance(n, int) else tuple(int(v) for v in n)
+    spacing = tuple(2.0 / d for d in dims)
+    G = np.eye(4)
+    if rotated:
+        # orthonormal rows (the CLI requires orthogonal gridVec*, main.cxx:363-382)
+        a, b = 0.3, -0.2
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        G[:3, :3] = Rz @ Rx
+    return GridDesc(dims, (-1.0, -1.0, -1.0), spacing, G)
+
+
+def default_ray_potential(grid: GridDesc) -> RayPotential:
+    """Same ratios as the reference's example command lines (main.cxx:102-103)."""
+    s = float(max(grid.spacing))
+    return RayPotential(thickness=2.5 * s, rho=0.8, eta=0.03, delta=10.0 * s)
+
+
+def look_at_rt(cam_pos: np.ndarray, target=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """4x4 [R|T] with camera z forward, x right, y down (image rows grow downwards)."""
+    c = np.asarray(cam_pos, dtype=np.float64)
+    fwd = np.asarray(target, dtype=np.float64) - c
+    fwd /= np.linalg.norm(fwd)
+    up = np.array([0.0, 0.0, 1.0])
+    if abs(fwd @ up) > 0.99:
+        up = np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R = np.stack([right, down, fwd])
+    RT = np.eye(4)
+    RT[:3, :3] = R
+    RT[:3, 3] = -R @ c
+    return RT
+
+
+def camera_positions(n: int, radius: float = 3.0, layout: str = "sphere") -> np.ndarray:
+    if layout == "ring":
+        t = 2 * np.pi * (np.arange(n) + 0.25) / n
+        return np.stack([radius * np.cos(t), radius * np.sin(t), 0.35 * radius * np.sin(2 * t)], axis=1)
+    # Fibonacci sphere
+    i = np.arange(n) + 0.5
+    phi = np.arccos(1 - 2 * i / n)
+    theta = np.pi * (1 + 5 ** 0.5) * i
+    return radius * np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+
+
+def render_sphere_depth(K: np.ndarray, RT: np.ndarray, W: int, H: int, center=(0.0, 0.0, 0.0),
+                        radius: float = 0.6, background: float | None = None) -> np.ndarray:
+    """Camera-z depth of a sphere, float32-representable f64, vtk row order."""
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    px = np.arange(W, dtype=np.float64)
+    py = np.arange(H, dtype=np.float64)
+    dx = ((px - cx) / fx)[None, :]
+    dy = ((py - cy) / fy)[:, None]
+    # ray = t * (dx, dy, 1) in the camera frame; t is the camera-space z
+    c = RT[:3, :3] @ np.asarray(center, dtype=np.float64) + RT[:3, 3]
+    a = dx * dx + dy * dy + 1.0
+    b = dx * c[0] + dy * c[1] + c[2]
+    disc = b * b - a * (c @ c - radius * radius)
+    hit = disc >= 0
+    t = (b - np.sqrt(np.where(hit, disc, 0.0))) / a
+    hit &= t > 0
+    miss = -1.0 if background is None else float(background)
+    img = np.where(hit, t, miss)
+    img = img.astype(np.float32).astype(np.float64)  # lossless f32 storage on the device
+    return img[::-1].copy()  # image row py -> vtk row H-1-py
+
+
+def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", dense: bool = False,
+               with_best_cost: bool = False, radius: float = 3.0, focal_scale: float = 0.9) -> Views:
+    """n cameras around the sphere scene.  dense=True adds a background at camera z = radius + 0.5
+    so nearly every in-frustum voxel reaches the accumulate (hit rate ~100 % instead of ~30 %)."""
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = focal_scale * W
+    K[0, 2] = W / 2.0
+    K[1, 2] = H / 2.0
+    pos = camera_positions(n, radius=radius, layout=layout)
+    rng = np.random.default_rng(seed)
+    depth = np.empty((n, H, W), dtype=np.float64)
+    K4 = np.empty((n, 4, 4))
+    RT4 = np.empty((n, 4, 4))
+    for m in range(n):
+        # small deterministic jitter so no two cameras share exact symmetries
+        jitter = 0.02 * rng.standard_normal(3)
+        RT4[m] = look_at_rt(pos[m], target=jitter)
+        K4[m] = K
+        depth[m] = render_sphere_depth(K[:3, :3], RT4[m], W, H,
+                                       background=(radius + 0.5) if dense else None)
+    best = rng.random((n, H, W)) if with_best_cost else None
+    return Views(depth, K4, RT4, best)

@@ -1,0 +1,80 @@
+"""numpy restatement of the reference's fusion arithmetic (small cases only).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED.  Written independently of
+tsdf_oracle.c from the same reference lines, vectorised over voxels; used by
+tests/test_oracle.py to cross-check the C oracle bit for bit.  numpy's
+elementwise float64 multiply/add are separately rounded IEEE operations, i.e.
+the same canonical arithmetic as the C build with -ffp-contract=off.
+
+Citations: cu = Reconstruction/CudaReconstruction.cu of the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _round_half_away(u: np.ndarray) -> np.ndarray:
+    """C/CUDA round(): nearest integer, halves away from zero (cu:187-188).
+
+    u - trunc(u) is exact in fp64, so the comparison with 0.5 is exact too
+    (floor(u + 0.5) would be wrong for u = 0.49999999999999994).
+    """
+    t = np.trunc(u)
+    frac = np.abs(u - t)
+    return t + np.where(frac >= 0.5, np.copysign(1.0, u), 0.0)
+
+
+def _rows(M, x, y, z):
+    """cu:88-93: ((m0*x + m1*y) + m2*z) + m3 for rows 0..2 of a 4x4."""
+    out = []
+    for r in range(3):
+        out.append(((M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z) + M[r, 3])
+    return out
+
+
+def fuse(cell_dims, origin, spacing, grid_matrix, thick, rho, eta, delta, depths, K4, RT4, init_grid=None):
+    """Returns (grid f64 [nz,ny,nx], voxel_hits u32 [nz,ny,nx], map_hits u64 [n])."""
+    nx, ny, nz = (int(c) for c in cell_dims)
+    G = np.asarray(grid_matrix, dtype=np.float64).reshape(4, 4)
+    depths = np.asarray(depths, dtype=np.float64)
+    n, H, W = depths.shape
+    K4 = np.asarray(K4, dtype=np.float64).reshape(n, 4, 4)
+    RT4 = np.asarray(RT4, dtype=np.float64).reshape(n, 4, 4)
+
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    # cu:78-83
+    gx = origin[0] + (i + 0.5) * spacing[0]
+    gy = origin[1] + (j + 0.5) * spacing[1]
+    gz = origin[2] + (k + 0.5) * spacing[2]
+    wx, wy, wz = _rows(G, gx, gy, gz)  # cu:168
+
+    grid = np.zeros((nz, ny, nx)) if init_grid is None else np.array(init_grid, dtype=np.float64).reshape(nz, ny, nx)
+    vhits = np.zeros((nz, ny, nx), dtype=np.uint32)
+    mhits = np.zeros(n, dtype=np.uint64)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for m in range(n):
+            cx, cy, cz = _rows(RT4[m], wx, wy, wz)  # cu:172
+            hx, hy, hz = _rows(K4[m], cx, cy, cz)  # cu:176
+            ok = ~(hz < 0)  # cu:177
+            u = hx / hz  # cu:183
+            v = hy / hz  # cu:184
+            ru = _round_half_away(u)
+            rv = _round_half_away(v)
+            lim = 2147483648.0
+            ok &= (ru > -lim) & (ru < lim) & (rv > -lim) & (rv < lim)  # project rule, see tsdf_oracle.c
+            ok &= (ru >= 0) & (rv >= 0) & (ru < W) & (rv < H)  # cu:192-197
+            px = np.where(ok, ru, 0).astype(np.int64)
+            py = np.where(ok, rv, 0).astype(np.int64)
+            d = depths[m][H - 1 - py, px]  # cu:141-149
+            ok &= ~(d == -1)  # cu:202
+            diff = cz - d  # cu:108
+            a = np.abs(diff)
+            sign = np.where(diff != 0, np.trunc(diff / np.where(a == 0, 1.0, a)), 0.0)  # cu:112
+            far = np.where(diff > 0, 0.0, -eta * rho)  # cu:115
+            plateau = rho * sign  # cu:117
+            ramp = (rho / thick) * diff if thick != 0 else np.full_like(diff, np.nan)  # cu:119
+            val = np.where(a > delta, far, np.where(a > thick, plateau, ramp))
+            grid = np.where(ok, grid + val, grid)  # cu:211
+            vhits += ok.astype(np.uint32)
+            mhits[m] = np.count_nonzero(ok)
+    return grid, vhits, mhits

@@ -1,0 +1,129 @@
+"""CPU tests of the oracle itself (no GPU): golden fixtures, C-vs-numpy cross-check,
+hand-derived known answers from the reference's formulas.
+
+PARITY UNPINNED: the reference has no tests or vectors and cannot be run here; these
+tests pin the oracle to committed numbers and to hand calculations only."""
+import numpy as np
+import pytest
+
+from oracle import oracle, oracle_np
+from helpers import bits_equal, oracle_params_from_golden, thresholded_depth
+
+
+def test_c_oracle_matches_golden(golden):
+    p = oracle_params_from_golden(golden)
+    grid, vh, mh = oracle.fuse(p, thresholded_depth(golden), golden["K4"], golden["RT4"],
+                               init_grid=golden.get("init_grid"))
+    assert bits_equal(grid, golden["expected_grid"])
+    assert np.array_equal(vh, golden["expected_voxel_hits"])
+    assert np.array_equal(mh, golden["expected_map_hits"])
+
+
+def test_numpy_oracle_matches_golden(golden):
+    t, rho, eta, delta = (float(x) for x in golden["ray"])
+    grid, vh, mh = oracle_np.fuse(golden["cell_dims"], golden["origin"], golden["spacing"], golden["grid_matrix"],
+                                  t, rho, eta, delta, thresholded_depth(golden), golden["K4"], golden["RT4"],
+                                  init_grid=golden.get("init_grid"))
+    assert bits_equal(grid, golden["expected_grid"])
+    assert np.array_equal(vh, golden["expected_voxel_hits"])
+    assert np.array_equal(mh, golden["expected_map_hits"])
+
+
+def test_threads_do_not_change_results(golden):
+    p = oracle_params_from_golden(golden)
+    d = thresholded_depth(golden)
+    g1, vh1, mh1 = oracle.fuse(p, d, golden["K4"], golden["RT4"], init_grid=golden.get("init_grid"), n_threads=1)
+    g4, vh4, mh4 = oracle.fuse(p, d, golden["K4"], golden["RT4"], init_grid=golden.get("init_grid"), n_threads=4)
+    assert bits_equal(g1, g4) and np.array_equal(vh1, vh4) and np.array_equal(mh1, mh4)
+
+
+def test_sampled_voxels_equal_full_fuse(golden):
+    p = oracle_params_from_golden(golden)
+    d = thresholded_depth(golden)
+    nvox = int(np.prod(golden["cell_dims"]))
+    ids = np.random.default_rng(0).choice(nvox, size=min(nvox, 500), replace=False)
+    init = None if "init_grid" not in golden else golden["init_grid"].reshape(-1)[ids]
+    vals, hits = oracle.fuse_voxels(p, d, golden["K4"], golden["RT4"], ids, init=init)
+    assert bits_equal(vals, golden["expected_grid"].reshape(-1)[ids])
+    assert np.array_equal(hits, golden["expected_voxel_hits"].reshape(-1)[ids])
+
+
+# ---- known answers worked out by hand from the reference's formulas -------------------
+
+def _rp_params(thick=0.5, rho=0.8, eta=0.03, delta=1.5):
+    return oracle.make_params((1, 1, 1), (0, 0, 0), (1, 1, 1), np.eye(4), thick, rho, eta, delta, 1, 1)
+
+
+@pytest.mark.parametrize("real,depth,expected", [
+    # cu:105-120 with thick 0.5, rho 0.8, eta 0.03, delta 1.5 (README "TSDF" plot)
+    (5.0, 2.0, 0.0),                 # diff = +3 > delta, behind the surface: 0            (cu:115)
+    (2.0, 5.0, -0.03 * 0.8),         # diff = -3, |diff| > delta, free space: -eta*rho    (cu:115)
+    (3.0, 2.0, 0.8),                 # diff = +1 in (thick, delta]: +rho plateau           (cu:117)
+    (2.0, 3.0, -0.8),                # diff = -1: -rho plateau                             (cu:117)
+    (2.25, 2.0, (0.8 / 0.5) * 0.25),  # |diff| <= thick: linear ramp rho/thick*diff         (cu:119)
+    (2.0, 2.25, (0.8 / 0.5) * -0.25),
+    (2.0, 2.0, 0.0),                 # diff == 0: ramp gives exactly 0
+    (2.5, 2.0, (0.8 / 0.5) * 0.5),   # |diff| == thick is NOT > thick: still the ramp (== rho)
+    (3.5, 2.0, 0.8),                 # |diff| == delta is NOT > delta: plateau
+])
+def test_ray_potential_known_answers(real, depth, expected):
+    assert oracle.ray_potential(_rp_params(), real, depth) == expected
+
+
+def test_engineered_edges_hand_checked():
+    """Map 0 of the engineered fixture, k = 0 layer, by hand.
+
+    Grid origin 0, spacing 1, identity grid matrix -> centre (i+.5, j+.5, .5) (cu:78-83).
+    RT = identity, K = diag(.5,.5,1): h = (.5(i+.5), .5(j+.5), .5) -> u = i+.5, v = j+.5 (cu:183-184)
+    round half away (cu:187-188): px = i+1, py = j+1; in bounds iff i <= 6 and j <= 4 (W=8, H=6, cu:192-197).
+    vtk row = H-1-py (cu:141-149); fixture sets vtk row 0 (py = 5, j = 4) to -1 -> no hit (cu:202),
+    then adds 0.25*(1+row) to column px = 3 (i = 2): 0.5 + 0.25*(1+row) for rows >= 1 and
+    -1 + 0.25 = -0.75 in row 0, which is NOT the sentinel any more: diff = 0.5 + 0.75 = 1.25 -> +rho.
+    z_cam = 0.5: diff = 0 -> ramp -> 0 elsewhere; at i = 2: diff = -0.25*(1+row), thick = .5, delta = 1.5.
+    """
+    from conftest import load_golden
+    g = load_golden("engineered_edges")
+    p = oracle_params_from_golden(g)
+    grid, vh, mh = oracle.fuse(p, g["depth"][:1], g["K4"][:1], g["RT4"][:1])
+    k0_hits = vh[0]                                  # [ny=6, nx=8]
+    expect_hits = np.zeros((6, 8), dtype=np.uint32)
+    expect_hits[0:4, 0:7] = 1                        # j <= 3 (j = 4 reads the sentinel row), i <= 6
+    expect_hits[4, 2] = 1                            # ... except the -0.75 pixel
+    assert np.array_equal(k0_hits, expect_hits)
+    slope = 0.8 / 0.5
+    for j in range(4):
+        row = 6 - 1 - (j + 1)
+        diff = 0.5 - (0.5 + 0.25 * (1 + row))
+        a = abs(diff)
+        want = (-0.03 * 0.8) if a > 1.5 else (-0.8 if a > 0.5 else slope * diff)
+        assert grid[0, j, 2] == want
+        assert grid[0, j, 1] == 0.0 and grid[0, j, 3] == 0.0
+    assert grid[0, 4, 2] == 0.8
+
+
+def test_behind_camera_and_z_zero_are_out():
+    """Maps 4 and 5 of the engineered fixture shift z_cam by -0.5 / -1.5: the k = 0 layer then has
+    h.z == 0 (division by zero, out by the project rule) resp. h.z < 0 (cu:177)."""
+    from conftest import load_golden
+    g = load_golden("engineered_edges")
+    p = oracle_params_from_golden(g)
+    _, vh4, _ = oracle.fuse(p, g["depth"][4:5], g["K4"][4:5], g["RT4"][4:5])
+    assert vh4[0].sum() == 0 and vh4[1].sum() > 0
+    _, vh5, _ = oracle.fuse(p, g["depth"][5:6], g["K4"][5:6], g["RT4"][5:6])
+    assert vh5[0].sum() == 0 and vh5[1].sum() == 0 and vh5[2].sum() > 0
+    _, vh6, mh6 = oracle.fuse(p, g["depth"][6:7], g["K4"][6:7], g["RT4"][6:7])
+    assert mh6[0] == 0                                # all-sentinel map
+
+
+def test_threshold_filter_and_k4():
+    d = np.array([1.0, 2.0, -1.0, 4.0])
+    b = np.array([0.1, 0.5, 0.9, 0.50000001])
+    out = oracle.apply_depth_threshold(d, b, 0.5)     # strictly greater (RD.cxx:162)
+    assert out.tolist() == [1.0, 2.0, -1.0, -1.0]
+    K4 = oracle.k3_to_k4(np.arange(1.0, 10.0))
+    assert K4.tolist() == [[1, 2, 3, 0], [4, 5, 6, 0], [7, 8, 9, 0], [0, 0, 0, 1]]
+
+
+def test_round_half_away_numpy_helper():
+    u = np.array([0.5, -0.5, 1.5, 2.5, -2.5, 0.49999999999999994, -0.49999999999999994, 7.5, -0.2])
+    assert oracle_np._round_half_away(u).tolist() == [1.0, -1.0, 2.0, 3.0, -3.0, 0.0, -0.0, 8.0, -0.0]
