@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gvoxel-projections/s of the TSDF depth-map fusion path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|NxM@WxH]
+
+A step = one pass of the hot path over one batch of synthetic input: zero the grid, fuse every
+HBM-resident depth map of this rank into it (ONE kernel launch), and for N > 1 all-reduce the
+f32 grid over RCCL (the path's only exchange step).  Depth maps are resident before the timed
+region.  N = 1 workload = BASELINE.json configs[2]: 512^3 voxels x 256 depth maps of 1280x720.
+For N > 1 every rank fuses its own shard of 256 maps (weak scaling: 256*N maps in total).
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      HBM view of the fusion kernel: algorithmic bytes / hipEvent kernel time vs 8 TB/s
+  roofline_valu the binding roof of this kernel: fp64 VALU issue (DESIGN.md "Roofline")
+  cpu_baseline  the CPU oracle (restated reference arithmetic) timed on this host's cores on a
+                bounded sample of the same workload (N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor peak, FMA counted as 2 flop
+FLOP_PER_PROJECTION = 48.0  # algorithmic fp64 flop per voxel-projection
+MAPREC_BYTES = 208  # per-map camera record read by the kernel (fusion_kernels.h)
+
+WORKLOADS = {
+    # name: (grid cells, maps per GPU, W, H)   -- BASELINE.json configs
+    "cfg1": ((64, 64, 64), 4, 320, 240),
+    "cfg2": ((256, 256, 256), 64, 640, 480),
+    "cfg3": ((512, 512, 512), 256, 1280, 720),
+    "cfg3vga": ((512, 512, 512), 256, 640, 480),
+}
+
+
+def parse_workload(s: str):
+    if s in WORKLOADS:
+        return WORKLOADS[s]
+    grid_s, rest = s.split("x", 1)
+    maps_s, wh = rest.split("@")
+    w, h = wh.split("x")
+    n = int(grid_s)
+    return (n, n, n), int(maps_s), int(w), int(h)
+
+
+def algorithmic_bytes(n_vox: int, n_maps: int, w: int, h: int, grid_bytes: int, depth_bytes: int) -> float:
+    """B_alg of one fusion launch: grid written once, every depth value and camera
+    record read once."""
+    return float(grid_bytes * n_vox + depth_bytes * n_maps * w * h + MAPREC_BYTES * n_maps)
+
+
+def cpu_baseline(grid, ray, views, target_seconds: float = 15.0):
+    """Time the CPU oracle on all host cores on the first m maps over the full grid."""
+    from oracle import oracle
+
+    cores = oracle.max_threads()
+    n_vox = grid.n_voxels
+    # ~18 M projections/s/thread measured for this arithmetic; size the sample for ~target_seconds
+    m = int(max(1, min(views.n, round(target_seconds * 18e6 * cores / n_vox))))
+    p = oracle.make_params(grid.cell_dims, grid.origin, grid.spacing, grid.grid_matrix, ray.thickness, ray.rho,
+                           ray.eta, ray.delta, views.width, views.height)
+    depth = np.ascontiguousarray(views.depth[:m], dtype=np.float64)
+    t0 = time.perf_counter()
+    oracle.fuse(p, depth, views.K4[:m], views.RT4[:m], count_hits=False, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_vox * m / dt / 1e9,
+        "unit": "Gvoxel-projections/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{grid.cell_dims[0]}x{grid.cell_dims[1]}x{grid.cell_dims[2]} voxels x first {m} of {views.n} depth "
+                  f"maps, oracle/tsdf_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over z on {cores} threads, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--scene", default="dense", choices=["dense", "sparse"],
+                    help="dense: background behind the sphere, ~every in-frustum voxel accumulates")
+    ap.add_argument("--grid-dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--secondary", action="store_true", help="also time the other scene variant (N = 1)")
+    args = ap.parse_args()
+
+    import torch
+
+    from cudadepthmapintegration_amd import capi, scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the fusion path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl")
+
+    cells, maps_per_gpu, W, H = parse_workload(args.workload)
+    grid = scene.default_grid(cells)
+    ray = scene.default_ray_potential(grid)
+    n_vox = grid.n_voxels
+
+    def make(scene_kind: str):
+        return scene.make_views(maps_per_gpu, W, H, seed=1000 + rank, dense=(scene_kind == "dense"),
+                                layout="sphere", dtype=np.float32)
+
+    views = make(args.scene)
+
+    torch_dtype = torch.float32 if args.grid_dtype == "f32" else torch.float64
+    grid_t = torch.zeros(n_vox, dtype=torch_dtype, device="cuda")
+    # an explicit (non-default) torch stream: the fusion kernel, the grid memset and the RCCL
+    # all-reduce are all ordered on it, and its handle is non-NULL for the C ABI
+    tstream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    ctx = capi.FusionContext(grid, ray, device=local_rank, grid_dtype=args.grid_dtype, depth_storage="auto",
+                             kernel_variant=args.variant, stream=stream, external_grid=grid_t.data_ptr())
+    t_up = time.perf_counter()
+    ctx.add_views(views)
+    upload_s = time.perf_counter() - t_up
+    info = ctx.info()
+    depth_bytes = 8 if info.depth_storage_in_use == capi.DMI_DEPTH_F64 else 4
+    grid_bytes = 4 if args.grid_dtype == "f32" else 8
+
+    def step():
+        ctx.reset_grid()
+        ctx.fuse()
+        if dist is not None:
+            dist.all_reduce(grid_t)  # the single RCCL all-reduce of the TSDF grid over xGMI
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(steps: int, warmup: int):
+        for _ in range(warmup):
+            step()
+        barrier()
+        k0 = ctx.timings()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        k1 = ctx.timings()
+        kern_ms = (k1.total_fuse_kernel_ms - k0.total_fuse_kernel_ms) / max(1, k1.fuse_launches - k0.fuse_launches)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kern_ms
+
+    dt, kern_ms = timed(args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    total_maps = maps_per_gpu * world
+    value = n_vox * total_maps * args.steps / dt / 1e9
+
+    secondary = None
+    if args.secondary and world == 1:
+        other = "sparse" if args.scene == "dense" else "dense"
+        v2 = make(other)
+        ctx.clear_views()
+        ctx.add_views(v2)
+        dt2, kern2 = timed(max(2, args.steps // 2), 1)
+        secondary = {"scene": other, "value": n_vox * maps_per_gpu * max(2, args.steps // 2) / dt2 / 1e9,
+                     "kernel_ms": kern2}
+        del v2
+
+    b_alg = algorithmic_bytes(n_vox, maps_per_gpu, W, H, grid_bytes, depth_bytes)
+    achieved_gbps = b_alg / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            rec = json.load(open(pmc_path)).get(f"{args.workload}:{args.scene}:{args.grid_dtype}")
+            if rec:
+                traffic = rec["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    proj_per_launch = float(n_vox) * maps_per_gpu
+    valu_tflops = FLOP_PER_PROJECTION * proj_per_launch / (kern_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "Gvoxel-projections/s",
+        "value": value,
+        "unit": "Gvoxel-projections/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{cells[0]}x{cells[1]}x{cells[2]} voxels x {maps_per_gpu} depth maps {W}x{H} per GPU "
+                        f"({args.workload}, {args.scene} sphere scene)",
+            "grid_dtype": args.grid_dtype,
+            "depth_storage": "f64" if depth_bytes == 8 else "f32",
+            "k_mode": int(info.k_mode),
+            "kernel_variant": args.variant,
+            "maps_total": total_maps,
+            "parallelism": f"depth-map shards x{world}, one RCCL all-reduce of the grid" if world > 1 else "single GPU",
+            "host_upload_s": round(upload_s, 3),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved_gbps,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved_gbps / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "kernel": "dmi::fuse_kernel",
+            "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_launch": b_alg,
+            "note": "fused voxel-stationary order is fp64-VALU bound, not HBM bound: see roofline_valu and DESIGN.md",
+        },
+        "roofline_valu": {
+            "bound": "valu_fp64",
+            "achieved": valu_tflops,
+            "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": valu_tflops / FP64_VECTOR_PEAK_TFLOPS,
+            "flop_per_projection": FLOP_PER_PROJECTION,
+        },
+    }
+    if secondary:
+        out["secondary"] = secondary
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(grid, ray, views, args.cpu_seconds)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,268 @@
+"""ctypes binding of the C ABI (include/dmi.h) -- used by tests, smoke and bench.
+
+There is NO CPU fallback: if libdmi_hip.so is missing or no HIP device is present every
+entry point raises.  The library is built in-tree by cudadepthmapintegration_amd.build.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+from .scene import GridDesc, RayPotential, Views
+
+DMI_OK = 0
+DMI_F32, DMI_F64 = 0, 1
+DMI_DEPTH_AUTO, DMI_DEPTH_F32, DMI_DEPTH_F64 = 0, 1, 2
+
+# kernel_variant bits (tuning knobs)
+VARIANT_EXACT_DIVISION = 1  # disable the checked-reciprocal fast path
+VARIANT_GENERAL_K = 2  # ignore K structure, evaluate the full 4x4 rows
+
+
+class GridDescC(ctypes.Structure):
+    _fields_ = [("cell_dims", ctypes.c_int32 * 3), ("origin", ctypes.c_double * 3),
+                ("spacing", ctypes.c_double * 3), ("grid_matrix", ctypes.c_double * 16)]
+
+
+class RayPotentialC(ctypes.Structure):
+    _fields_ = [("thickness", ctypes.c_double), ("rho", ctypes.c_double), ("eta", ctypes.c_double),
+                ("delta", ctypes.c_double)]
+
+
+class OptionsC(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("grid_dtype", ctypes.c_int32), ("depth_storage", ctypes.c_int32),
+                ("count_hits", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("stream", ctypes.c_void_p), ("external_grid", ctypes.c_void_p)]
+
+
+class TimingsC(ctypes.Structure):
+    _fields_ = [("last_fuse_kernel_ms", ctypes.c_double), ("total_fuse_kernel_ms", ctypes.c_double),
+                ("fuse_launches", ctypes.c_uint64), ("last_upload_ms", ctypes.c_double),
+                ("last_download_ms", ctypes.c_double)]
+
+
+class InfoC(ctypes.Structure):
+    _fields_ = [("n_voxels", ctypes.c_int64), ("n_views", ctypes.c_int32), ("depth_width", ctypes.c_int32),
+                ("depth_height", ctypes.c_int32), ("depth_storage_in_use", ctypes.c_int32),
+                ("grid_dtype", ctypes.c_int32), ("k_mode", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32), ("device_bytes", ctypes.c_uint64)]
+
+
+# every symbol include/dmi.h declares (tests/test_abi.py checks the library exports them all)
+ABI_SYMBOLS = [
+    "dmi_default_options", "dmi_create", "dmi_destroy", "dmi_last_error", "dmi_add_views", "dmi_add_views_f32",
+    "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_synchronize",
+    "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
+    "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
+]
+
+_lib = None
+
+
+class DmiError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"dmi error {code}: {message}")
+        self.code = code
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libdmi_hip.so (building it with hipcc if the sources are newer).  Raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: the HIP extension is required, there is no CPU fallback")
+    L = ctypes.CDLL(path)
+    vp, i32, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.dmi_default_options.argtypes = [ctypes.POINTER(OptionsC)]
+    L.dmi_default_options.restype = None
+    L.dmi_create.argtypes = [ctypes.POINTER(GridDescC), ctypes.POINTER(RayPotentialC), ctypes.POINTER(OptionsC),
+                             ctypes.POINTER(vp)]
+    L.dmi_destroy.argtypes = [vp]
+    L.dmi_destroy.restype = None
+    L.dmi_last_error.argtypes = [vp]
+    L.dmi_last_error.restype = ctypes.c_char_p
+    L.dmi_add_views.argtypes = [vp, dp, dp, dbl, dp, dp, i32, i32, i32]
+    L.dmi_add_views_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float), dp, dp, i32, i32, i32]
+    L.dmi_clear_views.argtypes = [vp]
+    L.dmi_reset_grid.argtypes = [vp]
+    L.dmi_upload_grid.argtypes = [vp, dp]
+    L.dmi_fuse.argtypes = [vp]
+    L.dmi_fuse_range.argtypes = [vp, i32, i32]
+    L.dmi_synchronize.argtypes = [vp]
+    L.dmi_download_grid_f64.argtypes = [vp, dp]
+    L.dmi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.dmi_download_hits.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
+    L.dmi_grid_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
+    L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
+    L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
+    L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.dmi_free_pinned.argtypes = [vp]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int:
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return int(load().dmi_device_count())
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class FusionContext:
+    """One fusion = one context (dmi_create ... dmi_destroy)."""
+
+    def __init__(self, grid: GridDesc, ray: RayPotential, *, device: int = 0, grid_dtype: str = "f64",
+                 depth_storage: str = "auto", count_hits: bool = False, kernel_variant: int = 0,
+                 stream: int | None = None, external_grid: int | None = None):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        g = GridDescC()
+        for i in range(3):
+            g.cell_dims[i] = int(grid.cell_dims[i])
+            g.origin[i] = float(grid.origin[i])
+            g.spacing[i] = float(grid.spacing[i])
+        gm = np.ascontiguousarray(grid.grid_matrix, dtype=np.float64).reshape(16)
+        for i in range(16):
+            g.grid_matrix[i] = gm[i]
+        r = RayPotentialC(float(ray.thickness), float(ray.rho), float(ray.eta), float(ray.delta))
+        o = OptionsC()
+        self._lib.dmi_default_options(ctypes.byref(o))
+        o.device = device
+        o.grid_dtype = {"f32": DMI_F32, "f64": DMI_F64}[grid_dtype]
+        o.depth_storage = {"auto": DMI_DEPTH_AUTO, "f32": DMI_DEPTH_F32, "f64": DMI_DEPTH_F64}[depth_storage]
+        o.count_hits = 1 if count_hits else 0
+        o.kernel_variant = int(kernel_variant)
+        o.stream = stream
+        o.external_grid = external_grid
+        self.grid = grid
+        self.grid_dtype = grid_dtype
+        self.n_voxels = grid.n_voxels
+        rc = self._lib.dmi_create(ctypes.byref(g), ctypes.byref(r), ctypes.byref(o), ctypes.byref(self._h))
+        if rc != DMI_OK:
+            self._h = ctypes.c_void_p()
+            raise DmiError(rc, self._lib.dmi_last_error(None).decode())
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != DMI_OK:
+            raise DmiError(rc, self._lib.dmi_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dmi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- views ---------------------------------------------------------------------------------
+    def add_views(self, views: Views, threshold: float | None = None):
+        n, H, W = views.depth.shape
+        K4 = np.ascontiguousarray(views.K4, dtype=np.float64).reshape(n, 16)
+        RT4 = np.ascontiguousarray(views.RT4, dtype=np.float64).reshape(n, 16)
+        if views.depth.dtype == np.float32:
+            if views.best_cost is not None and threshold is not None:
+                raise ValueError("f32 depth upload takes already-thresholded depths")
+            d = np.ascontiguousarray(views.depth)
+            self._check(self._lib.dmi_add_views_f32(self._h, d.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                    _dp(K4), _dp(RT4), n, W, H))
+            return
+        d = np.ascontiguousarray(views.depth, dtype=np.float64)
+        bc = None
+        if views.best_cost is not None and threshold is not None:
+            bc = np.ascontiguousarray(views.best_cost, dtype=np.float64)
+        self._check(self._lib.dmi_add_views(self._h, _dp(d), _dp(bc) if bc is not None else None,
+                                            float(threshold) if threshold is not None else 0.0,
+                                            _dp(K4), _dp(RT4), n, W, H))
+
+    def clear_views(self):
+        self._check(self._lib.dmi_clear_views(self._h))
+
+    # -- grid ----------------------------------------------------------------------------------
+    def reset_grid(self):
+        self._check(self._lib.dmi_reset_grid(self._h))
+
+    def upload_grid(self, grid: np.ndarray):
+        g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1)
+        if g.size != self.n_voxels:
+            raise ValueError("grid size does not match the context")
+        self._check(self._lib.dmi_upload_grid(self._h, _dp(g)))
+
+    def fuse(self, first: int | None = None, count: int | None = None):
+        if first is None:
+            self._check(self._lib.dmi_fuse(self._h))
+        else:
+            self._check(self._lib.dmi_fuse_range(self._h, int(first), int(count)))
+
+    def synchronize(self):
+        self._check(self._lib.dmi_synchronize(self._h))
+
+    def download_grid(self, dtype=np.float64) -> np.ndarray:
+        nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        if np.dtype(dtype) == np.float64:
+            out = np.empty(self.n_voxels, dtype=np.float64)
+            self._check(self._lib.dmi_download_grid_f64(self._h, _dp(out)))
+        else:
+            out = np.empty(self.n_voxels, dtype=np.float32)
+            self._check(self._lib.dmi_download_grid_f32(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return out.reshape(nz, ny, nx)
+
+    def download_hits(self):
+        nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        vh = np.empty(self.n_voxels, dtype=np.uint32)
+        mh = np.empty(self.info().n_views, dtype=np.uint64)
+        self._check(self._lib.dmi_download_hits(self._h, vh.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                mh.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return vh.reshape(nz, ny, nx), mh
+
+    def grid_device_pointer(self) -> int:
+        p = ctypes.c_void_p()
+        self._check(self._lib.dmi_grid_device_pointer(self._h, ctypes.byref(p)))
+        return int(p.value)
+
+    def timings(self) -> TimingsC:
+        t = TimingsC()
+        self._check(self._lib.dmi_get_timings(self._h, ctypes.byref(t)))
+        return t
+
+    def info(self) -> InfoC:
+        i = InfoC()
+        self._check(self._lib.dmi_get_info(self._h, ctypes.byref(i)))
+        return i
+
+
+def fuse_once(grid: GridDesc, ray: RayPotential, views: Views, *, threshold: float | None = None,
+              init_grid: np.ndarray | None = None, count_hits: bool = True, **ctx_kwargs):
+    """create -> (upload grid) -> add views -> fuse -> download.  Returns (grid, voxel_hits, map_hits)."""
+    with FusionContext(grid, ray, count_hits=count_hits, **ctx_kwargs) as ctx:
+        if init_grid is not None:
+            ctx.upload_grid(init_grid)
+        ctx.add_views(views, threshold)
+        ctx.fuse()
+        out = ctx.download_grid(np.float64)
+        vh, mh = ctx.download_hits() if count_hits else (None, None)
+    return out, vh, mh

@@ -1,0 +1,695 @@
+// dmi_capi.hip -- implementation of the C ABI declared in include/dmi.h.
+//
+// Host-side driver of the fusion path: what CudaInitialize (cu:269-298) and ProcessDepthMap
+// (cu:302-386) do in the reference, minus the disk I/O and the VTK types.  No global state: everything
+// lives in the context (the reference keeps __constant__ symbols and ch_gridDims, cu:55-64).
+#include "../../include/dmi.h"
+#include "fusion_kernels.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using dmi::FuseArgs;
+using dmi::FuseConfig;
+using dmi::MapRec;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Batch {
+  void *d_depth = nullptr;  // n * W * H values of the context's current storage type
+  int32_t n = 0;
+};
+
+struct EventPair {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+
+constexpr double kMagnitudeLimit = 1e60;  // see DESIGN.md "K specialisation": keeps every product finite
+
+}  // namespace
+
+struct dmi_context {
+  dmi_grid_desc grid{};
+  dmi_ray_potential ray{};
+  dmi_options opt{};
+  int64_t n_voxels = 0;
+
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  void *d_grid = nullptr;
+  bool own_grid = false;
+  bool grid_is_zero = false;
+  bool zero_fill_pending = false;  // reset requested, memset deferred: the next fuse overwrites every voxel
+  uint32_t *d_voxel_hits = nullptr;
+  unsigned long long *d_map_hits = nullptr;
+  size_t map_hits_capacity = 0;
+
+  int32_t W = 0, H = 0;
+  bool depth_f64 = false;
+  bool finite_bounded = true;  // grid descriptor magnitudes allow the K shortcuts
+  int k_mode = dmi::K_PINHOLE;
+  std::vector<Batch> batches;
+  std::vector<MapRec> h_maps;
+  MapRec *d_maps = nullptr;
+  size_t d_maps_capacity = 0;
+  bool maps_dirty = false;
+
+  double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
+  size_t stage_capacity = 0;  // elements per staging buffer
+  unsigned long long *d_lossy = nullptr;
+
+  std::vector<EventPair> pending, pool;
+  dmi_timings timings{};
+  uint64_t device_bytes = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(dmi_context *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define DMI_HIP(ctx, call)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      (void)hipGetLastError();                                                                          \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_DEVICE,              \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                                   \
+    }                                                                                                   \
+  } while (0)
+
+size_t grid_elem(const dmi_context *c) { return c->opt.grid_dtype == DMI_F64 ? 8 : 4; }
+size_t depth_elem(const dmi_context *c) { return c->depth_f64 ? 8 : 4; }
+
+bool bounded(double v) { return std::isfinite(v) && std::fabs(v) <= kMagnitudeLimit; }
+
+int classify_k(const double *K, const double *RT) {
+  for (int i = 0; i < 12; ++i)
+    if (!bounded(K[i]) || !bounded(RT[i])) return dmi::K_GENERAL;
+  const bool pinhole = K[3] == 0 && K[7] == 0 && K[11] == 0 && K[4] == 0 && K[8] == 0 && K[9] == 0 && K[10] == 1;
+  if (!pinhole) return dmi::K_GENERAL;
+  return K[1] == 0 ? dmi::K_PINHOLE : dmi::K_PINHOLE_SKEW;
+}
+
+int drain_events(dmi_context *ctx) {
+  for (EventPair &p : ctx->pending) {
+    DMI_HIP(ctx, hipEventSynchronize(p.stop));
+    float ms = 0.f;
+    DMI_HIP(ctx, hipEventElapsedTime(&ms, p.start, p.stop));
+    ctx->timings.last_fuse_kernel_ms = ms;
+    ctx->timings.total_fuse_kernel_ms += ms;
+    ctx->timings.fuse_launches += 1;
+    ctx->pool.push_back(p);
+  }
+  ctx->pending.clear();
+  return DMI_OK;
+}
+
+int ensure_stage(dmi_context *ctx, size_t elems, bool need_cost) {
+  if (ctx->stage_capacity < elems) {
+    if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
+    if (ctx->d_stage_cost) (void)hipFree(ctx->d_stage_cost);
+    ctx->device_bytes -= (ctx->d_stage_depth ? ctx->stage_capacity * 8 : 0) + (ctx->d_stage_cost ? ctx->stage_capacity * 8 : 0);
+    ctx->d_stage_depth = ctx->d_stage_cost = nullptr;
+    ctx->stage_capacity = 0;
+    DMI_HIP(ctx, hipMalloc(&ctx->d_stage_depth, elems * 8));
+    ctx->stage_capacity = elems;
+    ctx->device_bytes += elems * 8;
+  }
+  if (need_cost && !ctx->d_stage_cost) {
+    DMI_HIP(ctx, hipMalloc(&ctx->d_stage_cost, ctx->stage_capacity * 8));
+    ctx->device_bytes += ctx->stage_capacity * 8;
+  }
+  return DMI_OK;
+}
+
+// Converts the whole store to f64 (AUTO promotion).  f32 -> f64 is exact.
+int promote_to_f64(dmi_context *ctx) {
+  const size_t npix = (size_t)ctx->W * ctx->H;
+  size_t map_index = 0;
+  for (Batch &b : ctx->batches) {
+    double *wide = nullptr;
+    DMI_HIP(ctx, hipMalloc(&wide, npix * b.n * 8));
+    DMI_HIP(ctx, dmi::launch_widen_depth(static_cast<const float *>(b.d_depth), wide, (int64_t)npix * b.n, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(b.d_depth);
+    ctx->device_bytes += npix * b.n * 4;
+    b.d_depth = wide;
+    for (int i = 0; i < b.n; ++i) ctx->h_maps[map_index + i].depth = wide + npix * i;
+    map_index += b.n;
+  }
+  ctx->depth_f64 = true;
+  ctx->maps_dirty = true;
+  return DMI_OK;
+}
+
+// Uploads n maps (host f64 or f32) into a new batch buffer of the current storage type.
+// Returns the number of lossy f32 conversions through *lossy_out.
+int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, const double *best_cost,
+                 double threshold, int32_t n, Batch *out, unsigned long long *lossy_out) {
+  const size_t npix = (size_t)ctx->W * ctx->H;
+  const size_t esz = depth_elem(ctx);
+  Batch b;
+  b.n = n;
+  DMI_HIP(ctx, hipMalloc(&b.d_depth, npix * n * esz));
+  ctx->device_bytes += npix * n * esz;
+  *lossy_out = 0;
+  int rc = DMI_OK;
+  if (depth32 != nullptr && !ctx->depth_f64) {
+    // f32 in, f32 store: plain copy
+    hipError_t e = hipMemcpyAsync(b.d_depth, depth32, npix * n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
+  } else if (depth32 != nullptr) {
+    // f32 in, f64 store: stage the floats at the end of the buffer's own tail is not possible; use a temp
+    float *tmp = nullptr;
+    hipError_t e = hipMalloc(&tmp, npix * n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, depth32, npix * n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = dmi::launch_widen_depth(tmp, static_cast<double *>(b.d_depth), (int64_t)npix * n, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
+  } else {
+    // f64 in: stage <= 256 MiB of maps at a time, fuse threshold + narrowing into one pass
+    const size_t maps_per_chunk = std::max<size_t>(1, (size_t(256) << 20) / (npix * 8));
+    const size_t chunk = std::min<size_t>(maps_per_chunk, (size_t)n);
+    rc = ensure_stage(ctx, chunk * npix, best_cost != nullptr);
+    if (rc == DMI_OK) {
+      hipError_t e = hipMemsetAsync(ctx->d_lossy, 0, sizeof(unsigned long long), ctx->stream);
+      for (size_t m0 = 0; e == hipSuccess && m0 < (size_t)n; m0 += chunk) {
+        const size_t cnt = std::min(chunk, (size_t)n - m0);
+        e = hipMemcpyAsync(ctx->d_stage_depth, depth64 + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && best_cost)
+          e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+          e = dmi::launch_convert_depth(ctx->d_stage_depth, best_cost ? ctx->d_stage_cost : nullptr, threshold,
+                                        static_cast<char *>(b.d_depth) + m0 * npix * esz, ctx->depth_f64 ? 1 : 0,
+                                        (int64_t)(cnt * npix), ctx->d_lossy, ctx->stream);
+      }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
+    }
+  }
+  if (rc != DMI_OK) {
+    (void)hipFree(b.d_depth);
+    ctx->device_bytes -= npix * n * esz;
+    return rc;
+  }
+  *out = b;
+  return DMI_OK;
+}
+
+int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32, const double *best_cost,
+                   double threshold, const double *K4, const double *RT4, int32_t n, int32_t width, int32_t height) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  if ((!depth64 && !depth32) || !K4 || !RT4) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_add_views: null pointer");
+  if (n <= 0) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_add_views: n must be positive");
+  if (width < 1 || height < 1 || width > 32768 || height > 32768)
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_add_views: depth-map dimensions must be in [1, 32768]");
+  if (!ctx->batches.empty() && (width != ctx->W || height != ctx->H))
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_add_views: every view of a context must share width and height");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (ctx->batches.empty()) {
+    ctx->W = width;
+    ctx->H = height;
+    ctx->depth_f64 = ctx->opt.depth_storage == DMI_DEPTH_F64;
+    ctx->k_mode = ctx->finite_bounded ? (int)dmi::K_PINHOLE : (int)dmi::K_GENERAL;
+  }
+  const size_t npix = (size_t)width * height;
+
+  Batch b;
+  unsigned long long lossy = 0;
+  int rc = upload_batch(ctx, depth64, depth32, best_cost, threshold, n, &b, &lossy);
+  if (rc != DMI_OK) return rc;
+  if (lossy != 0 && !ctx->depth_f64 && ctx->opt.depth_storage == DMI_DEPTH_AUTO) {
+    // some depth is not an f32: keep every bit -> promote the whole store and redo this batch in f64
+    (void)hipFree(b.d_depth);
+    ctx->device_bytes -= npix * n * 4;
+    rc = promote_to_f64(ctx);
+    if (rc != DMI_OK) return rc;
+    rc = upload_batch(ctx, depth64, depth32, best_cost, threshold, n, &b, &lossy);
+    if (rc != DMI_OK) return rc;
+  }
+  ctx->batches.push_back(b);
+  const size_t esz = depth_elem(ctx);
+  for (int32_t m = 0; m < n; ++m) {
+    MapRec r;
+    std::memset(&r, 0, sizeof(r));
+    // rows 0..2 of the row-major 4x4s (cu:220-230 marshals all 16; the kernel reads 12, cu:90-92)
+    std::memcpy(r.rt, RT4 + 16 * (size_t)m, 12 * sizeof(double));
+    std::memcpy(r.k, K4 + 16 * (size_t)m, 12 * sizeof(double));
+    r.depth = static_cast<const char *>(b.d_depth) + (size_t)m * npix * esz;
+    ctx->h_maps.push_back(r);
+    const int km = classify_k(r.k, r.rt);
+    if (km < ctx->k_mode) ctx->k_mode = km;
+  }
+  ctx->maps_dirty = true;
+  ctx->timings.last_upload_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return DMI_OK;
+}
+
+int flush_zero_fill(dmi_context *ctx) {
+  if (ctx->zero_fill_pending) {
+    DMI_HIP(ctx, hipMemsetAsync(ctx->d_grid, 0, ctx->n_voxels * grid_elem(ctx), ctx->stream));
+    ctx->zero_fill_pending = false;
+  }
+  return DMI_OK;
+}
+
+int sync_maps(dmi_context *ctx) {
+  const size_t n = ctx->h_maps.size();
+  if (ctx->d_maps_capacity < n) {
+    if (ctx->d_maps) (void)hipFree(ctx->d_maps);
+    ctx->d_maps = nullptr;
+    size_t cap = std::max<size_t>(64, n * 2);
+    DMI_HIP(ctx, hipMalloc(&ctx->d_maps, cap * sizeof(MapRec)));
+    ctx->device_bytes += (cap - ctx->d_maps_capacity) * sizeof(MapRec);
+    ctx->d_maps_capacity = cap;
+  }
+  if (ctx->opt.count_hits && ctx->map_hits_capacity < n) {
+    // grow, keeping the counts gathered so far
+    size_t cap = std::max<size_t>(64, n * 2);
+    unsigned long long *grown = nullptr;
+    DMI_HIP(ctx, hipMalloc(&grown, cap * sizeof(unsigned long long)));
+    DMI_HIP(ctx, hipMemsetAsync(grown, 0, cap * sizeof(unsigned long long), ctx->stream));
+    if (ctx->d_map_hits) {
+      DMI_HIP(ctx, hipMemcpyAsync(grown, ctx->d_map_hits, ctx->map_hits_capacity * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+      DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->d_map_hits);
+    }
+    ctx->device_bytes += (cap - ctx->map_hits_capacity) * sizeof(unsigned long long);
+    ctx->d_map_hits = grown;
+    ctx->map_hits_capacity = cap;
+  }
+  if (ctx->maps_dirty) {
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_maps, ctx->h_maps.data(), n * sizeof(MapRec), hipMemcpyHostToDevice, ctx->stream));
+    // h_maps is pageable: the copy above is complete for the host when it returns
+    ctx->maps_dirty = false;
+  }
+  return DMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmi_abi_version(void) { return DMI_ABI_VERSION; }
+
+int dmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+void dmi_default_options(dmi_options *opt) {
+  if (!opt) return;
+  std::memset(opt, 0, sizeof(*opt));
+  opt->device = 0;
+  opt->grid_dtype = DMI_F64;
+  opt->depth_storage = DMI_DEPTH_AUTO;
+}
+
+const char *dmi_last_error(const dmi_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dmi_options *opt, dmi_context **out) {
+  auto bad = [](const char *m) {
+    g_create_error = m;
+    return (int)DMI_ERR_INVALID_ARGUMENT;
+  };
+  if (!grid || !ray || !out) return bad("dmi_create: null argument");
+  *out = nullptr;
+  for (int a = 0; a < 3; ++a)
+    if (grid->cell_dims[a] < 1) return bad("dmi_create: cell_dims must be >= 1 (vtk point dims >= 2)");
+  dmi_options o;
+  dmi_default_options(&o);
+  if (opt) o = *opt;
+  if (o.grid_dtype != DMI_F32 && o.grid_dtype != DMI_F64) return bad("dmi_create: grid_dtype must be DMI_F32 or DMI_F64");
+  if (o.depth_storage < DMI_DEPTH_AUTO || o.depth_storage > DMI_DEPTH_F64) return bad("dmi_create: bad depth_storage");
+  // the reference refuses only rho == 0 && thickness == 0 (filt.cxx:138-142); so do we
+  if (ray->rho == 0 && ray->thickness == 0) return bad("dmi_create: ray potential rho and thickness are both 0 (filt.cxx:138)");
+  if ((int64_t)(grid->cell_dims[1] + 3) / 4 > 65535 || (int64_t)grid->cell_dims[2] > 65535)
+    return bad("dmi_create: grid too large for one launch (ny <= 262140, nz <= 65535)");
+  int ndev = dmi_device_count();
+  if (ndev <= 0) return (g_create_error = "dmi_create: no HIP device available", (int)DMI_ERR_DEVICE);
+  if (o.device < 0 || o.device >= ndev) return bad("dmi_create: device ordinal out of range");
+
+  dmi_context *ctx = new (std::nothrow) dmi_context();
+  if (!ctx) return (g_create_error = "dmi_create: host allocation failed", (int)DMI_ERR_OUT_OF_MEMORY);
+  ctx->grid = *grid;
+  ctx->ray = *ray;
+  ctx->opt = o;
+  ctx->n_voxels = (int64_t)grid->cell_dims[0] * grid->cell_dims[1] * grid->cell_dims[2];
+  ctx->finite_bounded = true;
+  for (int i = 0; i < 12; ++i) ctx->finite_bounded = ctx->finite_bounded && bounded(grid->grid_matrix[i]);
+  for (int a = 0; a < 3; ++a)
+    ctx->finite_bounded = ctx->finite_bounded && bounded(grid->origin[a]) &&
+                          bounded(grid->spacing[a] * (grid->cell_dims[a] + 1.0));
+
+  auto hip_fail = [&](hipError_t e, const char *what) {
+    (void)hipGetLastError();
+    g_create_error = std::string("dmi_create: ") + what + ": " + hipGetErrorString(e);
+    int code = e == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_DEVICE;
+    dmi_destroy(ctx);
+    return code;
+  };
+  hipError_t e = hipSetDevice(o.device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  if (o.stream) {
+    ctx->stream = static_cast<hipStream_t>(o.stream);
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    ctx->own_stream = true;
+  }
+  if (o.external_grid) {
+    hipPointerAttribute_t attr;
+    e = hipPointerGetAttributes(&attr, o.external_grid);
+    if (e != hipSuccess || attr.type != hipMemoryTypeDevice) {
+      (void)hipGetLastError();
+      g_create_error = "dmi_create: external_grid is not a device pointer";
+      dmi_destroy(ctx);
+      return DMI_ERR_INVALID_ARGUMENT;
+    }
+    ctx->d_grid = o.external_grid;
+  } else {
+    e = hipMalloc(&ctx->d_grid, ctx->n_voxels * grid_elem(ctx));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(grid)");
+    ctx->own_grid = true;
+    ctx->device_bytes += ctx->n_voxels * grid_elem(ctx);
+  }
+  if (o.count_hits) {
+    e = hipMalloc(&ctx->d_voxel_hits, ctx->n_voxels * sizeof(uint32_t));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(voxel_hits)");
+    ctx->device_bytes += ctx->n_voxels * sizeof(uint32_t);
+  }
+  e = hipMalloc(&ctx->d_lossy, sizeof(unsigned long long));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(lossy)");
+  int rc = dmi_reset_grid(ctx);
+  if (rc != DMI_OK) {
+    g_create_error = ctx->err;
+    dmi_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return DMI_OK;
+}
+
+void dmi_destroy(dmi_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->opt.device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (Batch &b : ctx->batches) (void)hipFree(b.d_depth);
+  for (EventPair &p : ctx->pending) {
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  for (EventPair &p : ctx->pool) {
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  if (ctx->own_grid && ctx->d_grid) (void)hipFree(ctx->d_grid);
+  if (ctx->d_voxel_hits) (void)hipFree(ctx->d_voxel_hits);
+  if (ctx->d_map_hits) (void)hipFree(ctx->d_map_hits);
+  if (ctx->d_maps) (void)hipFree(ctx->d_maps);
+  if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
+  if (ctx->d_stage_cost) (void)hipFree(ctx->d_stage_cost);
+  if (ctx->d_lossy) (void)hipFree(ctx->d_lossy);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int dmi_add_views(dmi_context *ctx, const double *depth, const double *best_cost, double threshold, const double *K4,
+                  const double *RT4, int32_t n, int32_t width, int32_t height) {
+  return add_views_impl(ctx, depth, nullptr, best_cost, threshold, K4, RT4, n, width, height);
+}
+
+int dmi_add_views_f32(dmi_context *ctx, const float *depth, const double *K4, const double *RT4, int32_t n,
+                      int32_t width, int32_t height) {
+  return add_views_impl(ctx, nullptr, depth, nullptr, 0.0, K4, RT4, n, width, height);
+}
+
+int dmi_clear_views(dmi_context *ctx) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t npix = (size_t)ctx->W * ctx->H;
+  for (Batch &b : ctx->batches) {
+    (void)hipFree(b.d_depth);
+    ctx->device_bytes -= npix * b.n * depth_elem(ctx);
+  }
+  ctx->batches.clear();
+  ctx->h_maps.clear();
+  ctx->maps_dirty = true;
+  ctx->W = ctx->H = 0;
+  return DMI_OK;
+}
+
+int dmi_reset_grid(dmi_context *ctx) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  // The fusion kernel writes every voxel and skips the read when the grid is known to be zero, so
+  // a context-owned grid is only memset if something reads it before the next fuse.
+  if (ctx->own_grid) {
+    ctx->zero_fill_pending = true;
+  } else {
+    DMI_HIP(ctx, hipMemsetAsync(ctx->d_grid, 0, ctx->n_voxels * grid_elem(ctx), ctx->stream));
+  }
+  if (ctx->d_voxel_hits) DMI_HIP(ctx, hipMemsetAsync(ctx->d_voxel_hits, 0, ctx->n_voxels * sizeof(uint32_t), ctx->stream));
+  if (ctx->d_map_hits)
+    DMI_HIP(ctx, hipMemsetAsync(ctx->d_map_hits, 0, ctx->map_hits_capacity * sizeof(unsigned long long), ctx->stream));
+  ctx->grid_is_zero = true;
+  return DMI_OK;
+}
+
+int dmi_upload_grid(dmi_context *ctx, const double *grid) {
+  if (!ctx || !grid) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_upload_grid: null argument");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  ctx->zero_fill_pending = false;
+  if (ctx->opt.grid_dtype == DMI_F64) {
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_grid, grid, ctx->n_voxels * 8, hipMemcpyHostToDevice, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    std::vector<float> narrow((size_t)ctx->n_voxels);
+    for (int64_t i = 0; i < ctx->n_voxels; ++i) narrow[(size_t)i] = (float)grid[i];
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_grid, narrow.data(), ctx->n_voxels * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->grid_is_zero = false;
+  return DMI_OK;
+}
+
+int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  const int32_t n_views = (int32_t)ctx->h_maps.size();
+  if (n_views == 0) return fail(ctx, DMI_ERR_STATE, "dmi_fuse: no views resident (call dmi_add_views first)");
+  if (first < 0 || count < 0 || first > n_views || count > n_views - first)
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range: range outside the resident views");
+  if (count == 0) return DMI_OK;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  int rc = sync_maps(ctx);
+  if (rc != DMI_OK) return rc;
+
+  FuseArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.nx = ctx->grid.cell_dims[0];
+  a.ny = ctx->grid.cell_dims[1];
+  a.nz = ctx->grid.cell_dims[2];
+  a.W = ctx->W;
+  a.H = ctx->H;
+  a.first_map = first;
+  a.n_maps = count;
+  a.init_from_grid = ctx->grid_is_zero ? 0 : 1;
+  a.ox = ctx->grid.origin[0];
+  a.oy = ctx->grid.origin[1];
+  a.oz = ctx->grid.origin[2];
+  a.sx = ctx->grid.spacing[0];
+  a.sy = ctx->grid.spacing[1];
+  a.sz = ctx->grid.spacing[2];
+  std::memcpy(a.g, ctx->grid.grid_matrix, 12 * sizeof(double));
+  a.thick = ctx->ray.thickness;
+  a.delta = ctx->ray.delta;
+  a.rho_pos = ctx->ray.rho * 1.0;    // rho * sign, sign = +1 (cu:112,117)
+  a.rho_neg = ctx->ray.rho * -1.0;   // sign = -1
+  a.rho_zero = ctx->ray.rho * 0.0;   // sign = 0 (diff == 0 on the plateau branch: only if thickness < 0)
+  a.slope = ctx->ray.rho / ctx->ray.thickness;  // cu:119
+  a.free_space = -ctx->ray.eta * ctx->ray.rho;  // cu:115
+  a.maps = ctx->d_maps;
+  a.grid = ctx->d_grid;
+  a.voxel_hits = ctx->d_voxel_hits;
+  a.map_hits = ctx->d_map_hits;
+
+  FuseConfig cfg;
+  cfg.depth_is_f64 = ctx->depth_f64 ? 1 : 0;
+  cfg.grid_is_f64 = ctx->opt.grid_dtype == DMI_F64 ? 1 : 0;
+  cfg.k_mode = ctx->k_mode;
+  cfg.count_hits = ctx->opt.count_hits ? 1 : 0;
+  cfg.variant = ctx->opt.kernel_variant;
+
+  EventPair ev;
+  if (!ctx->pool.empty()) {
+    ev = ctx->pool.back();
+    ctx->pool.pop_back();
+  } else {
+    DMI_HIP(ctx, hipEventCreate(&ev.start));
+    DMI_HIP(ctx, hipEventCreate(&ev.stop));
+  }
+  DMI_HIP(ctx, hipEventRecord(ev.start, ctx->stream));
+  hipError_t e = dmi::launch_fuse(a, cfg, ctx->stream);
+  if (e != hipSuccess) {
+    ctx->pool.push_back(ev);
+    (void)hipGetLastError();
+    return fail(ctx, DMI_ERR_DEVICE, std::string("fusion kernel launch: ") + hipGetErrorString(e));
+  }
+  DMI_HIP(ctx, hipEventRecord(ev.stop, ctx->stream));
+  ctx->pending.push_back(ev);
+  ctx->grid_is_zero = false;
+  ctx->zero_fill_pending = false;  // every voxel was just written
+  if (ctx->pending.size() >= 256) return drain_events(ctx);
+  return DMI_OK;
+}
+
+int dmi_fuse(dmi_context *ctx) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  return dmi_fuse_range(ctx, 0, (int32_t)ctx->h_maps.size());
+}
+
+int dmi_synchronize(dmi_context *ctx) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return drain_events(ctx);
+}
+
+int dmi_download_grid_f64(dmi_context *ctx, double *out) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_download_grid_f64: null argument");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  { int rc_ = flush_zero_fill(ctx); if (rc_ != DMI_OK) return rc_; }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (ctx->opt.grid_dtype == DMI_F64) {
+    // one bulk copy instead of the reference's per-tuple SetTuple1 loop (cu:256-264)
+    DMI_HIP(ctx, hipMemcpyAsync(out, ctx->d_grid, ctx->n_voxels * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    std::vector<float> tmp((size_t)ctx->n_voxels);
+    DMI_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->d_grid, ctx->n_voxels * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < ctx->n_voxels; ++i) out[i] = (double)tmp[(size_t)i];
+  }
+  ctx->timings.last_download_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return drain_events(ctx);
+}
+
+int dmi_download_grid_f32(dmi_context *ctx, float *out) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_download_grid_f32: null argument");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  { int rc_ = flush_zero_fill(ctx); if (rc_ != DMI_OK) return rc_; }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (ctx->opt.grid_dtype == DMI_F32) {
+    DMI_HIP(ctx, hipMemcpyAsync(out, ctx->d_grid, ctx->n_voxels * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    std::vector<double> tmp((size_t)ctx->n_voxels);
+    DMI_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->d_grid, ctx->n_voxels * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < ctx->n_voxels; ++i) out[i] = (float)tmp[(size_t)i];
+  }
+  ctx->timings.last_download_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return drain_events(ctx);
+}
+
+int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  if (!ctx->opt.count_hits) return fail(ctx, DMI_ERR_STATE, "dmi_download_hits: context created without count_hits");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  if (voxel_hits)
+    DMI_HIP(ctx, hipMemcpyAsync(voxel_hits, ctx->d_voxel_hits, ctx->n_voxels * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  if (map_hits) {
+    const size_t n = ctx->h_maps.size();
+    if (n > 0 && ctx->d_map_hits && ctx->map_hits_capacity >= n) {
+      static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "u64");
+      DMI_HIP(ctx, hipMemcpyAsync(map_hits, ctx->d_map_hits, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      for (size_t i = 0; i < n; ++i) map_hits[i] = 0;
+    }
+  }
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return drain_events(ctx);
+}
+
+int dmi_grid_device_pointer(dmi_context *ctx, void **ptr) {
+  if (!ctx || !ptr) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_grid_device_pointer: null argument");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  int rc = flush_zero_fill(ctx);
+  if (rc != DMI_OK) return rc;
+  *ptr = ctx->d_grid;
+  return DMI_OK;
+}
+
+int dmi_get_timings(dmi_context *ctx, dmi_timings *out) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_timings: null argument");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  int rc = drain_events(ctx);
+  if (rc != DMI_OK) return rc;
+  *out = ctx->timings;
+  return DMI_OK;
+}
+
+int dmi_get_info(dmi_context *ctx, dmi_info *out) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_info: null argument");
+  std::memset(out, 0, sizeof(*out));
+  out->n_voxels = ctx->n_voxels;
+  out->n_views = (int32_t)ctx->h_maps.size();
+  out->depth_width = ctx->W;
+  out->depth_height = ctx->H;
+  out->depth_storage_in_use = ctx->depth_f64 ? DMI_DEPTH_F64 : DMI_DEPTH_F32;
+  out->grid_dtype = ctx->opt.grid_dtype;
+  out->k_mode = (ctx->opt.kernel_variant & 2) ? 0 : ctx->k_mode;
+  out->kernel_variant = ctx->opt.kernel_variant;
+  out->device_bytes = ctx->device_bytes;
+  return DMI_OK;
+}
+
+int dmi_alloc_pinned(size_t bytes, void **out) {
+  if (!out || bytes == 0) return DMI_ERR_INVALID_ARGUMENT;
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_create_error = std::string("dmi_alloc_pinned: ") + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_DEVICE;
+  }
+  return DMI_OK;
+}
+
+int dmi_free_pinned(void *ptr) {
+  if (!ptr) return DMI_OK;
+  hipError_t e = hipHostFree(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return DMI_ERR_DEVICE;
+  }
+  return DMI_OK;
+}
+
+}  // extern "C"

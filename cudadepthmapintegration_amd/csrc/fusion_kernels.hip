@@ -1,0 +1,268 @@
+// fusion_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the TSDF depth-map fusion path.
+//
+// What the reference does (Reconstruction/CudaReconstruction.cu:158-212, launched once per depth
+// map at cu:363): one thread per voxel projects the voxel centre into ONE depth map and does a
+// read-modify-write of the fp64 grid, so the whole grid crosses HBM twice per depth map.
+//
+// What this kernel does instead (voxel-stationary): one lane owns one voxel for the whole fusion,
+// loops over every resident depth map, keeps the running sum in an fp64 register and writes the
+// grid once.  A wavefront is 64 consecutive voxels along x, so the final store is one contiguous
+// 256 B (f32) / 512 B (f64) segment per wave.  The per-map camera record (MapRec) is indexed by
+// the wave-uniform loop counter, so it arrives through the scalar cache into SGPRs and feeds the
+// fp64 VALU directly as scalar operands.  The only per-lane memory access in the loop is the
+// depth gather, served by L1/L2/Infinity Cache (a depth map is re-read by many voxels).
+//
+// Arithmetic contract: IEEE fp64, the reference's expression order, no FMA contraction in any value
+// that reaches the result (this file is compiled with -ffp-contract=off; the explicit fma() calls
+// below only feed a self-checked reciprocal that selects WHICH exact code path runs).  The grid is
+// therefore bit-identical to oracle/tsdf_oracle.c.
+#include "fusion_kernels.h"
+
+namespace dmi {
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ---- rows 0..2 of a row-major 4x4 times [p,1], exactly as cu:90-92: ((m0*x + m1*y) + m2*z) + m3
+__device__ __forceinline__ double row4(const double *__restrict__ m, double x, double y, double z) {
+  return ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+}
+
+// ---- rayPotential<double>, cu:105-120 --------------------------------------------------------
+// sign = diff != 0 ? (int)(diff/|diff|) : 0 is +1, -1 or 0 and rho*sign one of three host-computed
+// products (FuseArgs::rho_pos / rho_neg / rho_zero), so no division is needed on the device.
+__device__ __forceinline__ double ray_potential(const FuseArgs &a, double real_depth, double depth) {
+  const double diff = real_depth - depth;  // cu:108
+  const double ad = fabs(diff);            // cu:110
+  const double far_value = diff > 0 ? 0.0 : a.free_space;                               // cu:115
+  const double plateau = diff > 0 ? a.rho_pos : (diff < 0 ? a.rho_neg : a.rho_zero);    // cu:112,117
+  const double ramp = a.slope * diff;                                                   // cu:119
+  return ad > a.delta ? far_value : (ad > a.thick ? plateau : ramp);                    // cu:114-119
+}
+
+// ---- exact pixel decision: the reference's divide + round + bounds test (cu:177-197) ---------
+// NaN, +-inf and |round| >= 2^31 are out of the map (project rule, see oracle/tsdf_oracle.c).
+__device__ __forceinline__ bool pixel_exact(double hx, double hy, double hz, int W, int H, int &px, int &py) {
+  if (hz < 0) return false;         // cu:177
+  const double u = hx / hz;         // cu:183 (correctly rounded fp64 division)
+  const double v = hy / hz;         // cu:184
+  const double ru = round(u);       // cu:187 half away from zero
+  const double rv = round(v);       // cu:188
+  // fp64 form of cu:192-197; false for NaN.  -0.0 >= 0 holds and converts to pixel 0.
+  if (!(ru >= 0.0 && rv >= 0.0 && ru < (double)W && rv < (double)H)) return false;
+  px = (int)ru;
+  py = (int)rv;
+  return true;
+}
+
+// ---- fast pixel decision ----------------------------------------------------------------------
+// u = hx/hz only matters through round(u): every decision boundary is a half-integer of u.  The
+// fast path multiplies by a Newton-refined reciprocal whose residual it CHECKS (|1 - hz*r| < 2^-40,
+// so |ua - u| <= |u| * 2^-38 whatever v_rcp_f64's accuracy is), and accepts its answer only when
+//   (a) ua is outside [-1, W] (then u is certainly outside [-0.5, W-0.5)), or
+//   (b) ua + 0.5 is farther than 2^-20 from an integer (then floor(ua + 0.5) == round(u), because
+//       the total error is below 2^-21 for W, H <= 32768).
+// Anything else -- including NaN/inf, hz ~ 0, exact halves -- is `undecided` and re-done by
+// pixel_exact().  Returns: 1 in (px,py valid), 0 out, -1 undecided.
+__device__ __forceinline__ int pixel_fast(double hx, double hy, double hz, int W, int H, int &px, int &py) {
+  if (hz < 0) return 0;  // cu:177, exact compare
+  double r = __builtin_amdgcn_rcp(hz);
+  double e = __builtin_fma(-hz, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-hz, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double resid = __builtin_fma(-hz, r, 1.0);
+  if (!(fabs(resid) < 0x1p-40)) return -1;  // also catches NaN / inf / overflowed reciprocal
+  const double ua = hx * r;
+  const double va = hy * r;
+  // certainly outside: no exactness needed (NaN compares false and falls through)
+  if (ua < -1.0 || va < -1.0 || ua > (double)W || va > (double)H) return 0;
+  const double tu = ua + 0.5, tv = va + 0.5;
+  const double fu = floor(tu), fv = floor(tv);
+  const double du = tu - fu, dv = tv - fv;
+  constexpr double tau = 0x1p-20;
+  if (!(du > tau && du < 1.0 - tau && dv > tau && dv < 1.0 - tau)) return -1;
+  if (!(fu >= 0.0 && fv >= 0.0 && fu < (double)W && fv < (double)H)) return 0;
+  px = (int)fu;
+  py = (int)fv;
+  return 1;
+}
+
+template <typename DepthT, typename GridT, int KMODE, bool FAST, bool COUNT>
+__global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs a) {
+  // lane -> voxel: x is the wave dimension (cu:163 uses threadIdx.x for x as well)
+  const int i = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const bool inside = i < a.nx && j < a.ny && k < a.nz;
+
+  // cu:78-83 computeVoxelCenter, cu:168 grid matrix -- once per voxel instead of once per map
+  const double gx = a.ox + (i + 0.5) * a.sx;
+  const double gy = a.oy + (j + 0.5) * a.sy;
+  const double gz = a.oz + (k + 0.5) * a.sz;
+  const double wx = row4(a.g + 0, gx, gy, gz);
+  const double wy = row4(a.g + 4, gx, gy, gz);
+  const double wz = row4(a.g + 8, gx, gy, gz);
+
+  const int64_t gid = ((int64_t)k * a.ny + j) * a.nx + i;  // cu:126-134
+  GridT *__restrict__ grid = static_cast<GridT *>(a.grid);
+  double acc = 0.0;
+  if (a.init_from_grid && inside) acc = (double)grid[gid];  // cu:211 accumulates onto what is there
+  uint32_t nhit = 0;
+
+  const int m_end = a.first_map + a.n_maps;
+  for (int m = a.first_map; m < m_end; ++m) {
+    const MapRec *__restrict__ rec = a.maps + m;  // wave-uniform -> scalar loads
+    // cu:172 world -> camera
+    const double cx = row4(rec->rt + 0, wx, wy, wz);
+    const double cy = row4(rec->rt + 4, wx, wy, wz);
+    const double cz = row4(rec->rt + 8, wx, wy, wz);
+    // cu:176 camera -> homogeneous pixel
+    double hx, hy, hz;
+    if (KMODE == K_GENERAL) {
+      hx = row4(rec->k + 0, cx, cy, cz);
+      hy = row4(rec->k + 4, cx, cy, cz);
+      hz = row4(rec->k + 8, cx, cy, cz);
+    } else {
+      // K = [fx s cx0 0; 0 fy cy0 0; 0 0 1 0]: the dropped terms are products with an exact 0
+      // (value +-0 for finite operands) and additions of +-0, which change no non-zero value;
+      // a zero result can only change sign, which no later step observes.
+      if (KMODE == K_PINHOLE_SKEW)
+        hx = (rec->k[0] * cx + rec->k[1] * cy) + rec->k[2] * cz;
+      else
+        hx = rec->k[0] * cx + rec->k[2] * cz;
+      hy = rec->k[5] * cy + rec->k[6] * cz;
+      hz = cz;
+    }
+
+    int px = 0, py = 0;
+    bool in;
+    if (FAST) {
+      int s = inside ? pixel_fast(hx, hy, hz, a.W, a.H, px, py) : 0;
+      if (s < 0) s = pixel_exact(hx, hy, hz, a.W, a.H, px, py) ? 1 : 0;  // rare lanes only
+      in = s > 0;
+    } else {
+      in = inside && pixel_exact(hx, hy, hz, a.W, a.H, px, py);
+    }
+
+    bool hit = false;
+    if (in) {
+      const DepthT *__restrict__ dm = static_cast<const DepthT *>(rec->depth);
+      const double depth = (double)dm[a.W * (a.H - 1 - py) + px];  // cu:141-149, cu:201
+      if (depth != -1.0) {                                         // cu:202
+        acc += ray_potential(a, cz, depth);                        // cu:207-211
+        hit = true;
+      }
+    }
+    if (COUNT) {
+      nhit += hit ? 1u : 0u;
+      // wavefront ballot: one popcount per wave and map instead of 64 atomics
+      const unsigned long long b = __ballot(hit);
+      if (b != 0 && (threadIdx.x & (kWave - 1)) == 0) atomicAdd(&a.map_hits[m], (unsigned long long)__popcll(b));
+    }
+  }
+
+  if (inside) {
+    grid[gid] = (GridT)acc;
+    if (COUNT) a.voxel_hits[gid] += nhit;
+  }
+}
+
+template <typename DepthT, typename GridT, int KMODE, bool FAST>
+hipError_t launch_count(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim3 block, hipStream_t s) {
+  if (cfg.count_hits)
+    hipLaunchKernelGGL((fuse_kernel<DepthT, GridT, KMODE, FAST, true>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((fuse_kernel<DepthT, GridT, KMODE, FAST, false>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+template <typename DepthT, typename GridT, int KMODE>
+hipError_t launch_fast(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim3 block, hipStream_t s) {
+  if (cfg.variant & 1) return launch_count<DepthT, GridT, KMODE, false>(a, cfg, grid, block, s);
+  return launch_count<DepthT, GridT, KMODE, true>(a, cfg, grid, block, s);
+}
+
+template <typename DepthT, typename GridT>
+hipError_t launch_kmode(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim3 block, hipStream_t s) {
+  const int km = (cfg.variant & 2) ? (int)K_GENERAL : cfg.k_mode;
+  switch (km) {
+    case K_PINHOLE: return launch_fast<DepthT, GridT, K_PINHOLE>(a, cfg, grid, block, s);
+    case K_PINHOLE_SKEW: return launch_fast<DepthT, GridT, K_PINHOLE_SKEW>(a, cfg, grid, block, s);
+    default: return launch_fast<DepthT, GridT, K_GENERAL>(a, cfg, grid, block, s);
+  }
+}
+
+// ---- depth upload: threshold + optional narrowing ------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void convert_depth_kernel(const double *__restrict__ in,
+                                                            const double *__restrict__ best_cost, double thr,
+                                                            OutT *__restrict__ out, int64_t n,
+                                                            unsigned long long *__restrict__ lossy) {
+  unsigned int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double d = in[i];
+    if (best_cost != nullptr && best_cost[i] > thr) d = -1.0;  // RD.cxx:159-166
+    const OutT o = (OutT)d;
+    // bit compare so that a NaN depth round-trips instead of flagging a lossy conversion forever
+    if (sizeof(OutT) == 4) {
+      const double back = (double)o;
+      bad += (__double_as_longlong(back) != __double_as_longlong(d)) && !(d != d);
+    }
+    out[i] = o;
+  }
+  if (sizeof(OutT) == 4 && bad != 0) atomicAdd(lossy, (unsigned long long)bad);
+}
+
+__global__ __launch_bounds__(256) void widen_depth_kernel(const float *__restrict__ in, double *__restrict__ out,
+                                                          int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (double)in[i];
+}
+
+inline int blocks_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+hipError_t launch_fuse(const FuseArgs &a, const FuseConfig &cfg, hipStream_t stream) {
+  // block = 64 lanes along x times 4 rows; variant bits 2..3 pick how the 4 rows are laid out
+  dim3 block(kWave, 4, 1);
+  switch ((cfg.variant >> 2) & 3) {
+    case 1: block = dim3(kWave, 2, 2); break;
+    case 2: block = dim3(kWave, 1, 4); break;
+    case 3: block = dim3(kWave, 1, 1); break;
+    default: break;
+  }
+  dim3 grid((a.nx + kWave - 1) / kWave, (a.ny + block.y - 1) / block.y, (a.nz + block.z - 1) / block.z);
+  if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidConfiguration;
+  if (cfg.depth_is_f64) {
+    if (cfg.grid_is_f64) return launch_kmode<double, double>(a, cfg, grid, block, stream);
+    return launch_kmode<double, float>(a, cfg, grid, block, stream);
+  }
+  if (cfg.grid_is_f64) return launch_kmode<float, double>(a, cfg, grid, block, stream);
+  return launch_kmode<float, float>(a, cfg, grid, block, stream);
+}
+
+hipError_t launch_convert_depth(const double *in, const double *best_cost, double threshold, void *out,
+                                int out_is_f64, int64_t n, unsigned long long *lossy, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (out_is_f64)
+    hipLaunchKernelGGL((convert_depth_kernel<double>), dim3(blocks_for(n)), dim3(256), 0, stream, in, best_cost,
+                       threshold, static_cast<double *>(out), n, lossy);
+  else
+    hipLaunchKernelGGL((convert_depth_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, stream, in, best_cost,
+                       threshold, static_cast<float *>(out), n, lossy);
+  return hipGetLastError();
+}
+
+hipError_t launch_widen_depth(const float *in, double *out, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(widen_depth_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace dmi

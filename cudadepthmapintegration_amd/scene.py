@@ -140,7 +140,8 @@ def render_sphere_depth(K: np.ndarray, RT: np.ndarray, W: int, H: int, center=(0
 
 
 def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", dense: bool = False,
-               with_best_cost: bool = False, radius: float = 3.0, focal_scale: float = 0.9) -> Views:
+               with_best_cost: bool = False, radius: float = 3.0, focal_scale: float = 0.9,
+               dtype=np.float64) -> Views:
     """n cameras around the sphere scene.  dense=True adds a background at camera z = radius + 0.5
     so nearly every in-frustum voxel reaches the accumulate (hit rate ~100 % instead of ~30 %)."""
     K = np.eye(4)
@@ -149,7 +150,7 @@ def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", de
     K[1, 2] = H / 2.0
     pos = camera_positions(n, radius=radius, layout=layout)
     rng = np.random.default_rng(seed)
-    depth = np.empty((n, H, W), dtype=np.float64)
+    depth = np.empty((n, H, W), dtype=dtype)  # values are f32-representable either way
     K4 = np.empty((n, 4, 4))
     RT4 = np.empty((n, 4, 4))
     for m in range(n):

@@ -1,0 +1,187 @@
+/*
+ * dmi.h -- C ABI of the MI355X-native depth-map-integration (TSDF fusion) path.
+ *
+ * This is the drop-in boundary for ONE path of bastienjacquet/CudaDepthMapIntegration:
+ * the two free functions that vtkCudaReconstructionFilter forward-declares and calls
+ * (Reconstruction/vtkCudaReconstructionFilter.cxx:65-71, :171-176), defined in
+ * Reconstruction/CudaReconstruction.cu:
+ *
+ *     void CudaInitialize(vtkMatrix4x4*, int dims[3], double orig[3], double spacing[3],
+ *                         double thick, double rho, double eta, double delta, int depthDims[2]);   cu:269-298
+ *     template<class T> bool ProcessDepthMap(std::vector<std::string> vti, std::vector<std::string> krtd,
+ *                         double thresholdBestCost, vtkDoubleArray* io_scalar);                     cu:302-386
+ *
+ * Those take VTK objects and file names and do disk I/O inside the GPU loop.  Here the seam
+ * is split: the host side (VTK or the VTK-free mirror in cudadepthmapintegration_amd/csrc/host)
+ * loads or generates the views; this library only sees plain pointers and sizes.
+ *
+ * Conventions (all taken from the reference):
+ *   - the voxel grid is the CELL grid of the filter's input vtkImageData: cell_dims = point
+ *     dims - 1 (filt.cxx:123-124, cu:128-133, cu:330-331); linear voxel id = (k*ny + j)*nx + i,
+ *     x fastest (cu:126-134) = vtk cell-id order of the "reconstruction_scalar" array (filt.cxx:129-135);
+ *   - 4x4 matrices are row-major as vtkMatrix4x4 / cu:220-230; only rows 0..2 are used (cu:88-93);
+ *   - a depth table is W*H values in vtkImageData point order: row 0 is the BOTTOM image row
+ *     (cu:141-149); the value -1 means "no depth" (cu:202; Sources/ReconstructionData.cxx:164);
+ *   - arithmetic is IEEE fp64 in the reference's expression order, every multiply and add rounded
+ *     separately; results are bit-identical to oracle/tsdf_oracle.c on one GPU with an f64 grid.
+ *
+ * Every function returns DMI_OK (0) or a dmi_status error code and never calls exit()
+ * (the reference's gpuAssert does, cu:68-76).  dmi_last_error() gives the message.
+ * A context is not thread-safe; distinct contexts may be used from distinct threads
+ * (the reference keeps global __constant__ state, cu:55-64, and is not re-entrant).
+ */
+#ifndef DMI_H_
+#define DMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMI_ABI_VERSION 1
+
+typedef struct dmi_context dmi_context;
+
+typedef enum dmi_status {
+  DMI_OK = 0,
+  DMI_ERR_INVALID_ARGUMENT = 1,
+  DMI_ERR_DEVICE = 2, /* a HIP runtime call failed; message holds hipGetErrorString */
+  DMI_ERR_OUT_OF_MEMORY = 3,
+  DMI_ERR_STATE = 4 /* call order violated, e.g. fuse with no views */
+} dmi_status;
+
+typedef enum dmi_dtype { DMI_F32 = 0, DMI_F64 = 1 } dmi_dtype;
+
+/* How depth tables are kept in HBM.  AUTO keeps f32 while every uploaded depth is exactly
+ * representable in f32 (then f32 storage changes no result bit) and promotes the store to
+ * f64 the moment one is not. */
+typedef enum dmi_depth_storage { DMI_DEPTH_AUTO = 0, DMI_DEPTH_F32 = 1, DMI_DEPTH_F64 = 2 } dmi_depth_storage;
+
+/* Replaces the grid part of CudaInitialize's arguments (cu:269-272) = the reference's
+ * __constant__ c_gridMatrix / c_gridDims / c_gridOrig / c_gridSpacing (cu:55-58). */
+typedef struct dmi_grid_desc {
+  int32_t cell_dims[3];   /* voxels per axis (vtk point dims - 1) */
+  double origin[3];       /* vtkImageData origin (filt.cxx:121-122) */
+  double spacing[3];      /* vtkImageData spacing (filt.cxx:125-126) */
+  double grid_matrix[16]; /* row-major 4x4, rows = gridVecX/Y/Z (Reconstruction/main.cxx:345-359) */
+} dmi_grid_desc;
+
+/* Replaces c_rayPotentialThick/Rho/Eta/Delta (cu:60-63; CudaInitialize cu:273-276). */
+typedef struct dmi_ray_potential {
+  double thickness;
+  double rho;
+  double eta;
+  double delta;
+} dmi_ray_potential;
+
+typedef struct dmi_options {
+  int32_t device;         /* HIP device ordinal */
+  int32_t grid_dtype;     /* dmi_dtype of the device grid.  DMI_F64 = the reference's contract
+                             (ProcessDepthMap<double>, filt.cxx:175); DMI_F32 rounds once per fuse */
+  int32_t depth_storage;  /* dmi_depth_storage */
+  int32_t count_hits;     /* != 0: keep per-voxel u32 and per-map u64 hit counters (not a reference
+                             output; they expose every in-frustum / sentinel decision for parity) */
+  int32_t kernel_variant; /* 0 = default; other values select tuning variants */
+  int32_t reserved0;
+  void *stream;           /* hipStream_t to run on; NULL = a stream owned by the context */
+  void *external_grid;    /* device pointer to a caller-owned grid of grid_dtype[n_voxels]
+                             (e.g. a torch tensor that is later all-reduced); NULL = context-owned */
+} dmi_options;
+
+typedef struct dmi_timings {
+  double last_fuse_kernel_ms; /* hipEvent time of the fusion kernel of the last dmi_fuse, on its stream */
+  double total_fuse_kernel_ms;
+  uint64_t fuse_launches;
+  double last_upload_ms; /* host wall time of the last dmi_add_views (copy + convert, synchronised) */
+  double last_download_ms;
+} dmi_timings;
+
+typedef struct dmi_info {
+  int64_t n_voxels;
+  int32_t n_views;
+  int32_t depth_width;
+  int32_t depth_height;
+  int32_t depth_storage_in_use; /* DMI_DEPTH_F32 or DMI_DEPTH_F64 */
+  int32_t grid_dtype;
+  int32_t k_mode; /* 0 general 4x4 K rows, 1 pinhole with skew, 2 pinhole (chosen from the uploaded Ks) */
+  int32_t kernel_variant;
+  int32_t reserved0;
+  uint64_t device_bytes; /* HBM held by the context */
+} dmi_info;
+
+/* Fills *opt with the defaults: device 0, f64 grid, AUTO depth storage, no hit counters. */
+void dmi_default_options(dmi_options *opt);
+
+/* Replaces CudaInitialize (cu:269-298) and the grid cudaMalloc of ProcessDepthMap (cu:326).
+ * The grid starts zero-filled, as RequestData fills it (filt.cxx:133).  opt may be NULL. */
+int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dmi_options *opt, dmi_context **out);
+
+/* Replaces the cudaFree/delete block (cu:374-381). */
+void dmi_destroy(dmi_context *ctx);
+
+/* Message of the last failing call on ctx; ctx == NULL gives the calling thread's last
+ * dmi_create failure.  Never NULL.  Replaces gpuAssert's fprintf+exit (cu:68-76). */
+const char *dmi_last_error(const dmi_context *ctx);
+
+/* Replaces the per-depth-map body of ProcessDepthMap (cu:347-360): best-cost threshold
+ * (ReconstructionData::ApplyDepthThresholdFilter, RD.cxx:138-167: best_cost > threshold => depth = -1;
+ * skipped when best_cost == NULL), marshalling (cu:351-353) and the three H2D copies (cu:358-360).
+ * Appends n views; they stay resident in HBM until dmi_clear_views.
+ *   depth     [n][H][W] f64 host, vtk point order        ("Depths" array, cu:249)
+ *   best_cost [n][H][W] f64 host or NULL                 ("Best Cost Values", RD.cxx:146)
+ *   K4, RT4   [n][16]   f64 host, row-major 4x4          (Get4MatrixK / GetMatrixTR, RD.cxx:128-136)
+ * All views of a context share W and H (the reference reads them from map 0 only, filt.cxx:167-168). */
+int dmi_add_views(dmi_context *ctx, const double *depth, const double *best_cost, double threshold, const double *K4,
+                  const double *RT4, int32_t n, int32_t width, int32_t height);
+
+/* Same with f32 depth tables (already thresholded or best_cost given as f32 == NULL only). */
+int dmi_add_views_f32(dmi_context *ctx, const float *depth, const double *K4, const double *RT4, int32_t n,
+                      int32_t width, int32_t height);
+
+int dmi_clear_views(dmi_context *ctx);
+
+/* Zero the grid (and the hit counters): filt.cxx:133. */
+int dmi_reset_grid(dmi_context *ctx);
+
+/* Start from a caller-supplied grid, as ProcessDepthMap uploads io_scalar before accumulating
+ * onto it (cu:323-327).  grid: n_voxels f64 host, x fastest. */
+int dmi_upload_grid(dmi_context *ctx, const double *grid);
+
+/* Replaces the kernel launches of the depth-map loop (cu:363, one per map in the reference):
+ * fuses every resident view into the grid, each voxel accumulated in view order (cu:211).
+ * Asynchronous on the context's stream. */
+int dmi_fuse(dmi_context *ctx);
+
+/* Fuse only views [first, first+count): lets a caller shard or batch the resident views. */
+int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count);
+
+int dmi_synchronize(dmi_context *ctx);
+
+/* Replace the D2H copy and the per-tuple copy into io_scalar (cu:368-371).  They synchronise. */
+int dmi_download_grid_f64(dmi_context *ctx, double *out);
+int dmi_download_grid_f32(dmi_context *ctx, float *out);
+
+/* voxel_hits [n_voxels] u32 and/or map_hits [n_views] u64 (either may be NULL).
+ * Needs count_hits at creation. */
+int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits);
+
+/* Device pointer of the grid (context-owned or external) for zero-copy consumers. */
+int dmi_grid_device_pointer(dmi_context *ctx, void **ptr);
+
+int dmi_get_timings(dmi_context *ctx, dmi_timings *out);
+int dmi_get_info(dmi_context *ctx, dmi_info *out);
+
+/* Pinned host memory for the SoA staging buffers of the host side (hipHostMalloc). */
+int dmi_alloc_pinned(size_t bytes, void **out);
+int dmi_free_pinned(void *ptr);
+
+int dmi_abi_version(void);
+int dmi_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* DMI_H_ */

@@ -1,0 +1,65 @@
+"""CPU-side checks of the C-ABI boundary: the library builds, loads and exports exactly what
+include/dmi.h declares; with no GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from cudadepthmapintegration_amd import capi, scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_match_binding_list():
+    assert _declared_symbols() == sorted(capi.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(capi.load()._name)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/dmi.h but not exported"
+
+
+def test_abi_version_and_defaults():
+    lib = capi.load()
+    assert lib.dmi_abi_version() == 1
+    o = capi.OptionsC()
+    lib.dmi_default_options(ctypes.byref(o))
+    assert (o.device, o.grid_dtype, o.depth_storage, o.count_hits, o.kernel_variant) == (0, capi.DMI_F64, 0, 0, 0)
+    assert lib.dmi_last_error(None) is not None
+
+
+def test_invalid_arguments_are_reported_not_fatal():
+    g = scene.default_grid(4)
+    with pytest.raises(capi.DmiError) as e:
+        capi.FusionContext(scene.GridDesc((0, 4, 4), g.origin, g.spacing), scene.default_ray_potential(g))
+    assert e.value.code == 1 and "cell_dims" in str(e.value)
+    with pytest.raises(capi.DmiError) as e:      # filt.cxx:138-142
+        capi.FusionContext(g, scene.RayPotential(0.0, 0.0, 0.1, 0.1))
+    assert e.value.code == 1 and "rho" in str(e.value)
+
+
+def test_no_gpu_means_loud_failure():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = scene.default_grid(4)
+    with pytest.raises(capi.DmiError) as e:
+        capi.FusionContext(g, scene.default_ray_potential(g))
+    assert e.value.code == 2
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "cudadepthmapintegration_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                assert "liboracle" not in src and "tsdf_oracle.c\"" not in src
