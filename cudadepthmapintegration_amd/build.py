@@ -2,24 +2,29 @@
 
 hipcc cross-compiles without a GPU.  The shared object lands next to the sources
 (cudadepthmapintegration_amd/csrc/libdmi_hip.so) so it travels with the repo snapshot
-to the GPU box; it is git-ignored.
+to the GPU box; it is git-ignored.  Objects are compiled in parallel (one hipcc per source)
+into build/obj/ and relinked only when a source or header is newer.
 """
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libdmi_hip.so")
 
-SOURCES = ["fusion_kernels.hip", "dmi_capi.hip"]
-HEADERS = ["fusion_kernels.h", os.path.join("..", "..", "include", "dmi.h")]
+SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "coloration_kernels.hip", "dmi_capi.hip", "host/recon_host.cpp"]
+HEADERS = ["fusion_kernels.h", "fusion_device.h", os.path.join("host", "recon_host.h"),
+           os.path.join("..", "..", "include", "dmi.h"), os.path.join("..", "..", "include", "dmi_host.h")]
 
 # -ffp-contract=off: no FMA contraction anywhere on the result path (parity contract, DESIGN.md).
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+HIP_FLAGS = ["--offload-arch=gfx950"]
 
 
 def hipcc_path() -> str:
@@ -29,19 +34,51 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built (no CPU fallback exists)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _headers():
+    return [os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, src.replace("/", "_") + ".o")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build() -> bool:
+    deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
+    return _stale(LIB_PATH, deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    hipcc = hipcc_path()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = _headers()
+
+    def compile_one(src: str):
+        path = os.path.join(CSRC, src)
+        obj = _obj(src)
+        if not force and not _stale(obj, [path] + headers):
+            return
+        cmd = [hipcc] + COMMON_FLAGS + (HIP_FLAGS if src.endswith(".hip") else ["-x", "hip"] + HIP_FLAGS) + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(compile_one, _sources()))
+    cmd = [hipcc] + HIP_FLAGS + ["-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH

@@ -20,6 +20,8 @@ DMI_DEPTH_AUTO, DMI_DEPTH_F32, DMI_DEPTH_F64 = 0, 1, 2
 # kernel_variant bits (tuning knobs)
 VARIANT_EXACT_DIVISION = 1  # disable the checked-reciprocal fast path
 VARIANT_GENERAL_K = 2  # ignore K structure, evaluate the full 4x4 rows
+VARIANT_FORCE_GENERAL = 16  # never use the register-tiled kernel
+VARIANT_TILE_SHAPE = {"tk16_2x2": 0, "tk32_2x2": 32, "tk32_4x4": 64, "tk8_2x2": 96}  # tiled kernel shapes
 
 
 class GridDescC(ctypes.Structure):
@@ -48,7 +50,7 @@ class InfoC(ctypes.Structure):
     _fields_ = [("n_voxels", ctypes.c_int64), ("n_views", ctypes.c_int32), ("depth_width", ctypes.c_int32),
                 ("depth_height", ctypes.c_int32), ("depth_storage_in_use", ctypes.c_int32),
                 ("grid_dtype", ctypes.c_int32), ("k_mode", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32), ("device_bytes", ctypes.c_uint64)]
+                ("tiled_kernel", ctypes.c_int32), ("device_bytes", ctypes.c_uint64)]
 
 
 # every symbol include/dmi.h declares (tests/test_abi.py checks the library exports them all)

@@ -17,6 +17,8 @@
 using dmi::FuseArgs;
 using dmi::FuseConfig;
 using dmi::MapRec;
+using dmi::TileArgs;
+using dmi::TileMapRec;
 
 namespace {
 
@@ -61,6 +63,15 @@ struct dmi_context {
   MapRec *d_maps = nullptr;
   size_t d_maps_capacity = 0;
   bool maps_dirty = false;
+
+  // tiled kernel (fusion_tile.hip): per-map records, the r22*wz(k) table, a device copy of FuseArgs
+  std::vector<TileMapRec> h_tile_maps;
+  TileMapRec *d_tile_maps = nullptr;
+  double *d_cz_table = nullptr;
+  size_t cz_table_capacity = 0;  // doubles
+  FuseArgs *d_fuse_args = nullptr;
+  double max_tile_err = 0.0;     // largest TileMapRec::err among the resident views
+  bool last_fuse_tiled = false;
 
   double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
   size_t stage_capacity = 0;  // elements per staging buffer
@@ -146,7 +157,10 @@ int promote_to_f64(dmi_context *ctx) {
     (void)hipFree(b.d_depth);
     ctx->device_bytes += npix * b.n * 4;
     b.d_depth = wide;
-    for (int i = 0; i < b.n; ++i) ctx->h_maps[map_index + i].depth = wide + npix * i;
+    for (int i = 0; i < b.n; ++i) {
+      ctx->h_maps[map_index + i].depth = wide + npix * i;
+      ctx->h_tile_maps[map_index + i].depth = wide + npix * i;
+    }
     map_index += b.n;
   }
   ctx->depth_f64 = true;
@@ -166,42 +180,35 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   ctx->device_bytes += npix * n * esz;
   *lossy_out = 0;
   int rc = DMI_OK;
-  if (depth32 != nullptr && !ctx->depth_f64) {
-    // f32 in, f32 store: plain copy
-    hipError_t e = hipMemcpyAsync(b.d_depth, depth32, npix * n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
-  } else if (depth32 != nullptr) {
-    // f32 in, f64 store: stage the floats at the end of the buffer's own tail is not possible; use a temp
-    float *tmp = nullptr;
-    hipError_t e = hipMalloc(&tmp, npix * n * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(tmp, depth32, npix * n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = dmi::launch_widen_depth(tmp, static_cast<double *>(b.d_depth), (int64_t)npix * n, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (tmp) (void)hipFree(tmp);
-    if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
-  } else {
-    // f64 in: stage <= 256 MiB of maps at a time, fuse threshold + narrowing into one pass
-    const size_t maps_per_chunk = std::max<size_t>(1, (size_t(256) << 20) / (npix * 8));
-    const size_t chunk = std::min<size_t>(maps_per_chunk, (size_t)n);
-    rc = ensure_stage(ctx, chunk * npix, best_cost != nullptr);
-    if (rc == DMI_OK) {
-      hipError_t e = hipMemsetAsync(ctx->d_lossy, 0, sizeof(unsigned long long), ctx->stream);
-      for (size_t m0 = 0; e == hipSuccess && m0 < (size_t)n; m0 += chunk) {
-        const size_t cnt = std::min(chunk, (size_t)n - m0);
-        e = hipMemcpyAsync(ctx->d_stage_depth, depth64 + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && best_cost)
-          e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-          e = dmi::launch_convert_depth(ctx->d_stage_depth, best_cost ? ctx->d_stage_cost : nullptr, threshold,
-                                        static_cast<char *>(b.d_depth) + m0 * npix * esz, ctx->depth_f64 ? 1 : 0,
-                                        (int64_t)(cnt * npix), ctx->d_lossy, ctx->stream);
+  // Every path ends in a device kernel that writes the table top row first (the reference's vtk order is
+  // bottom row first, cu:141-149): <= 256 MiB of host data is staged at a time.
+  const size_t in_elem = depth32 ? 4 : 8;
+  const size_t maps_per_chunk = std::max<size_t>(1, (size_t(256) << 20) / (npix * 8));
+  const size_t chunk = std::min<size_t>(maps_per_chunk, (size_t)n);
+  rc = ensure_stage(ctx, chunk * npix, best_cost != nullptr);
+  if (rc == DMI_OK) {
+    hipError_t e = hipMemsetAsync(ctx->d_lossy, 0, sizeof(unsigned long long), ctx->stream);
+    for (size_t m0 = 0; e == hipSuccess && m0 < (size_t)n; m0 += chunk) {
+      const size_t cnt = std::min(chunk, (size_t)n - m0);
+      const char *src = depth32 ? reinterpret_cast<const char *>(depth32) : reinterpret_cast<const char *>(depth64);
+      e = hipMemcpyAsync(ctx->d_stage_depth, src + m0 * npix * in_elem, cnt * npix * in_elem, hipMemcpyHostToDevice,
+                         ctx->stream);
+      if (e == hipSuccess && best_cost)
+        e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->stream);
+      void *dst = static_cast<char *>(b.d_depth) + m0 * npix * esz;
+      if (e == hipSuccess) {
+        if (depth32)
+          e = dmi::launch_flip_depth_f32(reinterpret_cast<const float *>(ctx->d_stage_depth), dst, ctx->depth_f64 ? 1 : 0,
+                                         (int64_t)cnt, ctx->W, ctx->H, ctx->stream);
+        else
+          e = dmi::launch_convert_depth(ctx->d_stage_depth, best_cost ? ctx->d_stage_cost : nullptr, threshold, dst,
+                                        ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->d_lossy, ctx->stream);
       }
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
     }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
   }
   if (rc != DMI_OK) {
     (void)hipFree(b.d_depth);
@@ -210,6 +217,73 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   }
   *out = b;
   return DMI_OK;
+}
+
+// ---- tiled kernel support (fusion_tile.hip) --------------------------------------------------------
+
+constexpr int kMaxColumn = 32;  // tallest voxel column of any tile shape (error bound below uses it)
+
+// rows 0..2 of the grid matrix applied to the centre of voxel (i, j, k): cu:78-83 + cu:168
+void voxel_world(const dmi_grid_desc &g, int i, int j, int k, double w[3]) {
+  const double p[3] = {g.origin[0] + (i + 0.5) * g.spacing[0], g.origin[1] + (j + 0.5) * g.spacing[1],
+                       g.origin[2] + (k + 0.5) * g.spacing[2]};
+  for (int r = 0; r < 3; ++r)
+    w[r] = ((g.grid_matrix[4 * r] * p[0] + g.grid_matrix[4 * r + 1] * p[1]) + g.grid_matrix[4 * r + 2] * p[2]) +
+           g.grid_matrix[4 * r + 3];
+}
+
+bool grid_axis_aligned(const dmi_grid_desc &g) {
+  const double *m = g.grid_matrix;
+  return m[1] == 0 && m[2] == 0 && m[4] == 0 && m[6] == 0 && m[8] == 0 && m[9] == 0;
+}
+
+// Per-map record of the tiled kernel: row 2 of RT for the exact c.z, rows 0 and 1 of K*[R|T] for the
+// pixel selection, and `err`, a bound on the absolute difference between the reference's computed
+// h.x / h.y and the kernel's affine evaluation anywhere in the grid (DESIGN.md "Tiled kernel: proof
+// obligations" derives the 73-ulp budget this bound covers seven times over).
+TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
+  TileMapRec t;
+  std::memset(&t, 0, sizeof(t));
+  const double *rt = r.rt, *k = r.k;
+  t.rz0 = rt[8];
+  t.rz1 = rt[9];
+  t.rz3 = rt[11];
+  double P[4], Q[4];
+  for (int c = 0; c < 4; ++c) {
+    P[c] = k[0] * rt[c] + k[1] * rt[4 + c] + k[2] * rt[8 + c];  // row 0 of K (fx s cx0 0) times [R|T]
+    Q[c] = k[5] * rt[4 + c] + k[6] * rt[8 + c];                 // row 1 of K (0 fy cy0 0)
+  }
+  t.px = P[0]; t.py = P[1]; t.pz = P[2]; t.p0 = P[3];
+  t.qx = Q[0]; t.qy = Q[1]; t.qz = Q[2]; t.q0 = Q[3];
+  const double dz = ctx->grid.grid_matrix[10] * ctx->grid.spacing[2];  // step of wz per voxel along k
+  t.dhx = P[2] * dz;
+  t.dhy = Q[2] * dz;
+  // magnitudes: |w| is largest at a grid corner (each w component is monotone in its own index)
+  double lo[3], hi[3], wm[3];
+  voxel_world(ctx->grid, 0, 0, 0, lo);
+  voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1, ctx->grid.cell_dims[2] - 1 + kMaxColumn, hi);
+  for (int a = 0; a < 3; ++a) wm[a] = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+  double M[3];
+  for (int row = 0; row < 3; ++row)
+    M[row] = std::fabs(rt[4 * row]) * wm[0] + std::fabs(rt[4 * row + 1]) * wm[1] + std::fabs(rt[4 * row + 2]) * wm[2] +
+             std::fabs(rt[4 * row + 3]);
+  const double Sx = std::fabs(k[0]) * M[0] + std::fabs(k[1]) * M[1] + std::fabs(k[2]) * M[2];
+  const double Sy = std::fabs(k[5]) * M[1] + std::fabs(k[6]) * M[2];
+  t.err = std::max(Sx, Sy) * 0x1p-44;  // 512 ulps of the term magnitudes
+  t.depth = r.depth;
+  return t;
+}
+
+// Preconditions of the tiled kernel (fusion_tile.hip header); otherwise the general kernel runs.
+bool tile_eligible(const dmi_context *ctx) {
+  if (ctx->opt.kernel_variant & dmi::VAR_FORCE_GENERAL) return false;
+  if (!ctx->finite_bounded || !grid_axis_aligned(ctx->grid)) return false;
+  if (ctx->k_mode < (int)dmi::K_PINHOLE_SKEW) return false;
+  if (!(ctx->ray.thickness >= 0) || !(ctx->ray.delta >= 0)) return false;
+  if ((int64_t)ctx->W * ctx->H * (int64_t)(ctx->depth_f64 ? 8 : 4) >= (int64_t(1) << 31)) return false;
+  // pixel selection must be provable for nearly every lane: err / c.z must stay far below one pixel
+  if (!(ctx->max_tile_err < 0x1p-14)) return false;
+  return true;
 }
 
 int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32, const double *best_cost,
@@ -228,6 +302,7 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     ctx->H = height;
     ctx->depth_f64 = ctx->opt.depth_storage == DMI_DEPTH_F64;
     ctx->k_mode = ctx->finite_bounded ? (int)dmi::K_PINHOLE : (int)dmi::K_GENERAL;
+    ctx->max_tile_err = 0.0;
   }
   const size_t npix = (size_t)width * height;
 
@@ -256,6 +331,9 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     ctx->h_maps.push_back(r);
     const int km = classify_k(r.k, r.rt);
     if (km < ctx->k_mode) ctx->k_mode = km;
+    const TileMapRec t = make_tile_rec(ctx, r);
+    ctx->h_tile_maps.push_back(t);
+    if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
   }
   ctx->maps_dirty = true;
   ctx->timings.last_upload_ms =
@@ -278,8 +356,12 @@ int sync_maps(dmi_context *ctx) {
     ctx->d_maps = nullptr;
     size_t cap = std::max<size_t>(64, n * 2);
     DMI_HIP(ctx, hipMalloc(&ctx->d_maps, cap * sizeof(MapRec)));
-    ctx->device_bytes += (cap - ctx->d_maps_capacity) * sizeof(MapRec);
+    if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
+    ctx->d_tile_maps = nullptr;
+    DMI_HIP(ctx, hipMalloc(&ctx->d_tile_maps, cap * sizeof(TileMapRec)));
+    ctx->device_bytes += (cap - ctx->d_maps_capacity) * (sizeof(MapRec) + sizeof(TileMapRec));
     ctx->d_maps_capacity = cap;
+    ctx->maps_dirty = true;
   }
   if (ctx->opt.count_hits && ctx->map_hits_capacity < n) {
     // grow, keeping the counts gathered so far
@@ -299,7 +381,9 @@ int sync_maps(dmi_context *ctx) {
   }
   if (ctx->maps_dirty) {
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_maps, ctx->h_maps.data(), n * sizeof(MapRec), hipMemcpyHostToDevice, ctx->stream));
-    // h_maps is pageable: the copy above is complete for the host when it returns
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_tile_maps, ctx->h_tile_maps.data(), n * sizeof(TileMapRec), hipMemcpyHostToDevice,
+                                ctx->stream));
+    // h_maps / h_tile_maps are pageable: the copies above are complete for the host when they return
     ctx->maps_dirty = false;
   }
   return DMI_OK;
@@ -430,6 +514,9 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_voxel_hits) (void)hipFree(ctx->d_voxel_hits);
   if (ctx->d_map_hits) (void)hipFree(ctx->d_map_hits);
   if (ctx->d_maps) (void)hipFree(ctx->d_maps);
+  if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
+  if (ctx->d_cz_table) (void)hipFree(ctx->d_cz_table);
+  if (ctx->d_fuse_args) (void)hipFree(ctx->d_fuse_args);
   if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
   if (ctx->d_stage_cost) (void)hipFree(ctx->d_stage_cost);
   if (ctx->d_lossy) (void)hipFree(ctx->d_lossy);
@@ -458,6 +545,8 @@ int dmi_clear_views(dmi_context *ctx) {
   }
   ctx->batches.clear();
   ctx->h_maps.clear();
+  ctx->h_tile_maps.clear();
+  ctx->max_tile_err = 0.0;
   ctx->maps_dirty = true;
   ctx->W = ctx->H = 0;
   return DMI_OK;
@@ -544,6 +633,51 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   cfg.count_hits = ctx->opt.count_hits ? 1 : 0;
   cfg.variant = ctx->opt.kernel_variant;
 
+  cfg.use_tile = tile_eligible(ctx) ? 1 : 0;
+
+  TileArgs t;
+  std::memset(&t, 0, sizeof(t));
+  if (cfg.use_tile) {
+    const dmi::TileShape sh = dmi::tile_shape(cfg.variant);
+    t.nx = a.nx; t.ny = a.ny; t.nz = a.nz; t.W = a.W; t.H = a.H;
+    t.first_map = first; t.n_maps = count; t.init_from_grid = a.init_from_grid;
+    t.kpad = (a.nz + sh.tk - 1) / sh.tk * sh.tk;
+    t.bricks_x = (a.nx + 8 * sh.wx - 1) / (8 * sh.wx);
+    t.bricks_y = (a.ny + 8 * sh.wy - 1) / (8 * sh.wy);
+    t.bricks_z = t.kpad / sh.tk;
+    t.super_x = (t.bricks_x + 3) / 4;
+    t.super_y = (t.bricks_y + 3) / 4;
+    t.super_z = (t.bricks_z + 1) / 2;
+    if ((int64_t)t.super_x * t.super_y * t.super_z * 32 > (int64_t)0x7fffffff)
+      return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: grid too large for one launch");
+    t.depth_bytes = (int32_t)((int64_t)a.W * a.H * (ctx->depth_f64 ? 8 : 4));
+    t.ox = a.ox; t.oy = a.oy; t.oz = a.oz; t.sx = a.sx; t.sy = a.sy; t.sz = a.sz;
+    std::memcpy(t.g, a.g, sizeof(t.g));
+    t.thick = a.thick; t.delta = a.delta; t.rho_pos = a.rho_pos; t.rho_neg = a.rho_neg;
+    t.slope = a.slope; t.free_space = a.free_space;
+    t.tile_maps = ctx->d_tile_maps;
+    t.grid = a.grid; t.voxel_hits = a.voxel_hits; t.map_hits = a.map_hits;
+    // r22*wz(k) table, one row of kpad doubles per resident view
+    const size_t need = (size_t)n_views * (size_t)t.kpad;
+    if (ctx->cz_table_capacity < need) {
+      if (ctx->d_cz_table) {
+        DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_cz_table);
+        ctx->device_bytes -= ctx->cz_table_capacity * 8;
+        ctx->d_cz_table = nullptr;
+        ctx->cz_table_capacity = 0;
+      }
+      DMI_HIP(ctx, hipMalloc(&ctx->d_cz_table, need * 8));
+      ctx->cz_table_capacity = need;
+      ctx->device_bytes += need * 8;
+    }
+    t.cz_table = ctx->d_cz_table;
+    if (!ctx->d_fuse_args) DMI_HIP(ctx, hipMalloc(&ctx->d_fuse_args, sizeof(FuseArgs)));
+    // pageable source: the copy has left the host buffer when the call returns
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_fuse_args, &a, sizeof(FuseArgs), hipMemcpyHostToDevice, ctx->stream));
+    t.full = ctx->d_fuse_args;
+  }
+
   EventPair ev;
   if (!ctx->pool.empty()) {
     ev = ctx->pool.back();
@@ -553,12 +687,13 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
     DMI_HIP(ctx, hipEventCreate(&ev.stop));
   }
   DMI_HIP(ctx, hipEventRecord(ev.start, ctx->stream));
-  hipError_t e = dmi::launch_fuse(a, cfg, ctx->stream);
+  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
   if (e != hipSuccess) {
     ctx->pool.push_back(ev);
     (void)hipGetLastError();
     return fail(ctx, DMI_ERR_DEVICE, std::string("fusion kernel launch: ") + hipGetErrorString(e));
   }
+  ctx->last_fuse_tiled = cfg.use_tile != 0;
   DMI_HIP(ctx, hipEventRecord(ev.stop, ctx->stream));
   ctx->pending.push_back(ev);
   ctx->grid_is_zero = false;
@@ -667,6 +802,7 @@ int dmi_get_info(dmi_context *ctx, dmi_info *out) {
   out->grid_dtype = ctx->opt.grid_dtype;
   out->k_mode = (ctx->opt.kernel_variant & 2) ? 0 : ctx->k_mode;
   out->kernel_variant = ctx->opt.kernel_variant;
+  out->tiled_kernel = (ctx->h_maps.empty() ? 0 : (tile_eligible(ctx) ? 1 : 0));
   out->device_bytes = ctx->device_bytes;
   return DMI_OK;
 }

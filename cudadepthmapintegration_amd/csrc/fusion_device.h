@@ -1,0 +1,78 @@
+// fusion_device.h -- device helpers shared by the general kernel (fusion_kernels.hip) and the exact
+// fallback of the tiled kernel (fusion_tile.hip): the reference's arithmetic, statement by statement.
+// Compiled with -ffp-contract=off: every multiply and add below is rounded on its own.
+#pragma once
+
+#include "fusion_kernels.h"
+
+namespace dmi {
+namespace {
+
+// ---- rows 0..2 of a row-major 4x4 times [p,1], exactly as cu:90-92: ((m0*x + m1*y) + m2*z) + m3
+__device__ __forceinline__ double row4(const double *__restrict__ m, double x, double y, double z) {
+  return ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+}
+
+// ---- rayPotential<double>, cu:105-120 --------------------------------------------------------
+// sign = diff != 0 ? (int)(diff/|diff|) : 0 is +1, -1 or 0 and rho*sign one of three host-computed
+// products (FuseArgs::rho_pos / rho_neg / rho_zero), so no division is needed on the device.
+template <typename Args>
+__device__ __forceinline__ double ray_potential(const Args &a, double real_depth, double depth) {
+  const double diff = real_depth - depth;  // cu:108
+  const double ad = fabs(diff);            // cu:110
+  const double far_value = diff > 0 ? 0.0 : a.free_space;                               // cu:115
+  const double plateau = diff > 0 ? a.rho_pos : (diff < 0 ? a.rho_neg : a.rho_zero);    // cu:112,117
+  const double ramp = a.slope * diff;                                                   // cu:119
+  return ad > a.delta ? far_value : (ad > a.thick ? plateau : ramp);                    // cu:114-119
+}
+
+// ---- exact pixel decision: the reference's divide + round + bounds test (cu:177-197) ---------
+// NaN, +-inf and |round| >= 2^31 are out of the map (project rule, see oracle/tsdf_oracle.c).
+__device__ __forceinline__ bool pixel_exact(double hx, double hy, double hz, int W, int H, int &px, int &py) {
+  if (hz < 0) return false;         // cu:177
+  const double u = hx / hz;         // cu:183 (correctly rounded fp64 division)
+  const double v = hy / hz;         // cu:184
+  const double ru = round(u);       // cu:187 half away from zero
+  const double rv = round(v);       // cu:188
+  // fp64 form of cu:192-197; false for NaN.  -0.0 >= 0 holds and converts to pixel 0.
+  if (!(ru >= 0.0 && rv >= 0.0 && ru < (double)W && rv < (double)H)) return false;
+  px = (int)ru;
+  py = (int)rv;
+  return true;
+}
+
+// ---- fast pixel decision ----------------------------------------------------------------------
+// u = hx/hz only matters through round(u): every decision boundary is a half-integer of u.  The
+// fast path multiplies by a Newton-refined reciprocal whose residual it CHECKS (|1 - hz*r| < 2^-40,
+// so |ua - u| <= |u| * 2^-38 whatever v_rcp_f64's accuracy is), and accepts its answer only when
+//   (a) ua is outside [-1, W] (then u is certainly outside [-0.5, W-0.5)), or
+//   (b) ua + 0.5 is farther than 2^-20 from an integer (then floor(ua + 0.5) == round(u), because
+//       the total error is below 2^-21 for W, H <= 32768).
+// Anything else -- including NaN/inf, hz ~ 0, exact halves -- is `undecided` and re-done by
+// pixel_exact().  Returns: 1 in (px,py valid), 0 out, -1 undecided.
+__device__ __forceinline__ int pixel_fast(double hx, double hy, double hz, int W, int H, int &px, int &py) {
+  if (hz < 0) return 0;  // cu:177, exact compare
+  double r = __builtin_amdgcn_rcp(hz);
+  double e = __builtin_fma(-hz, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-hz, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double resid = __builtin_fma(-hz, r, 1.0);
+  if (!(fabs(resid) < 0x1p-40)) return -1;  // also catches NaN / inf / overflowed reciprocal
+  const double ua = hx * r;
+  const double va = hy * r;
+  // certainly outside: no exactness needed (NaN compares false and falls through)
+  if (ua < -1.0 || va < -1.0 || ua > (double)W || va > (double)H) return 0;
+  const double tu = ua + 0.5, tv = va + 0.5;
+  const double fu = floor(tu), fv = floor(tv);
+  const double du = tu - fu, dv = tv - fv;
+  constexpr double tau = 0x1p-20;
+  if (!(du > tau && du < 1.0 - tau && dv > tau && dv < 1.0 - tau)) return -1;
+  if (!(fu >= 0.0 && fv >= 0.0 && fu < (double)W && fv < (double)H)) return 0;
+  px = (int)fu;
+  py = (int)fv;
+  return 1;
+}
+
+}  // namespace
+}  // namespace dmi

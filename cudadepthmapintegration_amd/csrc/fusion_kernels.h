@@ -1,5 +1,6 @@
 // fusion_kernels.h -- device-side records and launchers shared by the C ABI (dmi_capi.hip)
-// and the kernels (fusion_kernels.hip).  gfx950 only.
+// and the kernels (fusion_kernels.hip: general kernel + upload helpers; fusion_tile.hip: the
+// register-tiled kernel for axis-aligned grids and pinhole cameras).  gfx950 only.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -7,15 +8,32 @@
 
 namespace dmi {
 
-// One depth map as the kernel reads it.  The loop index over maps is wave-uniform, so the
-// compiler fetches a record with scalar loads (s_load_dwordx*) into SGPRs: no VGPRs, no LDS.
+// One depth map as the general kernel (and the exact fallback of the tiled kernel) reads it.  The loop
+// index over maps is wave-uniform, so a record arrives through scalar loads into SGPRs: no VGPRs, no LDS.
 struct alignas(16) MapRec {
   double rt[12];      // rows 0..2 of [R|T]   (reference: matrixTR, cu:159,172)
   double k[12];       // rows 0..2 of the 4x4 K (reference: matrixK, cu:159,176)
-  const void *depth;  // W*H depth table, float or double, vtk row order (cu:141-149)
+  const void *depth;  // W*H depth table, float or double, image row order (row 0 = TOP row: the
+                      // reference's bottom-up vtk order, cu:141-149, is flipped once at upload)
   uint64_t pad;
 };
 static_assert(sizeof(MapRec) == 208, "MapRec layout");
+
+// What the tiled kernel needs per map (scalar loads, 128 B).  Only cz -- the camera-space depth that
+// enters the ray potential (cu:207) -- is evaluated in the reference's exact arithmetic; the
+// homogeneous pixel coordinates hx, hy only select a pixel, so the fast path evaluates them as an
+// affine function of the (axis-aligned) world coordinates and proves its choice (DESIGN.md
+// "Tiled kernel: proof obligations"); anything unproven goes through the exact expression.
+struct alignas(16) TileMapRec {
+  double rz0, rz1, rz3;    // RT row 2: r20, r21, r23 (r22 * wz(k) comes from the cz table)
+  double px, py, pz, p0;   // hx ~ px*wx + py*wy + pz*wz + p0   (row 0 of K*[R|T])
+  double qx, qy, qz, q0;   // hy ~ qx*wx + qy*wy + qz*wz + q0   (row 1 of K*[R|T])
+  double dhx, dhy;         // increments of hx, hy per voxel step along k
+  double err;              // bound on |hx_ref - hx_fast| and |hy_ref - hy_fast| (absolute)
+  const void *depth;       // same table as MapRec::depth
+  uint64_t pad;
+};
+static_assert(sizeof(TileMapRec) == 128, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical
 // shortcuts proven in DESIGN.md ("K specialisation").
@@ -43,22 +61,66 @@ struct FuseArgs {
   unsigned long long *map_hits;  // nullable, indexed by absolute map id
 };
 
+// Kernel argument of the tiled kernel: only what its main loop keeps in SGPRs.  Everything the rare
+// exact fallback needs beyond this is read from `full`, a device copy of FuseArgs, inside the branch.
+struct TileArgs {
+  int32_t nx, ny, nz, W, H, first_map, n_maps, init_from_grid;
+  int32_t kpad;                          // row pitch of cz_table (nz rounded up to the column height)
+  int32_t bricks_x, bricks_y, bricks_z;  // workgroup bricks per axis
+  int32_t super_x, super_y, super_z;     // super-bricks (4 x 4 x 2 bricks) per axis, XCD-aware ordering
+  int32_t depth_bytes;                   // W * H * sizeof(depth element): buffer range of one depth table
+  double ox, oy, oz, sx, sy, sz;         // c_gridOrig, c_gridSpacing
+  double g[12];                          // rows 0..2 of c_gridMatrix (3x3 part diagonal)
+  double thick, delta, rho_pos, rho_neg, slope, free_space;  // as in FuseArgs
+  const TileMapRec *tile_maps;           // [n_views]
+  const double *cz_table;                // [n_views][kpad]: r22[m] * wz(k), the exact product (cu:92)
+  void *grid;
+  uint32_t *voxel_hits;
+  unsigned long long *map_hits;
+  const FuseArgs *full;                  // device memory
+};
+
 struct FuseConfig {
   int depth_is_f64;
   int grid_is_f64;
   int k_mode;
   int count_hits;
-  int variant;  // tuning variant, see fusion_kernels.hip
+  int variant;   // tuning variant bits, see launch_fuse / launch_fuse_tiled
+  int use_tile;  // host decision: the tiled kernel's preconditions hold
 };
 
-// Enqueues the fusion kernel on `stream`.  Returns hipSuccess or the launch error.
+// tuning-variant bits (dmi_options::kernel_variant)
+enum VariantBits : int {
+  VAR_EXACT_DIVISION = 1,   // general kernel: no checked-reciprocal fast path
+  VAR_GENERAL_K = 2,        // general kernel: ignore K structure
+  VAR_BLOCK_SHAPE_MASK = 12,  // general kernel: bits 2..3 pick the 256-thread block shape
+  VAR_FORCE_GENERAL = 16,   // never use the tiled kernel
+  VAR_TILE_SHAPE_MASK = 0xE0,  // tiled kernel: bits 5..7 pick column height / workgroup shape
+  VAR_TILE_SHAPE_SHIFT = 5
+};
+
+// Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.
+struct TileShape {
+  int tk, wx, wy;  // column height; waves per workgroup along x and y (a wave is 8 x 8 lanes)
+};
+TileShape tile_shape(int variant);
+
+// Enqueues the general fusion kernel on `stream`.  Returns hipSuccess or the launch error.
 hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t stream);
 
+// Tiled kernel: fills args.cz_table for maps [first_map, first_map + n_maps) and fuses them.
+// args.full must point to a device copy of the matching FuseArgs (read by the exact fallback).
+hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const FuseConfig &cfg, hipStream_t stream);
+
 // depth upload helpers ------------------------------------------------------------------
-// out[i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64;
-// *lossy += number of values whose f32 rounding is not exact (only when storing f32).
+// out[row-flipped i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64, n_maps
+// tables of W x H; *lossy += number of values whose f32 rounding is not exact (only when storing f32).
 hipError_t launch_convert_depth(const double *in, const double *best_cost, double threshold, void *out,
-                                int out_is_f64, int64_t n, unsigned long long *lossy, hipStream_t stream);
+                                int out_is_f64, int64_t n_maps, int W, int H, unsigned long long *lossy,
+                                hipStream_t stream);
+// f32 host tables: row flip, optionally widened to f64.
+hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int64_t n_maps, int W, int H,
+                                 hipStream_t stream);
 hipError_t launch_widen_depth(const float *in, double *out, int64_t n, hipStream_t stream);
 
 }  // namespace dmi

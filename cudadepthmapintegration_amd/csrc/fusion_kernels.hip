@@ -17,77 +17,13 @@
 // below only feed a self-checked reciprocal that selects WHICH exact code path runs).  The grid is
 // therefore bit-identical to oracle/tsdf_oracle.c.
 #include "fusion_kernels.h"
+#include "fusion_device.h"
 
 namespace dmi {
 
 namespace {
 
 constexpr int kWave = 64;
-
-// ---- rows 0..2 of a row-major 4x4 times [p,1], exactly as cu:90-92: ((m0*x + m1*y) + m2*z) + m3
-__device__ __forceinline__ double row4(const double *__restrict__ m, double x, double y, double z) {
-  return ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
-}
-
-// ---- rayPotential<double>, cu:105-120 --------------------------------------------------------
-// sign = diff != 0 ? (int)(diff/|diff|) : 0 is +1, -1 or 0 and rho*sign one of three host-computed
-// products (FuseArgs::rho_pos / rho_neg / rho_zero), so no division is needed on the device.
-__device__ __forceinline__ double ray_potential(const FuseArgs &a, double real_depth, double depth) {
-  const double diff = real_depth - depth;  // cu:108
-  const double ad = fabs(diff);            // cu:110
-  const double far_value = diff > 0 ? 0.0 : a.free_space;                               // cu:115
-  const double plateau = diff > 0 ? a.rho_pos : (diff < 0 ? a.rho_neg : a.rho_zero);    // cu:112,117
-  const double ramp = a.slope * diff;                                                   // cu:119
-  return ad > a.delta ? far_value : (ad > a.thick ? plateau : ramp);                    // cu:114-119
-}
-
-// ---- exact pixel decision: the reference's divide + round + bounds test (cu:177-197) ---------
-// NaN, +-inf and |round| >= 2^31 are out of the map (project rule, see oracle/tsdf_oracle.c).
-__device__ __forceinline__ bool pixel_exact(double hx, double hy, double hz, int W, int H, int &px, int &py) {
-  if (hz < 0) return false;         // cu:177
-  const double u = hx / hz;         // cu:183 (correctly rounded fp64 division)
-  const double v = hy / hz;         // cu:184
-  const double ru = round(u);       // cu:187 half away from zero
-  const double rv = round(v);       // cu:188
-  // fp64 form of cu:192-197; false for NaN.  -0.0 >= 0 holds and converts to pixel 0.
-  if (!(ru >= 0.0 && rv >= 0.0 && ru < (double)W && rv < (double)H)) return false;
-  px = (int)ru;
-  py = (int)rv;
-  return true;
-}
-
-// ---- fast pixel decision ----------------------------------------------------------------------
-// u = hx/hz only matters through round(u): every decision boundary is a half-integer of u.  The
-// fast path multiplies by a Newton-refined reciprocal whose residual it CHECKS (|1 - hz*r| < 2^-40,
-// so |ua - u| <= |u| * 2^-38 whatever v_rcp_f64's accuracy is), and accepts its answer only when
-//   (a) ua is outside [-1, W] (then u is certainly outside [-0.5, W-0.5)), or
-//   (b) ua + 0.5 is farther than 2^-20 from an integer (then floor(ua + 0.5) == round(u), because
-//       the total error is below 2^-21 for W, H <= 32768).
-// Anything else -- including NaN/inf, hz ~ 0, exact halves -- is `undecided` and re-done by
-// pixel_exact().  Returns: 1 in (px,py valid), 0 out, -1 undecided.
-__device__ __forceinline__ int pixel_fast(double hx, double hy, double hz, int W, int H, int &px, int &py) {
-  if (hz < 0) return 0;  // cu:177, exact compare
-  double r = __builtin_amdgcn_rcp(hz);
-  double e = __builtin_fma(-hz, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-hz, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  const double resid = __builtin_fma(-hz, r, 1.0);
-  if (!(fabs(resid) < 0x1p-40)) return -1;  // also catches NaN / inf / overflowed reciprocal
-  const double ua = hx * r;
-  const double va = hy * r;
-  // certainly outside: no exactness needed (NaN compares false and falls through)
-  if (ua < -1.0 || va < -1.0 || ua > (double)W || va > (double)H) return 0;
-  const double tu = ua + 0.5, tv = va + 0.5;
-  const double fu = floor(tu), fv = floor(tv);
-  const double du = tu - fu, dv = tv - fv;
-  constexpr double tau = 0x1p-20;
-  if (!(du > tau && du < 1.0 - tau && dv > tau && dv < 1.0 - tau)) return -1;
-  if (!(fu >= 0.0 && fv >= 0.0 && fu < (double)W && fv < (double)H)) return 0;
-  px = (int)fu;
-  py = (int)fv;
-  return 1;
-}
 
 template <typename DepthT, typename GridT, int KMODE, bool FAST, bool COUNT>
 __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs a) {
@@ -149,7 +85,9 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs a) {
     bool hit = false;
     if (in) {
       const DepthT *__restrict__ dm = static_cast<const DepthT *>(rec->depth);
-      const double depth = (double)dm[a.W * (a.H - 1 - py) + px];  // cu:141-149, cu:201
+      // cu:141-149, cu:201: the reference indexes W*(H-1-py)+px into the bottom-up vtk table; the
+      // table is stored top-down here (flipped once at upload), so the same value sits at W*py+px
+      const double depth = (double)dm[a.W * py + px];
       if (depth != -1.0) {                                         // cu:202
         acc += ray_potential(a, cz, depth);                        // cu:207-211
         hit = true;
@@ -180,13 +118,13 @@ hipError_t launch_count(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim
 
 template <typename DepthT, typename GridT, int KMODE>
 hipError_t launch_fast(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim3 block, hipStream_t s) {
-  if (cfg.variant & 1) return launch_count<DepthT, GridT, KMODE, false>(a, cfg, grid, block, s);
+  if (cfg.variant & VAR_EXACT_DIVISION) return launch_count<DepthT, GridT, KMODE, false>(a, cfg, grid, block, s);
   return launch_count<DepthT, GridT, KMODE, true>(a, cfg, grid, block, s);
 }
 
 template <typename DepthT, typename GridT>
 hipError_t launch_kmode(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim3 block, hipStream_t s) {
-  const int km = (cfg.variant & 2) ? (int)K_GENERAL : cfg.k_mode;
+  const int km = (cfg.variant & VAR_GENERAL_K) ? (int)K_GENERAL : cfg.k_mode;
   switch (km) {
     case K_PINHOLE: return launch_fast<DepthT, GridT, K_PINHOLE>(a, cfg, grid, block, s);
     case K_PINHOLE_SKEW: return launch_fast<DepthT, GridT, K_PINHOLE_SKEW>(a, cfg, grid, block, s);
@@ -194,11 +132,22 @@ hipError_t launch_kmode(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim
   }
 }
 
-// ---- depth upload: threshold + optional narrowing ------------------------------------------------
+// ---- depth upload: threshold + row flip + optional narrowing ---------------------------------------
+// Storage order: image row 0 (top) first.  The reference keeps vtk order (row 0 = bottom) and flips
+// in the kernel's index (cu:141-149); flipping once here removes a subtract from every projection.
+__device__ __forceinline__ int64_t flipped_index(int64_t i, int W, int H) {
+  const int64_t npix = (int64_t)W * H;
+  const int64_t m = i / npix;
+  const int64_t rem = i - m * npix;
+  const int64_t row = rem / W;
+  const int64_t col = rem - row * W;
+  return m * npix + (int64_t)(H - 1 - row) * W + col;
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(256) void convert_depth_kernel(const double *__restrict__ in,
                                                             const double *__restrict__ best_cost, double thr,
-                                                            OutT *__restrict__ out, int64_t n,
+                                                            OutT *__restrict__ out, int64_t n, int W, int H,
                                                             unsigned long long *__restrict__ lossy) {
   unsigned int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -210,9 +159,16 @@ __global__ __launch_bounds__(256) void convert_depth_kernel(const double *__rest
       const double back = (double)o;
       bad += (__double_as_longlong(back) != __double_as_longlong(d)) && !(d != d);
     }
-    out[i] = o;
+    out[flipped_index(i, W, H)] = o;
   }
   if (sizeof(OutT) == 4 && bad != 0) atomicAdd(lossy, (unsigned long long)bad);
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void flip_depth_f32_kernel(const float *__restrict__ in, OutT *__restrict__ out,
+                                                             int64_t n, int W, int H) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[flipped_index(i, W, H)] = (OutT)in[i];
 }
 
 __global__ __launch_bounds__(256) void widen_depth_kernel(const float *__restrict__ in, double *__restrict__ out,
@@ -248,14 +204,29 @@ hipError_t launch_fuse(const FuseArgs &a, const FuseConfig &cfg, hipStream_t str
 }
 
 hipError_t launch_convert_depth(const double *in, const double *best_cost, double threshold, void *out,
-                                int out_is_f64, int64_t n, unsigned long long *lossy, hipStream_t stream) {
+                                int out_is_f64, int64_t n_maps, int W, int H, unsigned long long *lossy,
+                                hipStream_t stream) {
+  const int64_t n = n_maps * W * H;
   if (n <= 0) return hipSuccess;
   if (out_is_f64)
     hipLaunchKernelGGL((convert_depth_kernel<double>), dim3(blocks_for(n)), dim3(256), 0, stream, in, best_cost,
-                       threshold, static_cast<double *>(out), n, lossy);
+                       threshold, static_cast<double *>(out), n, W, H, lossy);
   else
     hipLaunchKernelGGL((convert_depth_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, stream, in, best_cost,
-                       threshold, static_cast<float *>(out), n, lossy);
+                       threshold, static_cast<float *>(out), n, W, H, lossy);
+  return hipGetLastError();
+}
+
+hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int64_t n_maps, int W, int H,
+                                 hipStream_t stream) {
+  const int64_t n = n_maps * W * H;
+  if (n <= 0) return hipSuccess;
+  if (out_is_f64)
+    hipLaunchKernelGGL((flip_depth_f32_kernel<double>), dim3(blocks_for(n)), dim3(256), 0, stream, in,
+                       static_cast<double *>(out), n, W, H);
+  else
+    hipLaunchKernelGGL((flip_depth_f32_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, stream, in,
+                       static_cast<float *>(out), n, W, H);
   return hipGetLastError();
 }
 

@@ -1,0 +1,397 @@
+// fusion_tile.hip -- register-tiled TSDF fusion kernel for gfx950 (MI355X): the fast path of dmi_fuse.
+//
+// Preconditions (checked on the host, dmi_capi.hip `tile_eligible`): the 3x3 part of the grid matrix
+// is diagonal (axis-aligned grid; the reference CLI builds it from gridVecX/Y/Z, main.cxx:345-359),
+// every K is a pinhole matrix [fx s cx 0; 0 fy cy 0; 0 0 1 0], all magnitudes are finite and bounded,
+// thickness >= 0 and delta >= 0.  Everything else runs the general kernel (fusion_kernels.hip).
+//
+// Decomposition.  A wavefront is an 8 x 8 patch of lanes in (i, j); every lane owns a COLUMN of TK
+// voxels along k and keeps their TK fp64 running sums in registers for the whole fusion; a workgroup
+// is WX x WY such waves = a brick of 8WX x 8WY x TK voxels; bricks are ordered so that each XCD (own
+// L2) works on one compact super-brick at a time.  The kernel loops over the resident depth maps
+// (wave-uniform index -> camera record and cz table through scalar loads into SGPRs) and, inside,
+// over the column (fully unrolled).  The grid is written once at the end.
+//
+// What is exact and what is only proven.  The reference evaluates, per voxel and map (cu:158-212):
+//   c = RT*[w,1]; h = K*[c,1]; if (h.z < 0) return; px = round(h.x/h.z); py = round(h.y/h.z);
+//   bounds; depth = D[py][px]; if (depth == -1) return; out += rayPotential(c.z, depth)
+// Only c.z and depth reach the accumulated value; h.x, h.y only SELECT the pixel.  So
+//   * c.z is computed in the reference's exact arithmetic, but shared: with an axis-aligned grid
+//     c.z = ((r20*wx(i) + r21*wy(j)) + r22*wz(k)) + r23; the first sum is per lane and map (3 flops per
+//     TK voxels), r22*wz(k) is per map and k (a table filled by cz_table_kernel, read by scalar loads),
+//     leaving 2 adds per voxel-projection instead of 6 flops;
+//   * the pixel is chosen from hx, hy evaluated as an affine function (3 FMAs per column, then one add
+//     per voxel) and a Newton-refined reciprocal, and the choice is ACCEPTED only when the distance of
+//     u, v to the nearest rounding boundary exceeds a bound on everything the shortcut can have
+//     changed (TileMapRec::err / c.z + 2^-22); the reciprocal's own residual is checked too.
+//     Unproven lanes (about 2^-19 of them) are redone with the reference's expression (tile_exact).
+//   * rayPotential is the reference's arithmetic; its three-way select is executed as EXEC-masked
+//     adds of the class constants, so a wave pays only for the classes it contains.
+// Results are bit-identical to the general kernel and to oracle/tsdf_oracle.c (tests/test_gpu_parity.py).
+#include "fusion_kernels.h"
+#include "fusion_device.h"
+
+namespace dmi {
+
+namespace {
+
+constexpr int kLX = 8, kLY = 8;                   // lanes of a wave over (i, j)
+constexpr int kGroup = 4;                          // voxels of a column whose depth loads are in flight together
+constexpr double kMagic = 6755399441055744.0;      // 1.5 * 2^52: x + kMagic rounds x to an integer (RNE)
+constexpr double kDecide = 0.5 - 0x1p-22;          // see DESIGN.md "Tiled kernel: proof obligations"
+constexpr double kRcpResidual = 0x1p-20;           // |1 - cz*r0| below this => |1 - cz*r| < 2^-39
+typedef unsigned long long mask_t;
+
+// acc += v on the lanes of m only: one VALU issue slot, no select.  (Not volatile: the statements have
+// no effect beyond their outputs, and a volatile asm would stop the compiler from using scalar loads.)
+__device__ __forceinline__ void add_where_s(double &acc, mask_t m, double v /* wave-uniform */) {
+  mask_t saved;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(saved) : "s"(m), "s"(v));
+}
+__device__ __forceinline__ void add_where_v(double &acc, mask_t m, double v) {
+  mask_t saved;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(saved) : "s"(m), "v"(v));
+}
+__device__ __forceinline__ void add_where_zero(double &acc, mask_t m) {
+  mask_t saved;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_add_f64 %0, %0, 0\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(saved) : "s"(m));
+}
+
+// bits |= bit on the lanes of m only
+__device__ __forceinline__ void or_where(uint32_t &bits, mask_t m, uint32_t bit /* wave-uniform */) {
+  mask_t saved;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(bits), "=&s"(saved) : "s"(m), "s"(bit));
+}
+
+__device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Read-only, wave-uniform data (camera records, the cz table, the FuseArgs copy) is read through the
+// constant address space: with a uniform address that is a scalar load into SGPRs.
+template <typename T>
+__device__ __forceinline__ T cload(const T *p) {
+  return *reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(p));
+}
+
+// buffer loads: 32-bit per-lane byte offset, hardware range check (an out-of-range offset returns 0
+// instead of faulting), descriptor in SGPRs built once per map.  The table is stored top-down, so the
+// reference's W*(H-1-py)+px into the bottom-up vtk table (cu:141-149) is W*py+px here.
+template <typename DepthT>
+struct DepthLoad;
+template <>
+struct DepthLoad<float> {
+  typedef float raw_t;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned pixel) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(pixel << 2), 0, 0));
+  }
+  static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
+  static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0f; }  // cu:202; f32 holds the f64 exactly
+  static __device__ __forceinline__ double widen(raw_t d) { return (double)d; }
+};
+template <>
+struct DepthLoad<double> {
+  typedef double raw_t;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned pixel) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(pixel << 3), 0, 0);
+    return __hiloint2double((int)raw.y, (int)raw.x);
+  }
+  static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
+  static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0; }
+  static __device__ __forceinline__ double widen(raw_t d) { return d; }
+};
+
+// Ray-potential parameters as the exact fallback reads them from the FuseArgs copy.
+struct RayArgs {
+  double thick, delta, rho_pos, rho_neg, rho_zero, slope, free_space;
+};
+
+// The reference's expression for one voxel and one map, in full (cu:166-211).  Used for the lanes
+// whose fast-path pixel choice is not proven.  Everything is read from the FuseArgs copy in device
+// memory so that the main loop does not keep it in SGPRs.  Returns true when the thread reaches cu:211.
+template <typename DepthT>
+__device__ __forceinline__ bool tile_exact(const FuseArgs *__restrict__ fa, int m, __amdgpu_buffer_rsrc_t rsrc, int i,
+                                           int j, int k, double &val) {
+  double g[12], rt[12], kk[12];
+  const MapRec *maps = cload(&fa->maps);
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    g[q] = cload(&fa->g[q]);
+    rt[q] = cload(&maps[m].rt[q]);
+    kk[q] = cload(&maps[m].k[q]);
+  }
+  const int W = cload(&fa->W), H = cload(&fa->H);
+  const double gx = cload(&fa->ox) + (i + 0.5) * cload(&fa->sx);  // cu:80-82
+  const double gy = cload(&fa->oy) + (j + 0.5) * cload(&fa->sy);
+  const double gz = cload(&fa->oz) + (k + 0.5) * cload(&fa->sz);
+  const double wx = row4(g + 0, gx, gy, gz);  // cu:168
+  const double wy = row4(g + 4, gx, gy, gz);
+  const double wz = row4(g + 8, gx, gy, gz);
+  const double cx = row4(rt + 0, wx, wy, wz);  // cu:172
+  const double cy = row4(rt + 4, wx, wy, wz);
+  const double cz = row4(rt + 8, wx, wy, wz);
+  const double hx = row4(kk + 0, cx, cy, cz);  // cu:176
+  const double hy = row4(kk + 4, cx, cy, cz);
+  const double hz = row4(kk + 8, cx, cy, cz);
+  int px = 0, py = 0;
+  if (!pixel_exact(hx, hy, hz, W, H, px, py)) return false;  // cu:177-197
+  const typename DepthLoad<DepthT>::raw_t d = DepthLoad<DepthT>::load(rsrc, (unsigned)(W * py + px));  // cu:201
+  if (DepthLoad<DepthT>::is_sentinel(d)) return false;                                                  // cu:202
+  RayArgs ra;
+  ra.thick = cload(&fa->thick);
+  ra.delta = cload(&fa->delta);
+  ra.rho_pos = cload(&fa->rho_pos);
+  ra.rho_neg = cload(&fa->rho_neg);
+  ra.rho_zero = cload(&fa->rho_zero);
+  ra.slope = cload(&fa->slope);
+  ra.free_space = cload(&fa->free_space);
+  val = ray_potential(ra, cz, DepthLoad<DepthT>::widen(d));  // cu:207-209
+  return true;
+}
+
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, bool COUNT>
+__global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
+  typedef DepthLoad<DepthT> DL;
+  // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), so
+  // slot = (b % 8) * per_xcd + b / 8 gives every XCD a contiguous run of slots; slots enumerate
+  // super-bricks of 4 x 4 x 2 bricks, so the ~32 workgroups an XCD runs at a time are neighbours in
+  // space and their depth-map footprints overlap in that XCD's L2.
+  const int b = blockIdx.x;
+  const int per_xcd = gridDim.x >> 3;  // gridDim.x is a multiple of 32
+  const int slot = (b & 7) * per_xcd + (b >> 3);
+  const int sb = slot >> 5, within = slot & 31;
+  const int sbx = sb % a.super_x;
+  const int sbt = sb / a.super_x;
+  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
+  const int bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
+  if (bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = (bx * WX + (w % WX)) * kLX + (lane % kLX);
+  const int j = (by * WY + (w / WX)) * kLY + (lane / kLX);
+  const int k0 = bz * TK;
+  const int kcount = a.nz - k0 < TK ? a.nz - k0 : TK;  // wave-uniform, >= 1
+  const bool lane_ok = i < a.nx && j < a.ny;
+
+  // cu:78-83 + cu:168 once per lane.  With a diagonal 3x3 grid matrix wx depends on i only, wy on j
+  // only, wz on k only (the off-diagonal products are exact zeros; only the sign of a zero result can
+  // depend on the other indices, and no later step observes it: DESIGN.md).
+  const double gx = a.ox + (i + 0.5) * a.sx;
+  const double gy = a.oy + (j + 0.5) * a.sy;
+  const double gz0 = a.oz + (k0 + 0.5) * a.sz;
+  const double wx = row4(a.g + 0, gx, gy, gz0);
+  const double wy = row4(a.g + 4, gx, gy, gz0);
+  const double wz0 = row4(a.g + 8, gx, gy, gz0);
+
+  GridT *__restrict__ grid = static_cast<GridT *>(a.grid);
+  const int64_t plane = (int64_t)a.ny * a.nx;
+  const int64_t gid0 = ((int64_t)k0 * a.ny + j) * a.nx + i;  // cu:126-134
+
+  double acc[TK];
+  uint32_t nh[COUNT ? TK : 1];
+#pragma unroll
+  for (int kk = 0; kk < TK; ++kk) {
+    acc[kk] = 0.0;
+    if (COUNT) nh[kk] = 0;
+    if (a.init_from_grid && lane_ok && kk < kcount) acc[kk] = (double)grid[gid0 + kk * plane];  // cu:211 accumulates
+  }
+
+  // 0 <= r < W for an integer-valued double r, on its high dword alone: the high dword is monotone
+  // in r, W's low dword is zero (W <= 2^20), and negative values have the sign bit set.
+  const uint32_t hiW = (uint32_t)__double2hiint((double)a.W);
+  const uint32_t hiH = (uint32_t)__double2hiint((double)a.H);
+
+  const int m_end = a.first_map + a.n_maps;
+  for (int m = a.first_map; m < m_end; ++m) {
+    const TileMapRec *rec = a.tile_maps + m;                     // wave-uniform -> scalar loads
+    const double *ct = a.cz_table + (int64_t)m * a.kpad + k0;  // r22*wz(k), wave-uniform
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&rec->depth)), (short)0, a.depth_bytes, 0x00020000);
+
+    // exact: the part of c.z shared by the whole column, (r20*wx + r21*wy)  (cu:92).  Lanes outside
+    // the grid get -inf: their c.z is -inf, i.e. "behind the camera" (cu:177), at no cost per voxel.
+    // Voxels above the grid (k >= nz) get the same through a -inf entry of the cz table.
+    const double sz_in = cload(&rec->rz0) * wx + cload(&rec->rz1) * wy;
+    const double sz = lane_ok ? sz_in : -__builtin_inf();
+    const double rz3 = cload(&rec->rz3);
+    // pixel selection only: h.x, h.y at the column's first voxel, then one add per step
+    double hx = __builtin_fma(cload(&rec->px), wx,
+                              __builtin_fma(cload(&rec->py), wy, __builtin_fma(cload(&rec->pz), wz0, cload(&rec->p0))));
+    double hy = __builtin_fma(cload(&rec->qx), wx,
+                              __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
+    const double dhx = cload(&rec->dhx), dhy = cload(&rec->dhy), err = cload(&rec->err);
+
+    uint32_t undecided = 0;  // per lane: bit kk set = redo voxel kk of this map exactly
+    uint32_t map_hits = 0;   // wave-uniform
+
+#pragma unroll
+    for (int g0 = 0; g0 < TK; g0 += kGroup) {
+      double czg[kGroup];
+      typename DL::raw_t dg[kGroup];
+      mask_t ing[kGroup];
+      // ---- phase A: project the group's voxels and issue their depth loads
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const int kk = g0 + q;
+        if (kk > 0) {
+          hx += dhx;
+          hy += dhy;
+        }
+        const double cz = (sz + cload(ct + kk)) + rz3;  // exact c.z (cu:92, cu:172); h.z == c.z for a pinhole K
+        czg[q] = cz;
+        // reciprocal: hardware seed + one Newton step; e0 is the seed's residual, checked below
+        const double r0 = __builtin_amdgcn_rcp(cz);
+        const double e0 = __builtin_fma(-cz, r0, 1.0);
+        const double r = __builtin_fma(r0, e0, r0);
+        const double ua = hx * r, va = hy * r;
+        // nearest integers (ties never accepted, so RNE vs the reference's half-away does not matter)
+        const double tu = ua + kMagic, tv = va + kMagic;
+        const double ru = tu - kMagic, rv = tv - kMagic;
+        const double fu = ua - ru, fv = va - rv;  // exact: signed distance to the chosen integer
+        // accepted iff |frac| + (bound on |u_ref - ua|) < 1/2 - 2^-22; a NaN anywhere fails a compare
+        const double chk = __builtin_fma(err, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
+        // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot below is one
+        // v_cmp, all the logic between them runs on the scalar unit.
+        const mask_t m_front = ballot(!(cz < 0.0));  // cu:177: not behind the camera
+        const mask_t m_proven = ballot(__builtin_fabs(e0) < kRcpResidual) & ballot(chk < kDecide);
+        uint32_t hu = (uint32_t)__double2hiint(ru), hv = (uint32_t)__double2hiint(rv);
+        asm("" : "+v"(hu));  // keep these two as plain 32-bit compares
+        asm("" : "+v"(hv));
+        const mask_t m_in = m_front & m_proven & ballot(hu < hiW) & ballot(hv < hiH);  // cu:192-197
+        ing[q] = m_in;
+        const mask_t m_und = m_front & ~m_proven;
+        if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
+        if (__builtin_amdgcn_inverse_ballot_w64(m_in)) {
+          // the integers themselves are the low dwords of tu, tv (two's complement below 2^31)
+          const unsigned px = (unsigned)__double2loint(tu), py = (unsigned)__double2loint(tv);
+          dg[q] = DL::load(rsrc, __umul24(py, (unsigned)a.W) + px);  // cu:201
+        }
+      }
+      // ---- phase B: ray potential of the group (cu:105-120) as EXEC-masked adds
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const int kk = g0 + q;
+        const typename DL::raw_t d = dg[q];  // lanes that did not load hold garbage, masked by ing[q]
+        const mask_t m_hit = ing[q] & ballot(!DL::is_sentinel(d));  // cu:202
+        if (m_hit) {  // wave-uniform: skip the potential when no lane accumulates
+          const double diff = czg[q] - DL::widen(d);  // cu:108
+          const mask_t m_far = m_hit & ballot(__builtin_fabs(diff) > a.delta);  // cu:114
+          const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
+          if (m_far) {
+            const mask_t m_free = m_far & ~m_pos, m_zero = m_far & m_pos;
+            if (m_free) add_where_s(acc[kk], m_free, a.free_space);  // -eta*rho (cu:115)
+            if (m_zero) add_where_zero(acc[kk], m_zero);             // + 0 (cu:115): keeps -0.0 + 0.0 = +0.0
+          }
+          const mask_t m_near = m_hit & ~m_far;
+          if (m_near) {
+            const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > a.thick);  // cu:116
+            const mask_t m_ramp = m_near & ~m_plat;  // includes a NaN diff, as the reference's else branch
+            const mask_t m_pp = m_plat & m_pos, m_pn = m_plat & ~m_pos;
+            if (m_pp) add_where_s(acc[kk], m_pp, a.rho_pos);           // rho * +1 (cu:117)
+            if (m_pn) add_where_s(acc[kk], m_pn, a.rho_neg);           // rho * -1
+            if (m_ramp) add_where_v(acc[kk], m_ramp, a.slope * diff);  // (rho/thick)*diff (cu:119)
+          }
+          if (COUNT) {
+            nh[kk] += __builtin_amdgcn_inverse_ballot_w64(m_hit) ? 1u : 0u;
+            map_hits += (uint32_t)__popcll(m_hit);
+          }
+        }
+      }
+    }
+
+    // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so
+    // doing them after the column keeps every voxel's accumulation in map order, cu:211)
+    if (ballot(undecided != 0)) {
+#pragma unroll 1
+      for (int kk = 0; kk < kcount; ++kk) {
+        const bool mine = (undecided >> kk) & 1u;
+        if (!ballot(mine)) continue;
+        double val = 0.0;
+        bool hit = false;
+        if (mine) hit = tile_exact<DepthT>(a.full, m, rsrc, i, j, k0 + kk, val);
+#pragma unroll
+        for (int q = 0; q < TK; ++q) {
+          if (kk == q) {  // wave-uniform
+            if (hit) acc[q] += val;
+            if (COUNT) nh[q] += hit ? 1u : 0u;
+          }
+        }
+        if (COUNT) map_hits += (uint32_t)__popcll(ballot(hit));
+      }
+    }
+    if (COUNT) {
+      if (map_hits != 0 && lane == 0) atomicAdd(&a.map_hits[m], (unsigned long long)map_hits);
+    }
+  }
+
+  if (lane_ok) {
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      if (kk < kcount) {
+        grid[gid0 + kk * plane] = (GridT)acc[kk];
+        if (COUNT) a.voxel_hits[gid0 + kk * plane] += nh[kk];
+      }
+    }
+  }
+}
+
+// r22[m] * wz(k): the one product of c.z that depends on (map, k) only.  Exact fp64 multiply.
+__global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const MapRec *__restrict__ maps,
+                                                       double *__restrict__ table) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = a.first_map + blockIdx.y;
+  if (k >= a.kpad) return;
+  const double gx = a.ox + (0 + 0.5) * a.sx;
+  const double gy = a.oy + (0 + 0.5) * a.sy;
+  const double gz = a.oz + (k + 0.5) * a.sz;
+  const double wz = row4(a.g + 8, gx, gy, gz);  // cu:168 row 2; depends on k only (diagonal 3x3)
+  // rows above the grid: -inf makes c.z = -inf there, which the kernel treats as behind the camera
+  table[(int64_t)m * a.kpad + k] = k < a.nz ? maps[m].rt[10] * wz : -__builtin_inf();
+}
+
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW>
+hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
+  const unsigned blocks = (unsigned)(a.super_x * a.super_y * a.super_z * 32);
+  const dim3 block(64 * WX * WY);
+  if (cfg.count_hits)
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, true>), dim3(blocks), block, 0, s, a);
+  else
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, false>), dim3(blocks), block, 0, s, a);
+  return hipGetLastError();
+}
+
+template <typename DepthT, typename GridT>
+hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
+  const TileShape sh = tile_shape(cfg.variant);
+  if (sh.tk == 16 && sh.wx == 2 && sh.wy == 2) return launch_shape<DepthT, GridT, 16, 2, 2, 5>(a, cfg, s);
+  if (sh.tk == 32 && sh.wx == 2 && sh.wy == 2) return launch_shape<DepthT, GridT, 32, 2, 2, 4>(a, cfg, s);
+  if (sh.tk == 32 && sh.wx == 4 && sh.wy == 4) return launch_shape<DepthT, GridT, 32, 4, 4, 4>(a, cfg, s);
+  if (sh.tk == 8 && sh.wx == 2 && sh.wy == 2) return launch_shape<DepthT, GridT, 8, 2, 2, 7>(a, cfg, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+TileShape tile_shape(int variant) {
+  switch ((variant & VAR_TILE_SHAPE_MASK) >> VAR_TILE_SHAPE_SHIFT) {
+    case 1: return TileShape{32, 2, 2};
+    case 2: return TileShape{32, 4, 4};
+    case 3: return TileShape{8, 2, 2};
+    default: return TileShape{16, 2, 2};
+  }
+}
+
+hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const FuseConfig &cfg, hipStream_t stream) {
+  if (a.n_maps <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
+                     const_cast<double *>(a.cz_table));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (cfg.depth_is_f64) {
+    if (cfg.grid_is_f64) return launch_types<double, double>(a, cfg, stream);
+    return launch_types<double, float>(a, cfg, stream);
+  }
+  if (cfg.grid_is_f64) return launch_types<float, double>(a, cfg, stream);
+  return launch_types<float, float>(a, cfg, stream);
+}
+
+}  // namespace dmi

@@ -83,7 +83,9 @@ typedef struct dmi_options {
   int32_t depth_storage;  /* dmi_depth_storage */
   int32_t count_hits;     /* != 0: keep per-voxel u32 and per-map u64 hit counters (not a reference
                              output; they expose every in-frustum / sentinel decision for parity) */
-  int32_t kernel_variant; /* 0 = default; other values select tuning variants */
+  int32_t kernel_variant; /* 0 = default; bit field of tuning / test switches (DESIGN.md "kernel_variant"):
+                             1 exact division in the general kernel, 2 ignore K structure, 4|8 block shape of
+                             the general kernel, 16 never use the tiled kernel, 32..224 tile shape */
   int32_t reserved0;
   void *stream;           /* hipStream_t to run on; NULL = a stream owned by the context */
   void *external_grid;    /* device pointer to a caller-owned grid of grid_dtype[n_voxels]
@@ -107,7 +109,8 @@ typedef struct dmi_info {
   int32_t grid_dtype;
   int32_t k_mode; /* 0 general 4x4 K rows, 1 pinhole with skew, 2 pinhole (chosen from the uploaded Ks) */
   int32_t kernel_variant;
-  int32_t reserved0;
+  int32_t tiled_kernel; /* 1: the resident views and the grid meet the preconditions of the register-tiled
+                           kernel (axis-aligned grid matrix, pinhole K), 0: the general kernel runs */
   uint64_t device_bytes; /* HBM held by the context */
 } dmi_info;
 

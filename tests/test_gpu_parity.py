@@ -10,8 +10,12 @@ from helpers import bits_equal, oracle_params_from_golden, oracle_params_from_sc
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, capi.VARIANT_EXACT_DIVISION, capi.VARIANT_GENERAL_K,
-            capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K, 4, 8, 12]
+G = capi.VARIANT_FORCE_GENERAL
+# 0 = default: the register-tiled kernel when its preconditions hold, else the general kernel;
+# 32/64/96 = other tile shapes; G | x = the general kernel with its own switches
+VARIANTS = [0, 32, 64, 96, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
+            G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K, G | 4, G | 8, G | 12]
+TILE_SHAPES = [0, 32, 64, 96]
 
 
 def _golden_inputs(g):
@@ -142,7 +146,7 @@ def test_medium_scenes_against_oracle(dims, n_maps, wh, dense, rotated):
     views = scene.make_views(n_maps, wh[0], wh[1], seed=7, dense=dense)
     want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                    n_threads=oracle.max_threads())
-    for variant in (0, capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K):
+    for variant in (0, 64, G, G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K):
         out, vh, mh = capi.fuse_once(grid, rp, views, kernel_variant=variant)
         assert np.array_equal(mh, mh_w) and np.array_equal(vh, vh_w) and bits_equal(out, want)
 
@@ -164,6 +168,73 @@ def test_near_half_pixel_stress_fast_path_equals_exact():
     depth = rng.uniform(0.25, 3.0, size=(n, H, W))
     views = scene.Views(depth, K4, RT4)
     want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), depth, K4, RT4)
-    for variant in (0, capi.VARIANT_EXACT_DIVISION):
+    for variant in TILE_SHAPES + [G, G | capi.VARIANT_EXACT_DIVISION]:
         out, vh, mh = capi.fuse_once(grid, rp, views, kernel_variant=variant)
         assert np.array_equal(mh, mh_w) and np.array_equal(vh, vh_w) and bits_equal(out, want)
+
+
+def test_tiled_kernel_is_selected_only_when_its_preconditions_hold():
+    """Axis-aligned grid + pinhole K -> tiled kernel; rotated grid or general K -> general kernel."""
+    from conftest import load_golden
+    expect = {"generic_sphere_32": 1, "noncubic_70x33x17": 1, "anisotropic_rotated": 0, "general_k_f64_depth": 0}
+    for name, want in expect.items():
+        grid, rp, views, thr = _golden_inputs(load_golden(name))
+        with capi.FusionContext(grid, rp) as ctx:
+            ctx.add_views(views, thr)
+            assert ctx.info().tiled_kernel == want, name
+        with capi.FusionContext(grid, rp, kernel_variant=G) as ctx:
+            ctx.add_views(views, thr)
+            assert ctx.info().tiled_kernel == 0
+
+
+@pytest.mark.parametrize("shape", TILE_SHAPES)
+@pytest.mark.parametrize("case", ["scaled_translated_grid", "cameras_inside", "skewed_k", "thin_grid", "f64_depth",
+                                  "negative_axes"])
+def test_tiled_kernel_cases_against_oracle(shape, case):
+    """Inputs that exercise the tiled kernel's preconditions and its fallbacks, checked bit for bit."""
+    rng = np.random.default_rng(11)
+    dims, wh, n, dense = (40, 27, 21), (96, 72), 7, True
+    gm = np.eye(4)
+    radius = 3.0
+    if case == "scaled_translated_grid":
+        gm = np.diag([1.25, 0.75, 2.0, 1.0])
+        gm[:3, 3] = [0.125, -0.25, 0.0625]
+    elif case == "negative_axes":
+        gm = np.diag([-1.0, 1.0, -1.0, 1.0])
+    elif case == "cameras_inside":
+        radius = 0.45      # cameras inside the grid: voxels behind them take the c.z < 0 exit (cu:177)
+    elif case == "thin_grid":
+        dims = (130, 9, 3)
+    grid = scene.GridDesc(dims, (-1.0, -1.0, -1.0), tuple(2.0 / d for d in dims), gm)
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(n, wh[0], wh[1], seed=3, dense=dense, radius=radius)
+    if case == "skewed_k":
+        views.K4[:, 0, 1] = 0.37
+    if case == "f64_depth":
+        views.depth[:] = np.where(views.depth == -1.0, -1.0, views.depth * (1 + 2.0 ** -40))
+    p = oracle_params_from_scene(grid, rp, views)
+    want, vh_w, mh_w = oracle.fuse(p, views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())
+    with capi.FusionContext(grid, rp, count_hits=True, kernel_variant=shape) as ctx:
+        ctx.add_views(views)
+        assert ctx.info().tiled_kernel == 1
+        if case == "f64_depth":
+            assert ctx.info().depth_storage_in_use == capi.DMI_DEPTH_F64
+        ctx.fuse()
+        out = ctx.download_grid()
+        vh, mh = ctx.download_hits()
+    assert mh_w.sum() > 0
+    assert np.array_equal(mh, mh_w) and np.array_equal(vh, vh_w) and bits_equal(out, want)
+
+
+def test_tiled_kernel_keeps_negative_zero_semantics():
+    """-0.0 in the initial grid survives only until the first accumulate: x + 0.0 turns it into +0.0
+    exactly where the reference adds a zero (far behind the surface, cu:115)."""
+    grid = scene.default_grid(24)
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(3, 64, 48, seed=9, dense=True)
+    init = np.full((24, 24, 24), -0.0)
+    want, _, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, init_grid=init)
+    for variant in (0, G):
+        out, _, _ = capi.fuse_once(grid, rp, views, init_grid=init, kernel_variant=variant)
+        assert bits_equal(out, want)
+    assert np.signbit(want).any() and (~np.signbit(want)).any()
