@@ -60,19 +60,24 @@ def algorithmic_bytes(n_vox: int, n_maps: int, w: int, h: int, grid_bytes: int, 
 
 
 def cpu_baseline(grid, ray, views, target_seconds: float = 15.0):
-    """Time the CPU oracle on all host cores on the first m maps over the full grid."""
+    """Time the CPU oracle on all host cores on the first m maps over the full grid.  A one-map pass
+    measures this host's rate first, so that m is sized for about `target_seconds` of CPU work."""
     from oracle import oracle
 
     cores = oracle.max_threads()
     n_vox = grid.n_voxels
-    # ~18 M projections/s/thread measured for this arithmetic (BASELINE.md); size the sample for ~target_seconds
-    m = int(max(1, min(views.n, round(target_seconds * 18e6 * cores / n_vox))))
     p = oracle.make_params(grid.cell_dims, grid.origin, grid.spacing, grid.grid_matrix, ray.thickness, ray.rho,
                            ray.eta, ray.delta, views.width, views.height)
-    depth = np.ascontiguousarray(views.depth[:m], dtype=np.float64)
-    t0 = time.perf_counter()
-    oracle.fuse(p, depth, views.K4[:m], views.RT4[:m], count_hits=False, n_threads=cores)
-    dt = time.perf_counter() - t0
+
+    def run(m):
+        depth = np.ascontiguousarray(views.depth[:m], dtype=np.float64)
+        t0 = time.perf_counter()
+        oracle.fuse(p, depth, views.K4[:m], views.RT4[:m], count_hits=False, n_threads=cores)
+        return time.perf_counter() - t0
+
+    probe = run(1)
+    m = int(max(1, min(views.n, round(target_seconds / max(probe, 1e-3)))))
+    dt = run(m)
     return {
         "value": n_vox * m / dt / 1e9,
         "unit": "Gvoxel-projections/s",
@@ -223,6 +228,7 @@ def main():
             "grid_dtype": args.grid_dtype,
             "depth_storage": "f64" if depth_bytes == 8 else "f32",
             "k_mode": int(info.k_mode),
+            "tiled_kernel": int(info.tiled_kernel),
             "kernel_variant": args.variant,
             "maps_total": total_maps,
             "parallelism": f"depth-map shards x{world}, one RCCL all-reduce of the grid" if world > 1 else "single GPU",
@@ -235,7 +241,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbps / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "kernel": "dmi::fuse_kernel",
+            "kernel": "dmi::fuse_tile_kernel" if info.tiled_kernel else "dmi::fuse_kernel",
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": b_alg,
             "note": "fused voxel-stationary order is fp64-VALU bound, not HBM bound: see roofline_valu and DESIGN.md",
