@@ -105,7 +105,7 @@ def main():
 
     import torch
 
-    from cudadepthmapintegration_amd import capi, scene
+    from cudadepthmapintegration_amd import capi, scene, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +154,7 @@ def main():
         ctx.reset_grid()
         ctx.fuse()
         if dist is not None:
-            dist.all_reduce(grid_t)  # the single RCCL all-reduce of the TSDF grid over xGMI
+            sharding.all_reduce_grid(grid_t)  # the single RCCL all-reduce of the TSDF grid over xGMI
 
     def barrier():
         if dist is not None:

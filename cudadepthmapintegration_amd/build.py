@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libdmi_hip.so")
 
-SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "coloration_kernels.hip", "dmi_capi.hip", "host/recon_host.cpp"]
+SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "coloration_kernels.hip", "dmi_capi.hip", "host/recon_host.cpp", "host/dmi_host_capi.cpp"]
 HEADERS = ["fusion_kernels.h", "fusion_device.h", os.path.join("host", "recon_host.h"),
            os.path.join("..", "..", "include", "dmi.h"), os.path.join("..", "..", "include", "dmi_host.h")]
 
@@ -70,7 +70,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = _obj(src)
         if not force and not _stale(obj, [path] + headers):
             return
-        cmd = [hipcc] + COMMON_FLAGS + (HIP_FLAGS if src.endswith(".hip") else ["-x", "hip"] + HIP_FLAGS) + ["-c", path, "-o", obj]
+        # .cpp files are host-only C++ above the C ABI: no device code, no HIP headers
+        cmd = [hipcc] + COMMON_FLAGS + (HIP_FLAGS if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -36,7 +36,7 @@ class RayPotentialC(ctypes.Structure):
 
 class OptionsC(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("grid_dtype", ctypes.c_int32), ("depth_storage", ctypes.c_int32),
-                ("count_hits", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("count_hits", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("z_first", ctypes.c_int32),
                 ("stream", ctypes.c_void_p), ("external_grid", ctypes.c_void_p)]
 
 
@@ -130,7 +130,7 @@ class FusionContext:
 
     def __init__(self, grid: GridDesc, ray: RayPotential, *, device: int = 0, grid_dtype: str = "f64",
                  depth_storage: str = "auto", count_hits: bool = False, kernel_variant: int = 0,
-                 stream: int | None = None, external_grid: int | None = None):
+                 stream: int | None = None, external_grid: int | None = None, z_first: int = 0):
         self._lib = load()
         self._h = ctypes.c_void_p()
         g = GridDescC()
@@ -149,6 +149,7 @@ class FusionContext:
         o.depth_storage = {"auto": DMI_DEPTH_AUTO, "f32": DMI_DEPTH_F32, "f64": DMI_DEPTH_F64}[depth_storage]
         o.count_hits = 1 if count_hits else 0
         o.kernel_variant = int(kernel_variant)
+        o.z_first = int(z_first)
         o.stream = stream
         o.external_grid = external_grid
         self.grid = grid
@@ -268,3 +269,187 @@ def fuse_once(grid: GridDesc, ray: RayPotential, views: Views, *, threshold: flo
         out = ctx.download_grid(np.float64)
         vh, mh = ctx.download_hits() if count_hits else (None, None)
     return out, vh, mh
+
+
+# ---- host-side mirror of the reference's operator interface (include/dmi_host.h) -----------------------
+HOST_ABI_SYMBOLS = [
+    "dmi_filter_new", "dmi_filter_delete", "dmi_filter_set_ray_potential_thickness", "dmi_filter_set_ray_potential_rho",
+    "dmi_filter_set_ray_potential_eta", "dmi_filter_set_ray_potential_delta", "dmi_filter_set_threshold_best_cost",
+    "dmi_filter_set_file_path_krtd", "dmi_filter_set_file_path_vti", "dmi_filter_set_grid_matrix",
+    "dmi_filter_set_input_data", "dmi_filter_add_view", "dmi_filter_clear_views", "dmi_filter_set_device",
+    "dmi_filter_set_kernel_variant", "dmi_filter_update", "dmi_filter_get_execution_time",
+    "dmi_filter_get_fuse_kernel_ms", "dmi_filter_get_number_of_cells", "dmi_filter_get_output",
+    "dmi_filter_last_error", "dmi_read_krtd_file", "dmi_extract_all_file_path", "dmi_k3_to_k4",
+    "dmi_apply_depth_threshold", "dmi_read_depth_map",
+]
+
+_host_bound = False
+
+
+def load_host() -> ctypes.CDLL:
+    """Bind the dmi_host.h entry points of the same shared library."""
+    global _host_bound
+    L = load()
+    if _host_bound:
+        return L
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    L.dmi_filter_new.restype = vp
+    L.dmi_filter_new.argtypes = []
+    L.dmi_filter_delete.restype = None
+    L.dmi_filter_delete.argtypes = [vp]
+    for name in ("thickness", "rho", "eta", "delta"):
+        fn = getattr(L, f"dmi_filter_set_ray_potential_{name}")
+        fn.restype, fn.argtypes = None, [vp, dbl]
+    L.dmi_filter_set_threshold_best_cost.restype, L.dmi_filter_set_threshold_best_cost.argtypes = None, [vp, dbl]
+    L.dmi_filter_set_file_path_krtd.restype, L.dmi_filter_set_file_path_krtd.argtypes = None, [vp, ctypes.c_char_p]
+    L.dmi_filter_set_file_path_vti.restype, L.dmi_filter_set_file_path_vti.argtypes = None, [vp, ctypes.c_char_p]
+    L.dmi_filter_set_grid_matrix.restype, L.dmi_filter_set_grid_matrix.argtypes = None, [vp, dp]
+    L.dmi_filter_set_input_data.restype, L.dmi_filter_set_input_data.argtypes = None, [vp, ip, dp, dp]
+    L.dmi_filter_add_view.restype, L.dmi_filter_add_view.argtypes = ctypes.c_int, [vp, dp, dp, i32, i32, dp, dp]
+    L.dmi_filter_clear_views.restype, L.dmi_filter_clear_views.argtypes = None, [vp]
+    L.dmi_filter_set_device.restype, L.dmi_filter_set_device.argtypes = None, [vp, i32]
+    L.dmi_filter_set_kernel_variant.restype, L.dmi_filter_set_kernel_variant.argtypes = None, [vp, i32]
+    L.dmi_filter_update.restype, L.dmi_filter_update.argtypes = ctypes.c_int, [vp]
+    L.dmi_filter_get_execution_time.restype, L.dmi_filter_get_execution_time.argtypes = dbl, [vp]
+    L.dmi_filter_get_fuse_kernel_ms.restype, L.dmi_filter_get_fuse_kernel_ms.argtypes = dbl, [vp]
+    L.dmi_filter_get_number_of_cells.restype, L.dmi_filter_get_number_of_cells.argtypes = i64, [vp]
+    L.dmi_filter_get_output.restype, L.dmi_filter_get_output.argtypes = i64, [vp, dp]
+    L.dmi_filter_last_error.restype, L.dmi_filter_last_error.argtypes = ctypes.c_char_p, [vp]
+    L.dmi_read_krtd_file.restype, L.dmi_read_krtd_file.argtypes = ctypes.c_int, [ctypes.c_char_p, dp, dp]
+    L.dmi_extract_all_file_path.restype = ctypes.c_int
+    L.dmi_extract_all_file_path.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.dmi_k3_to_k4.restype, L.dmi_k3_to_k4.argtypes = None, [dp, dp]
+    L.dmi_apply_depth_threshold.restype, L.dmi_apply_depth_threshold.argtypes = i64, [dp, dp, i64, dbl]
+    L.dmi_read_depth_map.restype, L.dmi_read_depth_map.argtypes = ctypes.c_int, [ctypes.c_char_p, ip, dp, dp, ip]
+    _host_bound = True
+    return L
+
+
+class ReconstructionFilter:
+    """The reference's vtkCudaReconstructionFilter (filt.h:48-120) through the host mirror: same setter
+    names, Update() returns RequestData's 1 / 0, the output is the "reconstruction_scalar" cell array."""
+
+    def __init__(self):
+        self._lib = load_host()
+        self._h = self._lib.dmi_filter_new()
+        if not self._h:
+            raise MemoryError("dmi_filter_new failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dmi_filter_delete(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def SetRayPotentialThickness(self, v): self._lib.dmi_filter_set_ray_potential_thickness(self._h, float(v))
+    def SetRayPotentialRho(self, v): self._lib.dmi_filter_set_ray_potential_rho(self._h, float(v))
+    def SetRayPotentialEta(self, v): self._lib.dmi_filter_set_ray_potential_eta(self._h, float(v))
+    def SetRayPotentialDelta(self, v): self._lib.dmi_filter_set_ray_potential_delta(self._h, float(v))
+    def SetThresholdBestCost(self, v): self._lib.dmi_filter_set_threshold_best_cost(self._h, float(v))
+
+    def SetFilePathKRTD(self, path):
+        self._lib.dmi_filter_set_file_path_krtd(self._h, None if path is None else os.fsencode(path))
+
+    def SetFilePathVTI(self, path):
+        self._lib.dmi_filter_set_file_path_vti(self._h, None if path is None else os.fsencode(path))
+
+    def SetGridMatrix(self, m):
+        if m is None:
+            self._lib.dmi_filter_set_grid_matrix(self._h, None)
+            return
+        a = np.ascontiguousarray(m, dtype=np.float64).reshape(16)
+        self._lib.dmi_filter_set_grid_matrix(self._h, _dp(a))
+
+    def SetInputData(self, point_dims, origin, spacing):
+        d = (ctypes.c_int32 * 3)(*[int(x) for x in point_dims])
+        o = np.ascontiguousarray(origin, dtype=np.float64)
+        s = np.ascontiguousarray(spacing, dtype=np.float64)
+        self._point_dims = tuple(int(x) for x in point_dims)
+        self._lib.dmi_filter_set_input_data(self._h, d, _dp(o), _dp(s))
+
+    def AddView(self, depths, K3, RT4, best_cost=None):
+        d = np.ascontiguousarray(depths, dtype=np.float64)
+        H, W = d.shape
+        bc = None if best_cost is None else np.ascontiguousarray(best_cost, dtype=np.float64)
+        k = np.ascontiguousarray(K3, dtype=np.float64).reshape(9)
+        rt = np.ascontiguousarray(RT4, dtype=np.float64).reshape(16)
+        if not self._lib.dmi_filter_add_view(self._h, _dp(d), _dp(bc) if bc is not None else None, W, H, _dp(k), _dp(rt)):
+            raise ValueError("dmi_filter_add_view rejected the view")
+
+    def ClearViews(self): self._lib.dmi_filter_clear_views(self._h)
+    def SetDevice(self, d): self._lib.dmi_filter_set_device(self._h, int(d))
+    def SetKernelVariant(self, v): self._lib.dmi_filter_set_kernel_variant(self._h, int(v))
+    def Update(self) -> int: return int(self._lib.dmi_filter_update(self._h))
+    def GetExecutionTime(self) -> float: return float(self._lib.dmi_filter_get_execution_time(self._h))
+    def GetFuseKernelMs(self) -> float: return float(self._lib.dmi_filter_get_fuse_kernel_ms(self._h))
+    def GetNumberOfCells(self) -> int: return int(self._lib.dmi_filter_get_number_of_cells(self._h))
+    def LastError(self) -> str: return self._lib.dmi_filter_last_error(self._h).decode()
+
+    def GetOutputScalars(self) -> np.ndarray:
+        """The "reconstruction_scalar" cell array as [nz, ny, nx] (x fastest, filt.cxx:129-135)."""
+        n = self.GetNumberOfCells()
+        out = np.zeros(n, dtype=np.float64)
+        got = self._lib.dmi_filter_get_output(self._h, _dp(out))
+        if got != n:
+            return out[:got]
+        px, py, pz = self._point_dims
+        return out.reshape(pz - 1, py - 1, px - 1)
+
+
+def read_krtd_file(path):
+    L = load_host()
+    K = np.zeros(9)
+    RT = np.zeros(16)
+    ok = L.dmi_read_krtd_file(os.fsencode(path), _dp(K), _dp(RT))
+    return bool(ok), K.reshape(3, 3), RT.reshape(4, 4)
+
+
+def extract_all_file_path(list_path):
+    L = load_host()
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = L.dmi_extract_all_file_path(os.fsencode(list_path), buf, len(buf))
+    paths = buf.value.decode().split("\n") if n else []
+    return paths
+
+
+def k3_to_k4(K3):
+    L = load_host()
+    k = np.ascontiguousarray(K3, dtype=np.float64).reshape(9)
+    out = np.zeros(16)
+    L.dmi_k3_to_k4(_dp(k), _dp(out))
+    return out.reshape(4, 4)
+
+
+def apply_depth_threshold(depths, best_cost, threshold):
+    L = load_host()
+    d = np.ascontiguousarray(depths, dtype=np.float64).copy()
+    b = np.ascontiguousarray(best_cost, dtype=np.float64)
+    changed = L.dmi_apply_depth_threshold(_dp(d.reshape(-1)), _dp(b.reshape(-1)), d.size, float(threshold))
+    return d, int(changed)
+
+
+def read_depth_map(path):
+    L = load_host()
+    dims = (ctypes.c_int32 * 3)()
+    has = ctypes.c_int32(0)
+    if not L.dmi_read_depth_map(os.fsencode(path), dims, None, None, ctypes.byref(has)):
+        return None
+    n = dims[0] * dims[1] * dims[2]
+    d = np.zeros(n)
+    bc = np.zeros(n)
+    L.dmi_read_depth_map(os.fsencode(path), dims, _dp(d), _dp(bc), ctypes.byref(has))
+    shape = (dims[1], dims[0])
+    return d.reshape(shape), (bc.reshape(shape) if has.value else None)

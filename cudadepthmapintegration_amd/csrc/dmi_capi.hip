@@ -260,8 +260,9 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   t.dhy = Q[2] * dz;
   // magnitudes: |w| is largest at a grid corner (each w component is monotone in its own index)
   double lo[3], hi[3], wm[3];
-  voxel_world(ctx->grid, 0, 0, 0, lo);
-  voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1, ctx->grid.cell_dims[2] - 1 + kMaxColumn, hi);
+  voxel_world(ctx->grid, 0, 0, ctx->opt.z_first, lo);
+  voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1,
+              ctx->opt.z_first + ctx->grid.cell_dims[2] - 1 + kMaxColumn, hi);
   for (int a = 0; a < 3; ++a) wm[a] = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
   double M[3];
   for (int row = 0; row < 3; ++row)
@@ -428,6 +429,7 @@ int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dm
   if (opt) o = *opt;
   if (o.grid_dtype != DMI_F32 && o.grid_dtype != DMI_F64) return bad("dmi_create: grid_dtype must be DMI_F32 or DMI_F64");
   if (o.depth_storage < DMI_DEPTH_AUTO || o.depth_storage > DMI_DEPTH_F64) return bad("dmi_create: bad depth_storage");
+  if (o.z_first < 0 || (int64_t)o.z_first + grid->cell_dims[2] > (int64_t)0x3fffffff) return bad("dmi_create: z_first out of range");
   // the reference refuses only rho == 0 && thickness == 0 (filt.cxx:138-142); so do we
   if (ray->rho == 0 && ray->thickness == 0) return bad("dmi_create: ray potential rho and thickness are both 0 (filt.cxx:138)");
   if ((int64_t)(grid->cell_dims[1] + 3) / 4 > 65535 || (int64_t)grid->cell_dims[2] > 65535)
@@ -446,7 +448,7 @@ int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dm
   for (int i = 0; i < 12; ++i) ctx->finite_bounded = ctx->finite_bounded && bounded(grid->grid_matrix[i]);
   for (int a = 0; a < 3; ++a)
     ctx->finite_bounded = ctx->finite_bounded && bounded(grid->origin[a]) &&
-                          bounded(grid->spacing[a] * (grid->cell_dims[a] + 1.0));
+                          bounded(grid->spacing[a] * (grid->cell_dims[a] + 1.0 + (a == 2 ? o.z_first : 0)));
 
   auto hip_fail = [&](hipError_t e, const char *what) {
     (void)hipGetLastError();
@@ -607,6 +609,7 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   a.first_map = first;
   a.n_maps = count;
   a.init_from_grid = ctx->grid_is_zero ? 0 : 1;
+  a.kz0 = ctx->opt.z_first;
   a.ox = ctx->grid.origin[0];
   a.oy = ctx->grid.origin[1];
   a.oz = ctx->grid.origin[2];
@@ -651,6 +654,7 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
     if ((int64_t)t.super_x * t.super_y * t.super_z * 32 > (int64_t)0x7fffffff)
       return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: grid too large for one launch");
     t.depth_bytes = (int32_t)((int64_t)a.W * a.H * (ctx->depth_f64 ? 8 : 4));
+    t.kz0 = a.kz0;
     t.ox = a.ox; t.oy = a.oy; t.oz = a.oz; t.sx = a.sx; t.sy = a.sy; t.sz = a.sz;
     std::memcpy(t.g, a.g, sizeof(t.g));
     t.thick = a.thick; t.delta = a.delta; t.rho_pos = a.rho_pos; t.rho_neg = a.rho_neg;

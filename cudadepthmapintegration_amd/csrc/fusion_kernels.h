@@ -48,6 +48,7 @@ struct FuseArgs {
   int32_t W, H;        // depth-map dims (c_depthMapDims, cu:59)
   int32_t first_map, n_maps;
   int32_t init_from_grid;  // 0: grid is known to be all zero, skip the read
+  int32_t kz0, pad1;       // global cell index of this context's first z layer (dmi_options::z_first)
   double ox, oy, oz;       // c_gridOrig
   double sx, sy, sz;       // c_gridSpacing
   double g[12];            // rows 0..2 of c_gridMatrix
@@ -69,6 +70,7 @@ struct TileArgs {
   int32_t bricks_x, bricks_y, bricks_z;  // workgroup bricks per axis
   int32_t super_x, super_y, super_z;     // super-bricks (4 x 4 x 2 bricks) per axis, XCD-aware ordering
   int32_t depth_bytes;                   // W * H * sizeof(depth element): buffer range of one depth table
+  int32_t kz0, pad1;                     // global cell index of the first z layer
   double ox, oy, oz, sx, sy, sz;         // c_gridOrig, c_gridSpacing
   double g[12];                          // rows 0..2 of c_gridMatrix (3x3 part diagonal)
   double thick, delta, rho_pos, rho_neg, slope, free_space;  // as in FuseArgs

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs a) {
   // cu:78-83 computeVoxelCenter, cu:168 grid matrix -- once per voxel instead of once per map
   const double gx = a.ox + (i + 0.5) * a.sx;
   const double gy = a.oy + (j + 0.5) * a.sy;
-  const double gz = a.oz + (k + 0.5) * a.sz;
+  const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;  // global cell index (z-slab contexts)
   const double wx = row4(a.g + 0, gx, gy, gz);
   const double wy = row4(a.g + 4, gx, gy, gz);
   const double wz = row4(a.g + 8, gx, gy, gz);

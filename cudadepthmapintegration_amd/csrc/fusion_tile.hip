@@ -122,7 +122,7 @@ __device__ __forceinline__ bool tile_exact(const FuseArgs *__restrict__ fa, int 
   const int W = cload(&fa->W), H = cload(&fa->H);
   const double gx = cload(&fa->ox) + (i + 0.5) * cload(&fa->sx);  // cu:80-82
   const double gy = cload(&fa->oy) + (j + 0.5) * cload(&fa->sy);
-  const double gz = cload(&fa->oz) + (k + 0.5) * cload(&fa->sz);
+  const double gz = cload(&fa->oz) + ((k + cload(&fa->kz0)) + 0.5) * cload(&fa->sz);
   const double wx = row4(g + 0, gx, gy, gz);  // cu:168
   const double wy = row4(g + 4, gx, gy, gz);
   const double wz = row4(g + 8, gx, gy, gz);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // depend on the other indices, and no later step observes it: DESIGN.md).
   const double gx = a.ox + (i + 0.5) * a.sx;
   const double gy = a.oy + (j + 0.5) * a.sy;
-  const double gz0 = a.oz + (k0 + 0.5) * a.sz;
+  const double gz0 = a.oz + ((k0 + a.kz0) + 0.5) * a.sz;
   const double wx = row4(a.g + 0, gx, gy, gz0);
   const double wy = row4(a.g + 4, gx, gy, gz0);
   const double wz0 = row4(a.g + 8, gx, gy, gz0);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const M
   if (k >= a.kpad) return;
   const double gx = a.ox + (0 + 0.5) * a.sx;
   const double gy = a.oy + (0 + 0.5) * a.sy;
-  const double gz = a.oz + (k + 0.5) * a.sz;
+  const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
   const double wz = row4(a.g + 8, gx, gy, gz);  // cu:168 row 2; depends on k only (diagonal 3x3)
   // rows above the grid: -inf makes c.z = -inf there, which the kernel treats as behind the camera
   table[(int64_t)m * a.kpad + k] = k < a.nz ? maps[m].rt[10] * wz : -__builtin_inf();

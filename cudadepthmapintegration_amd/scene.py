@@ -162,3 +162,44 @@ def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", de
                                        background=(radius + 0.5) if dense else None)
     best = rng.random((n, H, W)) if with_best_cost else None
     return Views(depth, K4, RT4, best)
+
+
+# ---- file forms of a view (what the reference's filter reads: Sources/Helper.h:105-168, RD.cxx:223-229) ----
+def write_krtd(path: str, K3: np.ndarray, RT4: np.ndarray) -> None:
+    """.krtd text: 3 lines K, blank, 3 lines R, blank, 1 line T (%.17g round-trips every double)."""
+    f = lambda row: " ".join("%.17g" % float(v) for v in row)
+    lines = [f(K3[i]) for i in range(3)] + [""] + [f(RT4[i, :3]) for i in range(3)] + ["", f(RT4[:3, 3]), "0"]
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def write_vti_ascii(path: str, depth: np.ndarray, best_cost: np.ndarray | None = None) -> None:
+    """Minimal ascii VTK XML ImageData with the point arrays the path reads ("Depths", "Best Cost Values")."""
+    H, W = depth.shape
+    def arr(name, a):
+        vals = " ".join("%.17g" % float(v) for v in np.asarray(a, dtype=np.float64).reshape(-1))
+        return f'        <DataArray type="Float64" Name="{name}" format="ascii">\n          {vals}\n        </DataArray>\n'
+    body = arr("Depths", depth) + (arr("Best Cost Values", best_cost) if best_cost is not None else "")
+    with open(path, "w") as fh:
+        fh.write('<?xml version="1.0"?>\n<VTKFile type="ImageData" version="0.1" byte_order="LittleEndian">\n'
+                 f'  <ImageData WholeExtent="0 {W - 1} 0 {H - 1} 0 0" Origin="0 0 0" Spacing="1 1 1">\n'
+                 f'    <Piece Extent="0 {W - 1} 0 {H - 1} 0 0">\n      <PointData Scalars="Depths">\n{body}'
+                 '      </PointData>\n    </Piece>\n  </ImageData>\n</VTKFile>\n')
+
+
+def write_view_files(directory: str, views: "Views"):
+    """Writes frame_XXXX.vti / .krtd plus vtiList.txt / krtdList.txt; returns the two list paths."""
+    import os
+    vti, krtd = [], []
+    for m in range(views.n):
+        v, k = f"frame_{m:04d}.vti", f"frame_{m:04d}.krtd"
+        write_vti_ascii(os.path.join(directory, v), views.depth[m], None if views.best_cost is None else views.best_cost[m])
+        write_krtd(os.path.join(directory, k), views.K4[m][:3, :3], views.RT4[m])
+        vti.append(v)
+        krtd.append(k)
+    lv, lk = os.path.join(directory, "vtiList.txt"), os.path.join(directory, "krtdList.txt")
+    with open(lv, "w") as fh:
+        fh.write("".join(f"{i} {p}\n" for i, p in enumerate(vti)))
+    with open(lk, "w") as fh:
+        fh.write("".join(f"{i} {p}\n" for i, p in enumerate(krtd)))
+    return lv, lk

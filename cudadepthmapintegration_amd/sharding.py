@@ -1,0 +1,49 @@
+"""Multi-GPU partitioning of one fusion (one process per GPU, torch.distributed; backend "nccl" is RCCL).
+
+The fusion is a sum over depth maps of independent per-voxel terms (CudaReconstruction.cu:211), so it
+shards two ways:
+
+  * depth-map shards (the north-star contract): rank r fuses views [lo, hi) into its own full grid, then
+    ONE all-reduce(sum) of the f32 TSDF grid over xGMI.  The summation order changes: |delta| <=
+    (G-1) * 2^-24 * sum|partials| per voxel; hit counters all-reduce as integers and stay exact.
+  * z-slabs (no collective): rank r owns cell layers [z0, z1) of the grid (dmi_options.z_first), fuses
+    ALL views into them and hands its slab to the host: bit-identical to a single-GPU fusion.
+
+Only the partition arithmetic and the collective live here; the fusion itself is the C ABI (capi.py).
+"""
+from __future__ import annotations
+
+
+def view_shard(n_views: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced range [lo, hi) of views for `rank` (first n_views % world ranks get one more)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank/world out of range")
+    base, extra = divmod(int(n_views), world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def z_slab(nz: int, rank: int, world: int, multiple: int = 1) -> tuple[int, int]:
+    """Cell layers [z0, z1) owned by `rank`; slab boundaries fall on multiples of `multiple` (the tiled
+    kernel's column height) except at the top of the grid."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank/world out of range")
+    units = -(-int(nz) // multiple)
+    lo, hi = view_shard(units, rank, world)
+    return min(lo * multiple, nz), min(hi * multiple, nz)
+
+
+def all_reduce_grid(grid_tensor, group=None):
+    """The path's single exchange step: sum the per-rank TSDF grids in place (RCCL ring/direct over xGMI
+    on GPUs, gloo in the CPU tests).  Also used for the integer hit counters."""
+    import torch.distributed as dist
+
+    dist.all_reduce(grid_tensor, op=dist.ReduceOp.SUM, group=group)
+    return grid_tensor
+
+
+def sharded_tolerance(world: int, abs_partial_sum):
+    """Bound on |all-reduced f32 grid - single-GPU f64 grid| per voxel: each rank rounds its partial to f32
+    (2^-24 relative), the reduction adds world-1 f32 roundings of partial sums, fp64 reordering is
+    below that."""
+    return (2 * world) * 2.0 ** -24 * abs_partial_sum + 1e-30

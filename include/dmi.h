@@ -86,7 +86,10 @@ typedef struct dmi_options {
   int32_t kernel_variant; /* 0 = default; bit field of tuning / test switches (DESIGN.md "kernel_variant"):
                              1 exact division in the general kernel, 2 ignore K structure, 4|8 block shape of
                              the general kernel, 16 never use the tiled kernel, 32..224 tile shape */
-  int32_t reserved0;
+  int32_t z_first;        /* this context's grid is the z-slab [z_first, z_first + cell_dims[2]) of a taller grid
+                             with the same origin and spacing: voxel k has the centre of global cell z_first + k
+                             (cu:78-83 with the global index), so slabs fused on different GPUs are bit-identical
+                             to one fusion of the whole grid.  0 = the whole grid */
   void *stream;           /* hipStream_t to run on; NULL = a stream owned by the context */
   void *external_grid;    /* device pointer to a caller-owned grid of grid_dtype[n_voxels]
                              (e.g. a torch tensor that is later all-reduced); NULL = context-owned */

@@ -238,3 +238,55 @@ def test_tiled_kernel_keeps_negative_zero_semantics():
         out, _, _ = capi.fuse_once(grid, rp, views, init_grid=init, kernel_variant=variant)
         assert bits_equal(out, want)
     assert np.signbit(want).any() and (~np.signbit(want)).any()
+
+
+@pytest.mark.parametrize("variant", [0, G])
+def test_z_slab_contexts_are_bit_identical_to_one_fusion(variant):
+    """The zero-collective multi-GPU partition (dmi_options.z_first): each slab is fused by its own context
+    (on its own GPU in production) and the concatenation equals the single fusion bit for bit."""
+    from cudadepthmapintegration_amd import sharding
+    grid = scene.default_grid((40, 24, 37))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(6, 80, 60, seed=13, dense=True)
+    want, vh_w, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                n_threads=oracle.max_threads())
+    world = 3
+    parts, hits = [], []
+    for r in range(world):
+        z0, z1 = sharding.z_slab(37, r, world, multiple=16)
+        if z1 == z0:
+            continue
+        slab = scene.GridDesc((40, 24, z1 - z0), grid.origin, grid.spacing, grid.grid_matrix)
+        with capi.FusionContext(slab, rp, count_hits=True, kernel_variant=variant, z_first=z0) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            parts.append(ctx.download_grid())
+            hits.append(ctx.download_hits()[0])
+    assert bits_equal(np.concatenate(parts, axis=0), want)
+    assert np.array_equal(np.concatenate(hits, axis=0), vh_w)
+
+
+def test_view_shards_summed_in_f32_are_within_the_stated_tolerance():
+    """The north-star partition on one GPU: each shard of views fused into its own f32 grid, grids summed as
+    the all-reduce does; hit counters sum exactly."""
+    from cudadepthmapintegration_amd import sharding
+    grid = scene.default_grid((48, 40, 32))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(10, 96, 72, seed=17, dense=True)
+    want, vh_w, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                n_threads=oracle.max_threads())
+    world = 4
+    total = np.zeros(want.shape, dtype=np.float32)
+    absum = np.zeros(want.shape)
+    hits = np.zeros(want.shape, dtype=np.int64)
+    for r in range(world):
+        lo, hi = sharding.view_shard(views.n, r, world)
+        with capi.FusionContext(grid, rp, grid_dtype="f32", count_hits=True) as ctx:
+            ctx.add_views(views.subset(lo, hi))
+            ctx.fuse()
+            part = ctx.download_grid(np.float32)
+            total = total + part            # f32 adds, as ncclFloat sum
+            absum += np.abs(part)
+            hits += ctx.download_hits()[0]
+    assert np.array_equal(hits, vh_w.astype(np.int64))
+    assert np.all(np.abs(total.astype(np.float64) - want) <= sharding.sharded_tolerance(world, absum))

@@ -1,0 +1,98 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the N > 1 path: view shards + one all-reduce of the f32
+grid, and z-slab ownership.  The per-rank fusion is done by the oracle here (there is no GPU in this
+container; the oracle is the checker's arithmetic), so what is under test is the partition arithmetic,
+the collective and the stated tolerance; tests/test_gpu_parity.py runs the same partitions through the
+HIP path on one GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from cudadepthmapintegration_amd import scene, sharding
+
+
+def test_view_shard_is_a_balanced_partition():
+    for n in (0, 1, 7, 256, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            r = [sharding.view_shard(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_z_slab_respects_column_height():
+    for nz in (1, 17, 512, 1000):
+        for world in (1, 2, 8):
+            for mult in (1, 16, 32):
+                r = [sharding.z_slab(nz, k, world, mult) for k in range(world)]
+                assert r[0][0] == 0 and r[-1][1] == nz
+                assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+                assert all(lo % mult == 0 for lo, hi in r if lo < nz)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle
+    from helpers import oracle_params_from_scene
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grid = scene.default_grid((28, 24, 20))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(9, 64, 48, seed=5, dense=True)   # 9 views over 2 ranks: 5 + 4
+    p = oracle_params_from_scene(grid, rp, views)
+    lo, hi = sharding.view_shard(views.n, rank, world)
+    part, vh, mh = oracle.fuse(p, views.depth[lo:hi], views.K4[lo:hi], views.RT4[lo:hi])
+    g32 = torch.from_numpy(part.astype(np.float32))            # each rank's grid is f32 on the device
+    absum = torch.from_numpy(np.abs(part))
+    hits = torch.from_numpy(vh.astype(np.int64))
+    sharding.all_reduce_grid(g32)                               # the path's single exchange step
+    sharding.all_reduce_grid(absum)
+    sharding.all_reduce_grid(hits)
+    # z-slab ownership: every rank fuses all views into its own layers
+    z0, z1 = sharding.z_slab(grid.cell_dims[2], rank, world, multiple=8)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "reduced.npz"), grid=g32.numpy(), absum=absum.numpy(), hits=hits.numpy())
+    np.save(os.path.join(out_dir, f"slab_{rank}.npy"), np.array([z0, z1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_shards_plus_all_reduce_match_single_fusion(tmp_path):
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle
+    from helpers import oracle_params_from_scene
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    grid = scene.default_grid((28, 24, 20))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(9, 64, 48, seed=5, dense=True)
+    want, vh, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4)
+    got = np.load(tmp_path / "reduced.npz")
+    assert np.array_equal(got["hits"], vh.astype(np.int64))                  # integers: bit-exact
+    tol = sharding.sharded_tolerance(world, got["absum"])
+    assert np.all(np.abs(got["grid"].astype(np.float64) - want) <= tol)    # stated float tolerance
+    assert np.abs(want).max() > 0.1
+    slabs = [tuple(np.load(tmp_path / f"slab_{r}.npy")) for r in range(world)]
+    assert slabs[0][0] == 0 and slabs[-1][1] == 20 and slabs[0][1] == slabs[1][0] and slabs[0][1] % 8 == 0
