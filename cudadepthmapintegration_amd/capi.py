@@ -21,6 +21,7 @@ DMI_DEPTH_AUTO, DMI_DEPTH_F32, DMI_DEPTH_F64 = 0, 1, 2
 VARIANT_EXACT_DIVISION = 1  # disable the checked-reciprocal fast path
 VARIANT_GENERAL_K = 2  # ignore K structure, evaluate the full 4x4 rows
 VARIANT_FORCE_GENERAL = 16  # never use the register-tiled kernel
+VARIANT_NO_BRICK_CLASSES = 256  # tiled kernel without the proven per-brick shortcuts
 VARIANT_TILE_SHAPE = {"tk16_2x2": 0, "tk32_2x2": 32, "tk32_4x4": 64, "tk8_2x2": 96}  # tiled kernel shapes
 
 
@@ -58,7 +59,7 @@ ABI_SYMBOLS = [
     "dmi_default_options", "dmi_create", "dmi_destroy", "dmi_last_error", "dmi_add_views", "dmi_add_views_f32",
     "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
-    "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
+    "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
 ]
 
 _lib = None
@@ -105,6 +106,7 @@ def load() -> ctypes.CDLL:
     L.dmi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.dmi_download_hits.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_grid_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
+    L.dmi_get_brick_class_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -246,6 +248,12 @@ class FusionContext:
         p = ctypes.c_void_p()
         self._check(self._lib.dmi_grid_device_pointer(self._h, ctypes.byref(p)))
         return int(p.value)
+
+    def brick_class_histogram(self) -> dict:
+        """(brick, view) pairs of the last fuse by proven class (diagnostic)."""
+        h = (ctypes.c_uint64 * 4)()
+        self._check(self._lib.dmi_get_brick_class_histogram(self._h, h))
+        return {"mixed": int(h[0]), "free": int(h[1]), "behind": int(h[2]), "skip": int(h[3])}
 
     def timings(self) -> TimingsC:
         t = TimingsC()

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -25,7 +26,8 @@ namespace {
 thread_local std::string g_create_error;
 
 struct Batch {
-  void *d_depth = nullptr;  // n * W * H values of the context's current storage type
+  void *d_depth = nullptr;             // n * W * H values of the context's current storage type
+  dmi::DepthTile *d_pyramid = nullptr;  // n min/max pyramids (fusion_classify.hip)
   int32_t n = 0;
 };
 
@@ -72,6 +74,12 @@ struct dmi_context {
   FuseArgs *d_fuse_args = nullptr;
   double max_tile_err = 0.0;     // largest TileMapRec::err among the resident views
   bool last_fuse_tiled = false;
+  bool last_fuse_classes = false;
+  int64_t last_class_bricks = 0;  // wave bricks of the last fuse
+  int32_t last_class_pitch = 0, last_first = 0, last_count = 0;
+  dmi::PyramidDesc pyramid{};    // geometry of every view's depth min/max pyramid
+  uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch]
+  size_t classes_capacity = 0;   // bytes
 
   double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
   size_t stage_capacity = 0;  // elements per staging buffer
@@ -178,6 +186,17 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   b.n = n;
   DMI_HIP(ctx, hipMalloc(&b.d_depth, npix * n * esz));
   ctx->device_bytes += npix * n * esz;
+  const size_t pyr_bytes = (size_t)ctx->pyramid.total_tiles * n * sizeof(dmi::DepthTile);
+  {
+    hipError_t pe = hipMalloc(&b.d_pyramid, pyr_bytes);
+    if (pe != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(b.d_depth);
+      ctx->device_bytes -= npix * n * esz;
+      return fail(ctx, DMI_ERR_OUT_OF_MEMORY, std::string("hipMalloc(pyramid): ") + hipGetErrorString(pe));
+    }
+  }
+  ctx->device_bytes += pyr_bytes;
   *lossy_out = 0;
   int rc = DMI_OK;
   // Every path ends in a device kernel that writes the table top row first (the reference's vtk order is
@@ -205,6 +224,10 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
                                         ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->d_lossy, ctx->stream);
       }
     }
+    // depth bounds per 8x8 ... image-sized tile of every table: what the brick classification reads
+    if (e == hipSuccess)
+      e = dmi::launch_build_pyramids(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H, ctx->pyramid, b.d_pyramid,
+                                     ctx->stream);
     if (e == hipSuccess)
       e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -212,7 +235,8 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   }
   if (rc != DMI_OK) {
     (void)hipFree(b.d_depth);
-    ctx->device_bytes -= npix * n * esz;
+    (void)hipFree(b.d_pyramid);
+    ctx->device_bytes -= npix * n * esz + pyr_bytes;
     return rc;
   }
   *out = b;
@@ -304,6 +328,7 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     ctx->depth_f64 = ctx->opt.depth_storage == DMI_DEPTH_F64;
     ctx->k_mode = ctx->finite_bounded ? (int)dmi::K_PINHOLE : (int)dmi::K_GENERAL;
     ctx->max_tile_err = 0.0;
+    ctx->pyramid = dmi::make_pyramid_desc(width, height);
   }
   const size_t npix = (size_t)width * height;
 
@@ -314,7 +339,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
   if (lossy != 0 && !ctx->depth_f64 && ctx->opt.depth_storage == DMI_DEPTH_AUTO) {
     // some depth is not an f32: keep every bit -> promote the whole store and redo this batch in f64
     (void)hipFree(b.d_depth);
-    ctx->device_bytes -= npix * n * 4;
+    (void)hipFree(b.d_pyramid);
+    ctx->device_bytes -= npix * n * 4 + (size_t)ctx->pyramid.total_tiles * n * sizeof(dmi::DepthTile);
     rc = promote_to_f64(ctx);
     if (rc != DMI_OK) return rc;
     rc = upload_batch(ctx, depth64, depth32, best_cost, threshold, n, &b, &lossy);
@@ -329,6 +355,7 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     std::memcpy(r.rt, RT4 + 16 * (size_t)m, 12 * sizeof(double));
     std::memcpy(r.k, K4 + 16 * (size_t)m, 12 * sizeof(double));
     r.depth = static_cast<const char *>(b.d_depth) + (size_t)m * npix * esz;
+    r.pyramid = b.d_pyramid + (size_t)m * ctx->pyramid.total_tiles;
     ctx->h_maps.push_back(r);
     const int km = classify_k(r.k, r.rt);
     if (km < ctx->k_mode) ctx->k_mode = km;
@@ -503,7 +530,11 @@ void dmi_destroy(dmi_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->opt.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (Batch &b : ctx->batches) (void)hipFree(b.d_depth);
+  for (Batch &b : ctx->batches) {
+    (void)hipFree(b.d_depth);
+    (void)hipFree(b.d_pyramid);
+  }
+  if (ctx->d_classes) (void)hipFree(ctx->d_classes);
   for (EventPair &p : ctx->pending) {
     (void)hipEventDestroy(p.start);
     (void)hipEventDestroy(p.stop);
@@ -543,7 +574,8 @@ int dmi_clear_views(dmi_context *ctx) {
   const size_t npix = (size_t)ctx->W * ctx->H;
   for (Batch &b : ctx->batches) {
     (void)hipFree(b.d_depth);
-    ctx->device_bytes -= npix * b.n * depth_elem(ctx);
+    (void)hipFree(b.d_pyramid);
+    ctx->device_bytes -= npix * b.n * depth_elem(ctx) + (size_t)ctx->pyramid.total_tiles * b.n * sizeof(dmi::DepthTile);
   }
   ctx->batches.clear();
   ctx->h_maps.clear();
@@ -641,7 +673,7 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   TileArgs t;
   std::memset(&t, 0, sizeof(t));
   if (cfg.use_tile) {
-    const dmi::TileShape sh = dmi::tile_shape(cfg.variant);
+    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64);
     t.nx = a.nx; t.ny = a.ny; t.nz = a.nz; t.W = a.W; t.H = a.H;
     t.first_map = first; t.n_maps = count; t.init_from_grid = a.init_from_grid;
     t.kpad = (a.nz + sh.tk - 1) / sh.tk * sh.tk;
@@ -655,6 +687,8 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
       return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: grid too large for one launch");
     t.depth_bytes = (int32_t)((int64_t)a.W * a.H * (ctx->depth_f64 ? 8 : 4));
     t.kz0 = a.kz0;
+    // timing experiment only (results are wrong): a zero-length buffer makes the range check drop every depth load
+    if (std::getenv("DMI_DEBUG_NO_DEPTH_LOADS")) t.depth_bytes = 0;
     t.ox = a.ox; t.oy = a.oy; t.oz = a.oz; t.sx = a.sx; t.sy = a.sy; t.sz = a.sz;
     std::memcpy(t.g, a.g, sizeof(t.g));
     t.thick = a.thick; t.delta = a.delta; t.rho_pos = a.rho_pos; t.rho_neg = a.rho_neg;
@@ -676,6 +710,26 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
       ctx->device_bytes += need * 8;
     }
     t.cz_table = ctx->d_cz_table;
+    // brick classes: one byte per (8 x 8 x column wave brick, resident view)
+    t.wbricks_x = (a.nx + 7) / 8;
+    t.wbricks_y = (a.ny + 7) / 8;
+    t.class_pitch = (n_views + 15) / 16 * 16;
+    if (!(cfg.variant & dmi::VAR_NO_BRICK_CLASSES)) {
+      const size_t cbytes = (size_t)t.wbricks_x * t.wbricks_y * t.bricks_z * (size_t)t.class_pitch;
+      if (ctx->classes_capacity < cbytes) {
+        if (ctx->d_classes) {
+          DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          (void)hipFree(ctx->d_classes);
+          ctx->device_bytes -= ctx->classes_capacity;
+          ctx->d_classes = nullptr;
+          ctx->classes_capacity = 0;
+        }
+        DMI_HIP(ctx, hipMalloc(&ctx->d_classes, cbytes));
+        ctx->classes_capacity = cbytes;
+        ctx->device_bytes += cbytes;
+      }
+      t.classes = ctx->d_classes;
+    }
     if (!ctx->d_fuse_args) DMI_HIP(ctx, hipMalloc(&ctx->d_fuse_args, sizeof(FuseArgs)));
     // pageable source: the copy has left the host buffer when the call returns
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_fuse_args, &a, sizeof(FuseArgs), hipMemcpyHostToDevice, ctx->stream));
@@ -691,13 +745,18 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
     DMI_HIP(ctx, hipEventCreate(&ev.stop));
   }
   DMI_HIP(ctx, hipEventRecord(ev.start, ctx->stream));
-  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
+  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->pyramid, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
   if (e != hipSuccess) {
     ctx->pool.push_back(ev);
     (void)hipGetLastError();
     return fail(ctx, DMI_ERR_DEVICE, std::string("fusion kernel launch: ") + hipGetErrorString(e));
   }
   ctx->last_fuse_tiled = cfg.use_tile != 0;
+  ctx->last_fuse_classes = cfg.use_tile != 0 && t.classes != nullptr;
+  ctx->last_class_bricks = (int64_t)t.wbricks_x * t.wbricks_y * t.bricks_z;
+  ctx->last_class_pitch = t.class_pitch;
+  ctx->last_first = first;
+  ctx->last_count = count;
   DMI_HIP(ctx, hipEventRecord(ev.stop, ctx->stream));
   ctx->pending.push_back(ev);
   ctx->grid_is_zero = false;
@@ -783,6 +842,22 @@ int dmi_grid_device_pointer(dmi_context *ctx, void **ptr) {
   int rc = flush_zero_fill(ctx);
   if (rc != DMI_OK) return rc;
   *ptr = ctx->d_grid;
+  return DMI_OK;
+}
+
+int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_brick_class_histogram: null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!ctx->last_fuse_classes) return DMI_OK;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  const size_t bytes = (size_t)ctx->last_class_bricks * ctx->last_class_pitch;
+  std::vector<uint8_t> host(bytes);
+  DMI_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_classes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t b = 0; b < ctx->last_class_bricks; ++b) {
+    const uint8_t *row = host.data() + (size_t)b * ctx->last_class_pitch + ctx->last_first;
+    for (int32_t m = 0; m < ctx->last_count; ++m) out[row[m] & 3] += 1;
+  }
   return DMI_OK;
 }
 

@@ -1,0 +1,239 @@
+// fusion_classify.hip -- brick classes for the tiled fusion kernel, and the depth min/max pyramids they use.
+//
+// In a real fusion most voxel bricks are nowhere near a surface in most depth maps: the whole brick is in
+// free space in front of everything the camera saw, or far behind it, or outside the image.  For such a
+// (brick, map) pair the reference does THE SAME thing to every voxel of the brick (cu:158-212):
+//   * every voxel returns early (behind the camera cu:177, outside the map cu:192-197, no depth cu:202), or
+//   * every voxel accumulates the same constant: -eta*rho (|diff| > delta, diff < 0) or 0 (diff > delta), cu:114-115.
+// This file PROVES that, conservatively, from the eight corner voxels of the brick (computed with the
+// reference's exact expression) and a min/max pyramid of the depth table, and writes one class byte per
+// (brick, map).  The tiled kernel then replaces 16 projections by 16 adds (or nothing).  A pair that cannot
+// be proven is BRICK_MIXED and takes the full per-voxel path, so results stay bit-identical.
+//
+// Proof obligations (DESIGN.md "Brick classes"):
+//   1. c.z over the brick: with an axis-aligned grid the computed c.z = fl(fl(fl(r20*wx + r21*wy) + r22*wz) + r23)
+//      is monotone in each of wx(i), wy(j), wz(k) (rounding is monotone), so its minimum and maximum over the
+//      brick are attained at corner voxels.
+//   2. pixel footprint: u = h.x/h.z is a projective function; on a box with h.z > 0 it is monotone along every
+//      axis-parallel line, so every voxel's real-valued u lies between the corner values.  The reference's
+//      computed, rounded pixel differs from that by at most 1/2 + (TileMapRec::err / c.z); the box is dilated
+//      by one pixel and c.z >= 4*err is required.
+//   3. depth over the footprint: min/max pyramid, tiles rounded outward, at the level where the footprint
+//      spans at most 2 x 2 tiles.
+//   4. class FREE: fl(czmax - dmin) < -delta implies fl(c.z - d) < -delta for every voxel and pixel (monotone
+//      rounding).  Class BEHIND: fl(czmin - dmax) > delta likewise.
+#include <cstring>
+
+#include "fusion_kernels.h"
+#include "fusion_device.h"
+
+namespace dmi {
+
+namespace {
+
+__device__ __forceinline__ float float_below(double d) {  // largest float <= d
+  float f = (float)d;
+  if ((double)f > d) f = nextafterf(f, -__builtin_inff());
+  return f;
+}
+__device__ __forceinline__ float float_above(double d) {  // smallest float >= d
+  float f = (float)d;
+  if ((double)f < d) f = nextafterf(f, __builtin_inff());
+  return f;
+}
+
+struct TileAcc {
+  float dmin = __builtin_inff(), dmax = -__builtin_inff();
+  uint32_t flags = 0;
+  __device__ __forceinline__ void add_value(double d) {
+    if (d != d) {
+      flags |= TILE_HAS_NAN;
+    } else if (d == -1.0) {  // the "no depth" sentinel (cu:202, RD.cxx:164)
+      flags |= TILE_HAS_SENTINEL;
+    } else {
+      flags |= TILE_HAS_VALID;
+      dmin = fminf(dmin, float_below(d));
+      dmax = fmaxf(dmax, float_above(d));
+    }
+  }
+  __device__ __forceinline__ void add_tile(const DepthTile &t) {
+    flags |= t.flags;
+    if (t.flags & TILE_HAS_VALID) {
+      dmin = fminf(dmin, t.dmin);
+      dmax = fmaxf(dmax, t.dmax);
+    }
+  }
+  __device__ __forceinline__ DepthTile tile() const { return DepthTile{dmin, dmax, flags, 0u}; }
+};
+
+// level kPyramidMinLevel from the depth tables: one thread per 8 x 8 tile
+template <typename DepthT>
+__global__ __launch_bounds__(256) void pyramid_base_kernel(const DepthT *__restrict__ depth, int64_t n_maps, int W, int H,
+                                                           PyramidDesc P, DepthTile *__restrict__ pyr) {
+  const int64_t tiles = (int64_t)P.width[0] * P.height[0];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * n_maps) return;
+  const int64_t m = idx / tiles;
+  const int t = (int)(idx - m * tiles);
+  const int ty = t / P.width[0], tx = t - ty * P.width[0];
+  const DepthT *src = depth + m * (int64_t)W * H;
+  constexpr int S = 1 << kPyramidMinLevel;
+  TileAcc acc;
+  for (int y = ty * S; y < ty * S + S && y < H; ++y)
+    for (int x = tx * S; x < tx * S + S && x < W; ++x) acc.add_value((double)src[(int64_t)y * W + x]);
+  pyr[m * P.total_tiles + P.offset[0] + t] = acc.tile();
+}
+
+// level l from level l-1: one thread per tile, 2 x 2 children
+__global__ __launch_bounds__(256) void pyramid_up_kernel(int64_t n_maps, int level, PyramidDesc P, DepthTile *__restrict__ pyr) {
+  const int64_t tiles = (int64_t)P.width[level] * P.height[level];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * n_maps) return;
+  const int64_t m = idx / tiles;
+  const int t = (int)(idx - m * tiles);
+  const int ty = t / P.width[level], tx = t - ty * P.width[level];
+  const DepthTile *child = pyr + m * P.total_tiles + P.offset[level - 1];
+  const int cw = P.width[level - 1], ch = P.height[level - 1];
+  TileAcc acc;
+  for (int y = 2 * ty; y < 2 * ty + 2 && y < ch; ++y)
+    for (int x = 2 * tx; x < 2 * tx + 2 && x < cw; ++x) acc.add_tile(child[y * cw + x]);
+  pyr[m * P.total_tiles + P.offset[level] + t] = acc.tile();
+}
+
+// bounds of the depth values in pixels [x0, x1] x [y0, y1] (inside the image)
+__device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ pyr, const PyramidDesc &P, int x0, int x1,
+                                                 int y0, int y1) {
+  const int extent = max(x1 - x0, y1 - y0) + 1;
+  int li = 0;
+  while (li + 1 < P.n_levels && (1 << (kPyramidMinLevel + li)) < extent) ++li;
+  const int L = kPyramidMinLevel + li;
+  TileAcc acc;
+  if ((1 << L) < extent) {  // only possible at the top level: scan it (it is at most 2 x 2 tiles... or 1 x 1)
+    for (int t = 0; t < P.width[li] * P.height[li]; ++t) acc.add_tile(pyr[P.offset[li] + t]);
+    return acc;
+  }
+  const int tx0 = x0 >> L, tx1 = x1 >> L, ty0 = y0 >> L, ty1 = y1 >> L;  // at most 2 x 2 tiles
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) acc.add_tile(pyr[P.offset[li] + ty * P.width[li] + tx]);
+  return acc;
+}
+
+// one thread per (wave brick, map)
+__global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
+                                                       const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
+  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_bricks * a.n_maps) return;
+  const int64_t brick = idx / a.n_maps;
+  const int m = a.first_map + (int)(idx - brick * a.n_maps);
+  const int bx = (int)(brick % a.wbricks_x);
+  const int by = (int)((brick / a.wbricks_x) % a.wbricks_y);
+  const int bz = (int)(brick / ((int64_t)a.wbricks_x * a.wbricks_y));
+  const MapRec *__restrict__ mr = maps + m;
+
+  double czmin = __builtin_inf(), czmax = -__builtin_inf();
+  double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
+  bool bad = false;
+  for (int c = 0; c < 8; ++c) {
+    // the brick's full extents, also where it sticks out of the grid: a superset is conservative
+    const int i = bx * 8 + ((c & 1) ? 7 : 0), j = by * 8 + ((c & 2) ? 7 : 0), k = bz * tk + ((c & 4) ? tk - 1 : 0);
+    const double gx = a.ox + (i + 0.5) * a.sx;  // cu:80-82
+    const double gy = a.oy + (j + 0.5) * a.sy;
+    const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
+    const double wx = row4(a.g + 0, gx, gy, gz);  // cu:168
+    const double wy = row4(a.g + 4, gx, gy, gz);
+    const double wz = row4(a.g + 8, gx, gy, gz);
+    const double cx = row4(mr->rt + 0, wx, wy, wz);  // cu:172
+    const double cy = row4(mr->rt + 4, wx, wy, wz);
+    const double cz = row4(mr->rt + 8, wx, wy, wz);  // exactly the value the fusion kernel computes
+    const double hx = row4(mr->k + 0, cx, cy, cz);   // cu:176
+    const double hy = row4(mr->k + 4, cx, cy, cz);
+    const double u = hx / cz, v = hy / cz;           // h.z == c.z: pinhole K is a precondition of the tiled kernel
+    bad = bad || !(cz == cz);
+    czmin = fmin(czmin, cz);
+    czmax = fmax(czmax, cz);
+    umin = fmin(umin, u);
+    umax = fmax(umax, u);
+    vmin = fmin(vmin, v);
+    vmax = fmax(vmax, v);
+  }
+  uint8_t cls = BRICK_MIXED;
+  const double err = a.tile_maps[m].err;
+  if (!bad) {
+    if (czmax < 0.0) {
+      cls = BRICK_SKIP;  // every voxel is behind the camera (cu:177)
+    } else if (czmin > 4.0 * err && czmin > 0.0 && umin == umin && umax == umax && vmin == vmin && vmax == vmax &&
+               fabs(umin) < 0x1p30 && fabs(umax) < 0x1p30 && fabs(vmin) < 0x1p30 && fabs(vmax) < 0x1p30) {
+      // every voxel's rounded pixel lies in [x0, x1] x [y0, y1]
+      const int x0 = (int)floor(umin - 1.0), x1 = (int)ceil(umax + 1.0);
+      const int y0 = (int)floor(vmin - 1.0), y1 = (int)ceil(vmax + 1.0);
+      if (x1 < 0 || y1 < 0 || x0 >= a.W || y0 >= a.H) {
+        cls = BRICK_SKIP;  // every voxel projects outside the map (cu:192-197)
+      } else if (x0 >= 0 && y0 >= 0 && x1 < a.W && y1 < a.H) {
+        const TileAcc d = pyramid_query(mr->pyramid, P, x0, x1, y0, y1);
+        if (!(d.flags & TILE_HAS_NAN)) {
+          if (!(d.flags & TILE_HAS_VALID)) {
+            cls = BRICK_SKIP;  // only "no depth" pixels (cu:202)
+          } else if (!(d.flags & TILE_HAS_SENTINEL)) {
+            if ((czmax - (double)d.dmin) < -a.delta)
+              cls = BRICK_FREE;  // cu:114-115: |diff| > delta and diff < 0 for every voxel
+            else if ((czmin - (double)d.dmax) > a.delta)
+              cls = BRICK_BEHIND;  // cu:114-115: diff > delta for every voxel
+          }
+        }
+      }
+    }
+  }
+  classes[brick * a.class_pitch + m] = cls;
+}
+
+inline unsigned blocks_of(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+PyramidDesc make_pyramid_desc(int W, int H) {
+  PyramidDesc P;
+  std::memset(&P, 0, sizeof(P));
+  int off = 0;
+  for (int li = 0; li < kPyramidMaxLevels; ++li) {
+    const int L = kPyramidMinLevel + li, S = 1 << L;
+    P.width[li] = (W + S - 1) / S;
+    P.height[li] = (H + S - 1) / S;
+    P.offset[li] = off;
+    off += P.width[li] * P.height[li];
+    P.n_levels = li + 1;
+    if (P.width[li] == 1 && P.height[li] == 1) break;
+  }
+  P.total_tiles = off;
+  return P;
+}
+
+hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &P,
+                                 DepthTile *pyramids, hipStream_t stream) {
+  if (n_maps <= 0) return hipSuccess;
+  const int64_t base = (int64_t)P.width[0] * P.height[0] * n_maps;
+  if (depth_is_f64)
+    hipLaunchKernelGGL((pyramid_base_kernel<double>), dim3(blocks_of(base)), dim3(256), 0, stream,
+                       static_cast<const double *>(depth), n_maps, W, H, P, pyramids);
+  else
+    hipLaunchKernelGGL((pyramid_base_kernel<float>), dim3(blocks_of(base)), dim3(256), 0, stream,
+                       static_cast<const float *>(depth), n_maps, W, H, P, pyramids);
+  hipError_t e = hipGetLastError();
+  for (int li = 1; e == hipSuccess && li < P.n_levels; ++li) {
+    const int64_t n = (int64_t)P.width[li] * P.height[li] * n_maps;
+    hipLaunchKernelGGL(pyramid_up_kernel, dim3(blocks_of(n)), dim3(256), 0, stream, n_maps, li, P, pyramids);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, const PyramidDesc &P, int tk, uint8_t *classes,
+                                  hipStream_t stream) {
+  const int64_t n = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z * a.n_maps;
+  if (n <= 0) return hipSuccess;
+  if (n > (int64_t)0x7fffffff * 256) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(classify_kernel, dim3(blocks_of(n)), dim3(256), 0, stream, a, maps_dev, P, tk, classes);
+  return hipGetLastError();
+}
+
+}  // namespace dmi

@@ -5,17 +5,39 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 namespace dmi {
 
 // One depth map as the general kernel (and the exact fallback of the tiled kernel) reads it.  The loop
 // index over maps is wave-uniform, so a record arrives through scalar loads into SGPRs: no VGPRs, no LDS.
+// One tile of a depth table's min/max pyramid (level L: 2^L x 2^L pixels).  dmin/dmax bound every value of
+// the tile that is neither the -1 sentinel nor a NaN (rounded outward to f32); flags say what else is there.
+struct alignas(16) DepthTile {
+  float dmin, dmax;
+  uint32_t flags;  // TILE_* bits
+  uint32_t pad;
+};
+enum TileFlags : uint32_t { TILE_HAS_SENTINEL = 1, TILE_HAS_VALID = 2, TILE_HAS_NAN = 4 };
+
+constexpr int kPyramidMinLevel = 3;   // finest level kept: 8 x 8 pixel tiles
+constexpr int kPyramidMaxLevels = 13; // up to 2^15 pixels per axis
+
+// Geometry of the pyramid, identical for every view of a context (all share W x H).
+struct PyramidDesc {
+  int32_t n_levels;                       // levels kPyramidMinLevel .. kPyramidMinLevel + n_levels - 1
+  int32_t total_tiles;                    // tiles per view over all levels
+  int32_t width[kPyramidMaxLevels];       // tiles per row at each level
+  int32_t height[kPyramidMaxLevels];
+  int32_t offset[kPyramidMaxLevels];      // first tile of each level within a view's pyramid
+};
+
 struct alignas(16) MapRec {
   double rt[12];      // rows 0..2 of [R|T]   (reference: matrixTR, cu:159,172)
   double k[12];       // rows 0..2 of the 4x4 K (reference: matrixK, cu:159,176)
   const void *depth;  // W*H depth table, float or double, image row order (row 0 = TOP row: the
                       // reference's bottom-up vtk order, cu:141-149, is flipped once at upload)
-  uint64_t pad;
+  const DepthTile *pyramid;  // this view's min/max pyramid (PyramidDesc::total_tiles entries)
 };
 static_assert(sizeof(MapRec) == 208, "MapRec layout");
 
@@ -80,6 +102,21 @@ struct TileArgs {
   uint32_t *voxel_hits;
   unsigned long long *map_hits;
   const FuseArgs *full;                  // device memory
+  // brick classes (fusion_classify.hip): one byte per (wave brick, map), 16-byte aligned rows of class_pitch
+  // bytes; nullptr = every pair takes the full path
+  const uint8_t *classes;
+  int32_t class_pitch;
+  int32_t wbricks_x, wbricks_y;          // wave bricks (8 x 8 x column) per axis, x fastest
+  int32_t pad2;
+};
+
+// What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
+// corner voxels and the depth table's min/max pyramid (fusion_classify.hip):
+enum BrickClass : uint8_t {
+  BRICK_MIXED = 0,   // not provable: the full per-voxel path runs
+  BRICK_FREE = 1,    // every voxel accumulates -eta*rho (far in front of every surface, cu:115)
+  BRICK_BEHIND = 2,  // every voxel accumulates 0 (far behind every surface, cu:115)
+  BRICK_SKIP = 3     // no voxel reaches cu:211 (behind the camera cu:177, outside the map cu:192, no depth cu:202)
 };
 
 struct FuseConfig {
@@ -98,21 +135,23 @@ enum VariantBits : int {
   VAR_BLOCK_SHAPE_MASK = 12,  // general kernel: bits 2..3 pick the 256-thread block shape
   VAR_FORCE_GENERAL = 16,   // never use the tiled kernel
   VAR_TILE_SHAPE_MASK = 0xE0,  // tiled kernel: bits 5..7 pick column height / workgroup shape
-  VAR_TILE_SHAPE_SHIFT = 5
+  VAR_TILE_SHAPE_SHIFT = 5,
+  VAR_NO_BRICK_CLASSES = 256  // tiled kernel: every (brick, map) pair takes the per-voxel path
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.
 struct TileShape {
   int tk, wx, wy;  // column height; waves per workgroup along x and y (a wave is 8 x 8 lanes)
 };
-TileShape tile_shape(int variant);
+TileShape tile_shape(int variant, bool depth_is_f64);
 
 // Enqueues the general fusion kernel on `stream`.  Returns hipSuccess or the launch error.
 hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t stream);
 
 // Tiled kernel: fills args.cz_table for maps [first_map, first_map + n_maps) and fuses them.
 // args.full must point to a device copy of the matching FuseArgs (read by the exact fallback).
-hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const FuseConfig &cfg, hipStream_t stream);
+hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
+                             hipStream_t stream);
 
 // depth upload helpers ------------------------------------------------------------------
 // out[row-flipped i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64, n_maps
@@ -124,5 +163,13 @@ hipError_t launch_convert_depth(const double *in, const double *best_cost, doubl
 hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int64_t n_maps, int W, int H,
                                  hipStream_t stream);
 hipError_t launch_widen_depth(const float *in, double *out, int64_t n, hipStream_t stream);
+
+// min/max pyramids of n_maps depth tables (device, top-down rows) into pyramids[n_maps][desc.total_tiles]
+PyramidDesc make_pyramid_desc(int W, int H);
+hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &desc,
+                                 DepthTile *pyramids, hipStream_t stream);
+// classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.
+hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, const PyramidDesc &desc, int tk,
+                                  uint8_t *classes, hipStream_t stream);
 
 }  // namespace dmi

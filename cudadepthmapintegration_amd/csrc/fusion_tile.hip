@@ -28,15 +28,18 @@
 //   * rayPotential is the reference's arithmetic; its three-way select is executed as EXEC-masked
 //     adds of the class constants, so a wave pays only for the classes it contains.
 // Results are bit-identical to the general kernel and to oracle/tsdf_oracle.c (tests/test_gpu_parity.py).
+#include <type_traits>
+
 #include "fusion_kernels.h"
 #include "fusion_device.h"
 
 namespace dmi {
 
+int tile_shape_index(int variant);
+
 namespace {
 
 constexpr int kLX = 8, kLY = 8;                   // lanes of a wave over (i, j)
-constexpr int kGroup = 4;                          // voxels of a column whose depth loads are in flight together
 constexpr double kMagic = 6755399441055744.0;      // 1.5 * 2^52: x + kMagic rounds x to an integer (RNE)
 constexpr double kDecide = 0.5 - 0x1p-22;          // see DESIGN.md "Tiled kernel: proof obligations"
 constexpr double kRcpResidual = 0x1p-20;           // |1 - cz*r0| below this => |1 - cz*r| < 2^-39
@@ -61,6 +64,18 @@ __device__ __forceinline__ void add_where_zero(double &acc, mask_t m) {
 __device__ __forceinline__ void or_where(uint32_t &bits, mask_t m, uint32_t bit /* wave-uniform */) {
   mask_t saved;
   asm("s_and_saveexec_b64 %1, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(bits), "=&s"(saved) : "s"(m), "s"(bit));
+}
+
+// acc[0..7] += v on the lanes of m: eight VALU slots under one EXEC mask
+__device__ __forceinline__ void add8_where_s(double *acc, mask_t m, double v /* wave-uniform */) {
+  mask_t saved;
+  asm("s_and_saveexec_b64 %8, %9\n\t"
+      "v_add_f64 %0, %0, %10\n\tv_add_f64 %1, %1, %10\n\tv_add_f64 %2, %2, %10\n\tv_add_f64 %3, %3, %10\n\t"
+      "v_add_f64 %4, %4, %10\n\tv_add_f64 %5, %5, %10\n\tv_add_f64 %6, %6, %10\n\tv_add_f64 %7, %7, %10\n\t"
+      "s_mov_b64 exec, %8"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+        "=&s"(saved)
+      : "s"(m), "s"(v));
 }
 
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -148,9 +163,13 @@ __device__ __forceinline__ bool tile_exact(const FuseArgs *__restrict__ fa, int 
   return true;
 }
 
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, bool COUNT>
+// TK: column height; WX x WY: waves per workgroup; MINW: waves per SIMD the register budget must allow;
+// GROUP: voxels of a column whose depth loads are in flight together.
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
+  constexpr int kGroup = GROUP;
+  typedef double czvec __attribute__((ext_vector_type(GROUP)));
   // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), so
   // slot = (b % 8) * per_xcd + b / 8 gives every XCD a contiguous run of slots; slots enumerate
   // super-bricks of 4 x 4 x 2 bricks, so the ~32 workgroups an XCD runs at a time are neighbours in
@@ -165,9 +184,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
   if (bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = (bx * WX + (w % WX)) * kLX + (lane % kLX);
-  const int j = (by * WY + (w / WX)) * kLY + (lane / kLX);
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and provably so
+  const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
+  if (wbx >= a.wbricks_x || wby >= a.wbricks_y) return;            // wave entirely outside the grid
+  const int i = wbx * kLX + (lane % kLX);
+  const int j = wby * kLY + (lane / kLX);
   const int k0 = bz * TK;
   const int kcount = a.nz - k0 < TK ? a.nz - k0 : TK;  // wave-uniform, >= 1
   const bool lane_ok = i < a.nx && j < a.ny;
@@ -200,8 +222,50 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const uint32_t hiW = (uint32_t)__double2hiint((double)a.W);
   const uint32_t hiH = (uint32_t)__double2hiint((double)a.H);
 
+  const mask_t m_lane_ok = ballot(lane_ok);
   const int m_end = a.first_map + a.n_maps;
+
+  // brick classes of this wave's brick: one byte per map (fusion_classify.hip), read eight maps per scalar
+  // load, one block ahead
+  const uint8_t *crow =
+      a.classes ? a.classes + ((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x * (int64_t)a.class_pitch + (int64_t)wbx * a.class_pitch
+                : nullptr;
+  unsigned long long ccur = 0, cnxt = 0;
+  if (crow) {
+    const int b0 = a.first_map >> 3;
+    ccur = cload(reinterpret_cast<const unsigned long long *>(crow) + b0);
+    if (((b0 + 1) << 3) < m_end) cnxt = cload(reinterpret_cast<const unsigned long long *>(crow) + b0 + 1);
+  }
+
   for (int m = a.first_map; m < m_end; ++m) {
+    const unsigned cls = (unsigned)(ccur >> ((m & 7) * 8)) & 0xffu;  // BRICK_MIXED when classes are off
+    if ((m & 7) == 7) {
+      ccur = cnxt;
+      if (crow && (((m >> 3) + 2) << 3) < m_end)
+        cnxt = cload(reinterpret_cast<const unsigned long long *>(crow) + (m >> 3) + 2);
+    }
+    if (cls != BRICK_MIXED) {
+      // proven: the reference does the same to every voxel of this brick for this map
+      if (cls != BRICK_SKIP) {
+        const double v = cls == BRICK_FREE ? a.free_space : 0.0;  // cu:115 (adding 0 keeps -0.0 + 0.0 = +0.0)
+        if (kcount == TK) {
+#pragma unroll
+          for (int q = 0; q < TK; q += 8) add8_where_s(acc + q, m_lane_ok, v);
+        } else {
+#pragma unroll
+          for (int q = 0; q < TK; ++q)
+            if (q < kcount) add_where_s(acc[q], m_lane_ok, v);
+        }
+        if (COUNT) {
+#pragma unroll
+          for (int q = 0; q < TK; ++q)
+            if (q < kcount) nh[q] += lane_ok ? 1u : 0u;
+          const uint32_t hits = (uint32_t)__popcll(m_lane_ok) * (uint32_t)kcount;
+          if (hits != 0 && lane == 0) atomicAdd(&a.map_hits[m], (unsigned long long)hits);
+        }
+      }
+      continue;
+    }
     const TileMapRec *rec = a.tile_maps + m;                     // wave-uniform -> scalar loads
     const double *ct = a.cz_table + (int64_t)m * a.kpad + k0;  // r22*wz(k), wave-uniform
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -223,8 +287,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     uint32_t undecided = 0;  // per lane: bit kk set = redo voxel kk of this map exactly
     uint32_t map_hits = 0;   // wave-uniform
 
+    // r22*wz(k) for one group of the column per scalar load, fetched one group ahead of its use
+    czvec ct_cur = cload(reinterpret_cast<const czvec *>(ct));
 #pragma unroll
     for (int g0 = 0; g0 < TK; g0 += kGroup) {
+      czvec ct_next = ct_cur;
+      if (g0 + kGroup < TK) ct_next = cload(reinterpret_cast<const czvec *>(ct + g0 + kGroup));
       double czg[kGroup];
       typename DL::raw_t dg[kGroup];
       mask_t ing[kGroup];
@@ -236,7 +304,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           hx += dhx;
           hy += dhy;
         }
-        const double cz = (sz + cload(ct + kk)) + rz3;  // exact c.z (cu:92, cu:172); h.z == c.z for a pinhole K
+        const double cz = (sz + ct_cur[q]) + rz3;  // exact c.z (cu:92, cu:172); h.z == c.z for a pinhole K
         czg[q] = cz;
         // reciprocal: hardware seed + one Newton step; e0 is the seed's residual, checked below
         const double r0 = __builtin_amdgcn_rcp(cz);
@@ -296,6 +364,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           }
         }
       }
+      ct_cur = ct_next;
     }
 
     // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so
@@ -348,44 +417,63 @@ __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const M
   table[(int64_t)m * a.kpad + k] = k < a.nz ? maps[m].rt[10] * wz : -__builtin_inf();
 }
 
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW>
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   const unsigned blocks = (unsigned)(a.super_x * a.super_y * a.super_z * 32);
   const dim3 block(64 * WX * WY);
   if (cfg.count_hits)
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, true>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true>), dim3(blocks), block, 0, s, a);
   else
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, false>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false>), dim3(blocks), block, 0, s, a);
   return hipGetLastError();
 }
 
+// Shape 0 is built for every storage type; the other (tuning) shapes only for f32 depth tables.
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  const TileShape sh = tile_shape(cfg.variant);
-  if (sh.tk == 16 && sh.wx == 2 && sh.wy == 2) return launch_shape<DepthT, GridT, 16, 2, 2, 5>(a, cfg, s);
-  if (sh.tk == 32 && sh.wx == 2 && sh.wy == 2) return launch_shape<DepthT, GridT, 32, 2, 2, 4>(a, cfg, s);
-  if (sh.tk == 32 && sh.wx == 4 && sh.wy == 4) return launch_shape<DepthT, GridT, 32, 4, 4, 4>(a, cfg, s);
-  if (sh.tk == 8 && sh.wx == 2 && sh.wy == 2) return launch_shape<DepthT, GridT, 8, 2, 2, 7>(a, cfg, s);
-  return hipErrorInvalidValue;
+  const int shape = std::is_same<DepthT, float>::value ? tile_shape_index(cfg.variant) : 0;
+  if constexpr (std::is_same<DepthT, float>::value) {
+    switch (shape) {
+      case 1: return launch_shape<DepthT, GridT, 32, 2, 2, 4, 4>(a, cfg, s);
+      case 2: return launch_shape<DepthT, GridT, 32, 4, 4, 4, 4>(a, cfg, s);
+      case 3: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);
+      case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 8, 2>(a, cfg, s);
+      case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
+      case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 4, 8>(a, cfg, s);
+      case 7: return launch_shape<DepthT, GridT, 16, 4, 2, 5, 4>(a, cfg, s);
+      default: break;
+    }
+  }
+  return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);
 }
 
 }  // namespace
 
-TileShape tile_shape(int variant) {
-  switch ((variant & VAR_TILE_SHAPE_MASK) >> VAR_TILE_SHAPE_SHIFT) {
+int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VAR_TILE_SHAPE_SHIFT; }
+
+TileShape tile_shape(int variant, bool depth_is_f64) {
+  switch (depth_is_f64 ? 0 : tile_shape_index(variant)) {
     case 1: return TileShape{32, 2, 2};
     case 2: return TileShape{32, 4, 4};
     case 3: return TileShape{8, 2, 2};
+    case 4: return TileShape{8, 2, 2};
+    case 7: return TileShape{16, 4, 2};
     default: return TileShape{16, 2, 2};
   }
 }
 
-hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const FuseConfig &cfg, hipStream_t stream) {
+hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
+                             hipStream_t stream) {
   if (a.n_maps <= 0) return hipSuccess;
   hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
                      const_cast<double *>(a.cz_table));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (a.classes) {
+    e = launch_classify_bricks(a, maps_dev, pyramid, tile_shape(cfg.variant, cfg.depth_is_f64 != 0).tk,
+                               const_cast<uint8_t *>(a.classes), stream);
+    if (e != hipSuccess) return e;
+  }
   if (cfg.depth_is_f64) {
     if (cfg.grid_is_f64) return launch_types<double, double>(a, cfg, stream);
     return launch_types<double, float>(a, cfg, stream);

@@ -176,6 +176,12 @@ int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits
 /* Device pointer of the grid (context-owned or external) for zero-copy consumers. */
 int dmi_grid_device_pointer(dmi_context *ctx, void **ptr);
 
+/* Diagnostic: how many (8 x 8 x column brick, view) pairs of the last dmi_fuse were proven to be handled
+ * uniformly.  out[0] mixed (per-voxel path), out[1] all voxels accumulate -eta*rho, out[2] all accumulate 0,
+ * out[3] no voxel reaches the accumulate.  All zero when the last fuse ran the general kernel or classes
+ * are switched off.  Synchronises. */
+int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]);
+
 int dmi_get_timings(dmi_context *ctx, dmi_timings *out);
 int dmi_get_info(dmi_context *ctx, dmi_info *out);
 

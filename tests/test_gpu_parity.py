@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 G = capi.VARIANT_FORCE_GENERAL
 # 0 = default: the register-tiled kernel when its preconditions hold, else the general kernel;
 # 32/64/96 = other tile shapes; G | x = the general kernel with its own switches
-VARIANTS = [0, 32, 64, 96, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
+NC = capi.VARIANT_NO_BRICK_CLASSES
+# 0 = default: the register-tiled kernel with brick classes when its preconditions hold, else the general
+# kernel; NC = tiled kernel, every pair on the per-voxel path; 32..224 = other tile shapes; G | x = the general
+# kernel with its own switches
+VARIANTS = [0, NC, 32, 64, 96 | NC, 128, 160 | NC, 224, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
             G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K, G | 4, G | 8, G | 12]
-TILE_SHAPES = [0, 32, 64, 96]
+TILE_SHAPES = [0, NC, 32, 64 | NC, 96, 224]
 
 
 def _golden_inputs(g):
@@ -146,7 +150,7 @@ def test_medium_scenes_against_oracle(dims, n_maps, wh, dense, rotated):
     views = scene.make_views(n_maps, wh[0], wh[1], seed=7, dense=dense)
     want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                    n_threads=oracle.max_threads())
-    for variant in (0, 64, G, G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K):
+    for variant in (0, NC, 64, G, G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K):
         out, vh, mh = capi.fuse_once(grid, rp, views, kernel_variant=variant)
         assert np.array_equal(mh, mh_w) and np.array_equal(vh, vh_w) and bits_equal(out, want)
 
@@ -290,3 +294,53 @@ def test_view_shards_summed_in_f32_are_within_the_stated_tolerance():
             hits += ctx.download_hits()[0]
     assert np.array_equal(hits, vh_w.astype(np.int64))
     assert np.all(np.abs(total.astype(np.float64) - want) <= sharding.sharded_tolerance(world, absum))
+
+
+def test_brick_classes_cover_every_case_and_change_nothing():
+    """A scene with free space, occluded space, no-depth regions, NaN depths and cameras whose frustum
+    misses part of the grid: all four brick classes occur, and the grid and hit counters are bit-identical to
+    the oracle and to the per-voxel path."""
+    grid = scene.default_grid((64, 56, 48))
+    rp = scene.RayPotential(thickness=0.02, rho=0.8, eta=0.03, delta=0.05)
+    views = scene.make_views(8, 160, 120, seed=31, dense=True)
+    views.depth[0, 40:60, 50:90] = -1.0            # a hole without depth inside a valid region
+    views.depth[1, 10:14, 10:14] = np.nan          # NaN depths: never classified, handled per voxel
+    views.depth[2] = -1.0                          # a view without any depth
+    sparse = scene.make_views(3, 160, 120, seed=32, dense=False)
+    views = scene.Views(np.concatenate([views.depth, sparse.depth]), np.concatenate([views.K4, sparse.K4]),
+                        np.concatenate([views.RT4, sparse.RT4]))
+    want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                   n_threads=oracle.max_threads())
+    for variant in (0, 32, NC, G):
+        with capi.FusionContext(grid, rp, count_hits=True, kernel_variant=variant) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            out = ctx.download_grid()
+            vh, mh = ctx.download_hits()
+            hist = ctx.brick_class_histogram()
+        assert bits_equal(out, want), variant
+        assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w), variant
+        if variant in (0, 32):
+            assert all(hist[k] > 0 for k in ("mixed", "free", "behind", "skip")), hist
+            assert sum(hist.values()) == 8 * 7 * (48 // (16 if variant == 0 else 32) + (1 if variant == 32 else 0)) * views.n
+        else:
+            assert sum(hist.values()) == 0
+
+
+def test_brick_classes_with_fuse_range_and_initial_grid():
+    """Classes are indexed by absolute view id: fusing sub-ranges onto a non-zero grid stays bit-exact."""
+    grid = scene.default_grid((40, 40, 40))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(21, 96, 72, seed=8, dense=True)
+    init = np.random.default_rng(1).normal(size=(40, 40, 40))
+    want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                   init_grid=init, n_threads=oracle.max_threads())
+    with capi.FusionContext(grid, rp, count_hits=True) as ctx:
+        ctx.upload_grid(init)
+        ctx.add_views(views)
+        ctx.fuse(0, 5)
+        ctx.fuse(5, 11)
+        ctx.fuse(16, 5)
+        out = ctx.download_grid()
+        vh, mh = ctx.download_hits()
+    assert bits_equal(out, want) and np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w)
