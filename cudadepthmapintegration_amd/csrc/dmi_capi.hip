@@ -80,6 +80,9 @@ struct dmi_context {
   dmi::PyramidDesc pyramid{};    // geometry of every view's depth min/max pyramid
   uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch]
   size_t classes_capacity = 0;   // bytes
+  uint8_t *d_order_level = nullptr;  // workgroup order: scratch levels, order[], count
+  int32_t *d_order = nullptr;
+  size_t order_capacity = 0;     // slots
 
   double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
   size_t stage_capacity = 0;  // elements per staging buffer
@@ -535,6 +538,8 @@ void dmi_destroy(dmi_context *ctx) {
     (void)hipFree(b.d_pyramid);
   }
   if (ctx->d_classes) (void)hipFree(ctx->d_classes);
+  if (ctx->d_order) (void)hipFree(ctx->d_order);
+  if (ctx->d_order_level) (void)hipFree(ctx->d_order_level);
   for (EventPair &p : ctx->pending) {
     (void)hipEventDestroy(p.start);
     (void)hipEventDestroy(p.stop);
@@ -683,7 +688,10 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
     t.super_x = (t.bricks_x + 3) / 4;
     t.super_y = (t.bricks_y + 3) / 4;
     t.super_z = (t.bricks_z + 1) / 2;
-    if ((int64_t)t.super_x * t.super_y * t.super_z * 32 > (int64_t)0x7fffffff)
+    // spatial order: one z-layer of super-bricks per XCD and round (long runs keep an XCD on one region of every
+    // depth map); heaviest-first order: one super-brick's worth, so that the heavy bricks spread over all XCDs
+    t.xcd_run_wg = 32 * std::max(1, t.super_x * t.super_y);
+    if (((int64_t)t.super_x * t.super_y * t.super_z * 32 + 8 * (int64_t)t.xcd_run_wg) > (int64_t)0x7fffffff)
       return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: grid too large for one launch");
     t.depth_bytes = (int32_t)((int64_t)a.W * a.H * (ctx->depth_f64 ? 8 : 4));
     t.kz0 = a.kz0;
@@ -725,11 +733,35 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
           ctx->classes_capacity = 0;
         }
         DMI_HIP(ctx, hipMalloc(&ctx->d_classes, cbytes));
+        // padding bytes (views beyond the resident ones) read as BRICK_SKIP
+        DMI_HIP(ctx, hipMemsetAsync(ctx->d_classes, dmi::BRICK_SKIP, cbytes, ctx->stream));
         ctx->classes_capacity = cbytes;
         ctx->device_bytes += cbytes;
       }
       t.classes = ctx->d_classes;
+      if (!(cfg.variant & dmi::VAR_SPATIAL_ORDER)) {
+        const size_t n_slots = (size_t)t.super_x * t.super_y * t.super_z * 32;
+        if (ctx->order_capacity < n_slots) {
+          if (ctx->d_order) {
+            DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_order);
+            (void)hipFree(ctx->d_order_level);
+            ctx->device_bytes -= ctx->order_capacity * 5 + 4;
+            ctx->d_order = nullptr;
+            ctx->d_order_level = nullptr;
+            ctx->order_capacity = 0;
+          }
+          DMI_HIP(ctx, hipMalloc(&ctx->d_order, (n_slots + 1) * sizeof(int32_t)));
+          DMI_HIP(ctx, hipMalloc(&ctx->d_order_level, n_slots));
+          ctx->order_capacity = n_slots;
+          ctx->device_bytes += n_slots * 5 + 4;
+        }
+        t.order = ctx->d_order + 1;  // [0] holds the count
+        t.n_order = ctx->d_order;
+        t.xcd_run_wg = 32;
+      }
     }
+    if (const char *e = std::getenv("DMI_XCD_RUN_WG")) t.xcd_run_wg = std::max(1, std::atoi(e));  // tuning experiments
     if (!ctx->d_fuse_args) DMI_HIP(ctx, hipMalloc(&ctx->d_fuse_args, sizeof(FuseArgs)));
     // pageable source: the copy has left the host buffer when the call returns
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_fuse_args, &a, sizeof(FuseArgs), hipMemcpyHostToDevice, ctx->stream));
@@ -745,7 +777,7 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
     DMI_HIP(ctx, hipEventCreate(&ev.stop));
   }
   DMI_HIP(ctx, hipEventRecord(ev.start, ctx->stream));
-  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->pyramid, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
+  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->pyramid, ctx->d_order_level, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
   if (e != hipSuccess) {
     ctx->pool.push_back(ev);
     (void)hipGetLastError();

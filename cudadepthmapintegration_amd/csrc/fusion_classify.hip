@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
     const double cz = row4(mr->rt + 8, wx, wy, wz);  // exactly the value the fusion kernel computes
     const double hx = row4(mr->k + 0, cx, cy, cz);   // cu:176
     const double hy = row4(mr->k + 4, cx, cy, cz);
-    const double u = hx / cz, v = hy / cz;           // h.z == c.z: pinhole K is a precondition of the tiled kernel
+    // h.z == c.z (pinhole K is a precondition of the tiled kernel).  The footprint only needs u, v to a small
+    // fraction of the one-pixel dilation: a Newton-refined reciprocal (relative error < 2^-40) instead of two
+    // fp64 divisions.
+    double r = __builtin_amdgcn_rcp(cz);
+    r = __builtin_fma(r, __builtin_fma(-cz, r, 1.0), r);
+    const double u = hx * r, v = hy * r;
     bad = bad || !(cz == cz);
     czmin = fmin(czmin, cz);
     czmax = fmax(czmax, cz);
@@ -185,6 +190,86 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
     }
   }
   classes[brick * a.class_pitch + m] = cls;
+}
+
+// ---- heavy bricks first -------------------------------------------------------------------------------
+// A workgroup whose brick is near a surface in every map runs the per-voxel path 256 times; one in free space
+// only adds constants.  Dispatched in spatial order, the heavy ones that start late run on an almost empty chip
+// (23 % of the wave slots idle at cfg 3).  So workgroup bricks are partitioned by their share of BRICK_MIXED
+// pairs, heaviest level first, each level kept in spatial (super-brick) order for L2 locality.
+
+// slot = super_brick * 32 + brick within the 4 x 4 x 2 super-brick
+__device__ __forceinline__ bool slot_to_brick(const TileArgs &a, int slot, int &bx, int &by, int &bz) {
+  const int sb = slot >> 5, within = slot & 31;
+  const int sbx = sb % a.super_x;
+  const int sbt = sb / a.super_x;
+  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
+  bx = sbx * 4 + (within & 3);
+  by = sby * 4 + ((within >> 2) & 3);
+  bz = sbz * 2 + (within >> 4);
+  return bx < a.bricks_x && by < a.bricks_y && bz < a.bricks_z;
+}
+
+constexpr int kWorkLevels = 4;
+
+__global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int wx, int wy, int n_slots,
+                                                         uint8_t *__restrict__ level) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_slots) return;
+  int bx, by, bz;
+  if (!slot_to_brick(a, slot, bx, by, bz)) {
+    level[slot] = 255;  // padding of the super-brick grid: no workgroup needed
+    return;
+  }
+  int mixed = 0, total = 0;
+  for (int v = 0; v < wy; ++v)
+    for (int u = 0; u < wx; ++u) {
+      const int wbx = bx * wx + u, wby = by * wy + v;
+      if (wbx >= a.wbricks_x || wby >= a.wbricks_y) continue;
+      const uint8_t *row = a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch;
+      for (int m = a.first_map; m < a.first_map + a.n_maps; ++m) mixed += row[m] == BRICK_MIXED ? 1 : 0;
+      total += a.n_maps;
+    }
+  level[slot] = mixed * 2 >= total ? 0 : (mixed * 8 >= total ? 1 : (mixed > 0 ? 2 : 3));
+}
+
+// stable partition of the valid slots by level; one workgroup of 1024 threads, each owning a run of slots
+__global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__restrict__ level, int n_slots,
+                                                           int *__restrict__ order, int *__restrict__ n_valid) {
+  __shared__ int cnt[kWorkLevels][1024];
+  __shared__ int base[kWorkLevels + 1];
+  const int t = threadIdx.x;
+  const int per = (n_slots + 1023) / 1024;
+  const int lo = t * per, hi = min(n_slots, lo + per);
+  int mine[kWorkLevels] = {0, 0, 0, 0};
+  for (int s = lo; s < hi; ++s) {
+    const int l = level[s];
+    if (l < kWorkLevels) mine[l] += 1;
+  }
+  for (int l = 0; l < kWorkLevels; ++l) cnt[l][t] = mine[l];
+  __syncthreads();
+  if (t < kWorkLevels) {  // exclusive scan of this level's counts (1024 adds: a few microseconds)
+    int run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const int c = cnt[t][i];
+      cnt[t][i] = run;
+      run += c;
+    }
+    base[t + 1] = run;
+  }
+  __syncthreads();
+  if (t == 0) {
+    base[0] = 0;
+    for (int l = 1; l <= kWorkLevels; ++l) base[l] += base[l - 1];
+    *n_valid = base[kWorkLevels];
+  }
+  __syncthreads();
+  int pos[kWorkLevels];
+  for (int l = 0; l < kWorkLevels; ++l) pos[l] = base[l] + cnt[l][t];
+  for (int s = lo; s < hi; ++s) {
+    const int l = level[s];
+    if (l < kWorkLevels) order[pos[l]++] = s;
+  }
 }
 
 inline unsigned blocks_of(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -233,6 +318,16 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   if (n <= 0) return hipSuccess;
   if (n > (int64_t)0x7fffffff * 256) return hipErrorInvalidConfiguration;
   hipLaunchKernelGGL(classify_kernel, dim3(blocks_of(n)), dim3(256), 0, stream, a, maps_dev, P, tk, classes);
+  return hipGetLastError();
+}
+
+hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level, int *order, int *n_valid,
+                               hipStream_t stream) {
+  const int n_slots = a.super_x * a.super_y * a.super_z * 32;
+  hipLaunchKernelGGL(brick_work_kernel, dim3(blocks_of(n_slots)), dim3(256), 0, stream, a, wx, wy, n_slots, level);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, stream, level, n_slots, order, n_valid);
   return hipGetLastError();
 }
 

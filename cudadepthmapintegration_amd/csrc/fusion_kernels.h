@@ -107,7 +107,10 @@ struct TileArgs {
   const uint8_t *classes;
   int32_t class_pitch;
   int32_t wbricks_x, wbricks_y;          // wave bricks (8 x 8 x column) per axis, x fastest
-  int32_t pad2;
+  int32_t xcd_run_wg;                    // workgroups dealt to one XCD in a row
+  // workgroup order (fusion_classify.hip): slot of the p-th workgroup, heaviest bricks first; nullptr = spatial order
+  const int32_t *order;
+  const int32_t *n_order;                // number of entries of `order` (device)
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
@@ -136,7 +139,8 @@ enum VariantBits : int {
   VAR_FORCE_GENERAL = 16,   // never use the tiled kernel
   VAR_TILE_SHAPE_MASK = 0xE0,  // tiled kernel: bits 5..7 pick column height / workgroup shape
   VAR_TILE_SHAPE_SHIFT = 5,
-  VAR_NO_BRICK_CLASSES = 256  // tiled kernel: every (brick, map) pair takes the per-voxel path
+  VAR_NO_BRICK_CLASSES = 256,  // tiled kernel: every (brick, map) pair takes the per-voxel path
+  VAR_SPATIAL_ORDER = 512      // tiled kernel: workgroups in spatial order, not heaviest bricks first
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.
@@ -151,7 +155,7 @@ hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t 
 // Tiled kernel: fills args.cz_table for maps [first_map, first_map + n_maps) and fuses them.
 // args.full must point to a device copy of the matching FuseArgs (read by the exact fallback).
 hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
-                             hipStream_t stream);
+                             uint8_t *order_scratch, hipStream_t stream);
 
 // depth upload helpers ------------------------------------------------------------------
 // out[row-flipped i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64, n_maps
@@ -171,5 +175,9 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.
 hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, const PyramidDesc &desc, int tk,
                                   uint8_t *classes, hipStream_t stream);
+// order[p] = slot (super_brick * 32 + brick) of the p-th workgroup, bricks with the most BRICK_MIXED pairs first;
+// level: scratch of super_x*super_y*super_z*32 bytes; wx, wy: waves per workgroup
+hipError_t launch_order_bricks(const TileArgs &args, int wx, int wy, uint8_t *level, int *order, int *n_valid,
+                               hipStream_t stream);
 
 }  // namespace dmi

@@ -45,37 +45,13 @@ constexpr double kDecide = 0.5 - 0x1p-22;          // see DESIGN.md "Tiled kerne
 constexpr double kRcpResidual = 0x1p-20;           // |1 - cz*r0| below this => |1 - cz*r| < 2^-39
 typedef unsigned long long mask_t;
 
-// acc += v on the lanes of m only: one VALU issue slot, no select.  (Not volatile: the statements have
-// no effect beyond their outputs, and a volatile asm would stop the compiler from using scalar loads.)
-__device__ __forceinline__ void add_where_s(double &acc, mask_t m, double v /* wave-uniform */) {
-  mask_t saved;
-  asm("s_and_saveexec_b64 %1, %2\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(saved) : "s"(m), "s"(v));
-}
-__device__ __forceinline__ void add_where_v(double &acc, mask_t m, double v) {
-  mask_t saved;
-  asm("s_and_saveexec_b64 %1, %2\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(saved) : "s"(m), "v"(v));
-}
-__device__ __forceinline__ void add_where_zero(double &acc, mask_t m) {
-  mask_t saved;
-  asm("s_and_saveexec_b64 %1, %2\n\tv_add_f64 %0, %0, 0\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(saved) : "s"(m));
-}
+// EXEC-masked accumulates with the running sums pinned to fixed VGPR pairs (generated; see the script for why)
+#include "fusion_tile_acc.inc"
 
 // bits |= bit on the lanes of m only
 __device__ __forceinline__ void or_where(uint32_t &bits, mask_t m, uint32_t bit /* wave-uniform */) {
   mask_t saved;
   asm("s_and_saveexec_b64 %1, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(bits), "=&s"(saved) : "s"(m), "s"(bit));
-}
-
-// acc[0..7] += v on the lanes of m: eight VALU slots under one EXEC mask
-__device__ __forceinline__ void add8_where_s(double *acc, mask_t m, double v /* wave-uniform */) {
-  mask_t saved;
-  asm("s_and_saveexec_b64 %8, %9\n\t"
-      "v_add_f64 %0, %0, %10\n\tv_add_f64 %1, %1, %10\n\tv_add_f64 %2, %2, %10\n\tv_add_f64 %3, %3, %10\n\t"
-      "v_add_f64 %4, %4, %10\n\tv_add_f64 %5, %5, %10\n\tv_add_f64 %6, %6, %10\n\tv_add_f64 %7, %7, %10\n\t"
-      "s_mov_b64 exec, %8"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-        "=&s"(saved)
-      : "s"(m), "s"(v));
 }
 
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -163,20 +139,36 @@ __device__ __forceinline__ bool tile_exact(const FuseArgs *__restrict__ fa, int 
   return true;
 }
 
-// TK: column height; WX x WY: waves per workgroup; MINW: waves per SIMD the register budget must allow;
-// GROUP: voxels of a column whose depth loads are in flight together.
+// TK: column height; WX x WY: waves per workgroup; GROUP: voxels of a column whose depth loads are in flight
+// together.  MINW sets the COMPILER's register budget through __launch_bounds__ (64 / 72 / 80 / 96 VGPRs for
+// MINW = 8 / 7 / 6 / 5); the running sums live directly above it, in v[BASE ...] with BASE = that budget, behind
+// the compiler's back (fusion_tile_acc.inc).  The kernel as a whole uses BASE + 2*TK VGPRs, which sets the real
+// occupancy (<= 96: five waves per SIMD, <= 128: four).
+constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw == 6 ? 80 : minw == 5 ? 96 : 128; }
+
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
+  constexpr int BASE = acc_base(MINW);
   constexpr int kGroup = GROUP;
   typedef double czvec __attribute__((ext_vector_type(GROUP)));
-  // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), so
-  // slot = (b % 8) * per_xcd + b / 8 gives every XCD a contiguous run of slots; slots enumerate
-  // super-bricks of 4 x 4 x 2 bricks, so the ~32 workgroups an XCD runs at a time are neighbours in
-  // space and their depth-map footprints overlap in that XCD's L2.
+  // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD), and
+  // an XCD runs about 32 of these workgroups at a time.  So consecutive blocks OF ONE XCD enumerate one
+  // super-brick of 4 x 4 x 2 bricks: the workgroups an XCD runs together are neighbours in space and their
+  // depth-map footprints overlap in that XCD's L2.  Super-bricks are dealt to the XCDs in runs of a.xcd_run
+  // (one z-layer of super-bricks): long enough that an XCD keeps working on one region of every depth map
+  // (dealing single super-bricks round-robin cost 12 %), short enough that every XCD gets layers from all over
+  // the grid (the work per brick depends on how close it is to a surface).
   const int b = blockIdx.x;
-  const int per_xcd = gridDim.x >> 3;  // gridDim.x is a multiple of 32
-  const int slot = (b & 7) * per_xcd + (b >> 3);
+  const int q = b >> 3;                         // q-th workgroup of this block's XCD
+  const int run = a.xcd_run_wg;                 // workgroups dealt to one XCD in a row
+  const int p = (q / run) * (8 * run) + (b & 7) * run + q % run;
+  // heaviest bricks first when the classification has ordered them (fusion_classify.hip), else spatial order
+  int slot = p;
+  if (a.order) {
+    if (p >= cload(a.n_order)) return;
+    slot = cload(a.order + p);
+  }
   const int sb = slot >> 5, within = slot & 31;
   const int sbx = sb % a.super_x;
   const int sbt = sb / a.super_x;
@@ -208,13 +200,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int64_t plane = (int64_t)a.ny * a.nx;
   const int64_t gid0 = ((int64_t)k0 * a.ny + j) * a.nx + i;  // cu:126-134
 
-  double acc[TK];
+  // the TK running sums live in v[BASE ...], outside the compiler's register budget (fusion_tile_acc.inc)
   uint32_t nh[COUNT ? TK : 1];
 #pragma unroll
   for (int kk = 0; kk < TK; ++kk) {
-    acc[kk] = 0.0;
+    double v0 = 0.0;
     if (COUNT) nh[kk] = 0;
-    if (a.init_from_grid && lane_ok && kk < kcount) acc[kk] = (double)grid[gid0 + kk * plane];  // cu:211 accumulates
+    if (a.init_from_grid && lane_ok && kk < kcount) v0 = (double)grid[gid0 + kk * plane];  // cu:211 accumulates
+    acc_set<BASE, TK>(kk, v0);
   }
 
   // 0 <= r < W for an integer-valued double r, on its high dword alone: the high dword is monotone
@@ -225,36 +218,31 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const mask_t m_lane_ok = ballot(lane_ok);
   const int m_end = a.first_map + a.n_maps;
 
-  // brick classes of this wave's brick: one byte per map (fusion_classify.hip), read eight maps per scalar
-  // load, one block ahead
-  const uint8_t *crow =
-      a.classes ? a.classes + ((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x * (int64_t)a.class_pitch + (int64_t)wbx * a.class_pitch
+  // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
+  const unsigned long long *crow =
+      a.classes ? reinterpret_cast<const unsigned long long *>(
+                      a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch)
                 : nullptr;
-  unsigned long long ccur = 0, cnxt = 0;
-  if (crow) {
-    const int b0 = a.first_map >> 3;
-    ccur = cload(reinterpret_cast<const unsigned long long *>(crow) + b0);
-    if (((b0 + 1) << 3) < m_end) cnxt = cload(reinterpret_cast<const unsigned long long *>(crow) + b0 + 1);
-  }
 
+  unsigned long long cword = 0ull;  // all BRICK_MIXED when classes are off
   for (int m = a.first_map; m < m_end; ++m) {
-    const unsigned cls = (unsigned)(ccur >> ((m & 7) * 8)) & 0xffu;  // BRICK_MIXED when classes are off
-    if ((m & 7) == 7) {
-      ccur = cnxt;
-      if (crow && (((m >> 3) + 2) << 3) < m_end)
-        cnxt = cload(reinterpret_cast<const unsigned long long *>(crow) + (m >> 3) + 2);
+    if (crow && ((m & 7) == 0 || m == a.first_map)) cword = cload(crow + (m >> 3));
+    if (cword == 0x0303030303030303ull) {  // none of this block's eight maps touches the brick
+      m |= 7;
+      continue;
     }
+    const unsigned cls = (unsigned)(cword >> ((m & 7) * 8)) & 0xffu;
     if (cls != BRICK_MIXED) {
       // proven: the reference does the same to every voxel of this brick for this map
       if (cls != BRICK_SKIP) {
         const double v = cls == BRICK_FREE ? a.free_space : 0.0;  // cu:115 (adding 0 keeps -0.0 + 0.0 = +0.0)
         if (kcount == TK) {
 #pragma unroll
-          for (int q = 0; q < TK; q += 8) add8_where_s(acc + q, m_lane_ok, v);
+          for (int q = 0; q < TK; q += 8) acc_add8_s<BASE, TK>(q, m_lane_ok, v);
         } else {
 #pragma unroll
           for (int q = 0; q < TK; ++q)
-            if (q < kcount) add_where_s(acc[q], m_lane_ok, v);
+            if (q < kcount) acc_add_s<BASE, TK>(q, m_lane_ok, v);
         }
         if (COUNT) {
 #pragma unroll
@@ -333,6 +321,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const unsigned px = (unsigned)__double2loint(tu), py = (unsigned)__double2loint(tv);
           dg[q] = DL::load(rsrc, __umul24(py, (unsigned)a.W) + px);  // cu:201
         }
+        // keep the voxels' instruction streams apart: interleaving them buys nothing (other waves fill the
+        // gaps) and costs the registers that decide the occupancy
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- phase B: ray potential of the group (cu:105-120) as EXEC-masked adds
 #pragma unroll
@@ -346,17 +337,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
           if (m_far) {
             const mask_t m_free = m_far & ~m_pos, m_zero = m_far & m_pos;
-            if (m_free) add_where_s(acc[kk], m_free, a.free_space);  // -eta*rho (cu:115)
-            if (m_zero) add_where_zero(acc[kk], m_zero);             // + 0 (cu:115): keeps -0.0 + 0.0 = +0.0
+            if (m_free) acc_add_s<BASE, TK>(kk, m_free, a.free_space);  // -eta*rho (cu:115)
+            if (m_zero) acc_add_zero<BASE, TK>(kk, m_zero);             // + 0 (cu:115): keeps -0.0 + 0.0 = +0.0
           }
           const mask_t m_near = m_hit & ~m_far;
           if (m_near) {
             const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > a.thick);  // cu:116
             const mask_t m_ramp = m_near & ~m_plat;  // includes a NaN diff, as the reference's else branch
             const mask_t m_pp = m_plat & m_pos, m_pn = m_plat & ~m_pos;
-            if (m_pp) add_where_s(acc[kk], m_pp, a.rho_pos);           // rho * +1 (cu:117)
-            if (m_pn) add_where_s(acc[kk], m_pn, a.rho_neg);           // rho * -1
-            if (m_ramp) add_where_v(acc[kk], m_ramp, a.slope * diff);  // (rho/thick)*diff (cu:119)
+            if (m_pp) acc_add_s<BASE, TK>(kk, m_pp, a.rho_pos);           // rho * +1 (cu:117)
+            if (m_pn) acc_add_s<BASE, TK>(kk, m_pn, a.rho_neg);           // rho * -1
+            if (m_ramp) acc_add_v<BASE, TK>(kk, m_ramp, a.slope * diff);  // (rho/thick)*diff (cu:119)
           }
           if (COUNT) {
             nh[kk] += __builtin_amdgcn_inverse_ballot_w64(m_hit) ? 1u : 0u;
@@ -380,7 +371,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #pragma unroll
         for (int q = 0; q < TK; ++q) {
           if (kk == q) {  // wave-uniform
-            if (hit) acc[q] += val;
+            acc_add_v<BASE, TK>(q, ballot(hit), val);
             if (COUNT) nh[q] += hit ? 1u : 0u;
           }
         }
@@ -393,12 +384,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   }
 
   if (lane_ok) {
+    // Recompute the store addresses here: without this barrier the compiler keeps the TK addresses it formed
+    // for the initial loads alive across the whole map loop (2 VGPRs each).
+    int64_t gid = gid0;
+    asm("" : "+v"(gid));
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
       if (kk < kcount) {
-        grid[gid0 + kk * plane] = (GridT)acc[kk];
-        if (COUNT) a.voxel_hits[gid0 + kk * plane] += nh[kk];
+        grid[gid] = (GridT)acc_get<BASE, TK>(kk);
+        if (COUNT) a.voxel_hits[gid] += nh[kk];
       }
+      gid += plane;
     }
   }
 }
@@ -419,7 +415,9 @@ __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const M
 
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  const unsigned blocks = (unsigned)(a.super_x * a.super_y * a.super_z * 32);
+  // super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
+  const int per_round = 8 * a.xcd_run_wg;
+  const unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + per_round - 1) / per_round * per_round);
   const dim3 block(64 * WX * WY);
   if (cfg.count_hits)
     hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true>), dim3(blocks), block, 0, s, a);
@@ -434,17 +432,17 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   const int shape = std::is_same<DepthT, float>::value ? tile_shape_index(cfg.variant) : 0;
   if constexpr (std::is_same<DepthT, float>::value) {
     switch (shape) {
-      case 1: return launch_shape<DepthT, GridT, 32, 2, 2, 4, 4>(a, cfg, s);
-      case 2: return launch_shape<DepthT, GridT, 32, 4, 4, 4, 4>(a, cfg, s);
-      case 3: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);
-      case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 8, 2>(a, cfg, s);
-      case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
-      case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 4, 8>(a, cfg, s);
-      case 7: return launch_shape<DepthT, GridT, 16, 4, 2, 5, 4>(a, cfg, s);
+      case 1: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 4>(a, cfg, s);  // 80 + 32 = 112 VGPRs: 4 waves
+      case 2: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 4>(a, cfg, s);  // 64 + 32 = 96: 5 waves, tight compiler budget
+      case 3: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 4>(a, cfg, s);   // 80 + 16 = 96: 5 waves
+      case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 2>(a, cfg, s);
+      case 5: return launch_shape<DepthT, GridT, 8, 2, 2, 5, 4>(a, cfg, s);   // 96 + 16 = 112: 4 waves
+      case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
+      case 7: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);   // 72 + 16 = 88: 5 waves
       default: break;
     }
   }
-  return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);
+  return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);  // 96 + 32 = 128 VGPRs: 4 waves per SIMD
 }
 
 }  // namespace
@@ -453,26 +451,29 @@ int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VA
 
 TileShape tile_shape(int variant, bool depth_is_f64) {
   switch (depth_is_f64 ? 0 : tile_shape_index(variant)) {
-    case 1: return TileShape{32, 2, 2};
-    case 2: return TileShape{32, 4, 4};
-    case 3: return TileShape{8, 2, 2};
-    case 4: return TileShape{8, 2, 2};
-    case 7: return TileShape{16, 4, 2};
+    case 3:
+    case 4:
+    case 5:
+    case 7: return TileShape{8, 2, 2};
     default: return TileShape{16, 2, 2};
   }
 }
 
 hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
-                             hipStream_t stream) {
+                             uint8_t *order_scratch, hipStream_t stream) {
   if (a.n_maps <= 0) return hipSuccess;
   hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
                      const_cast<double *>(a.cz_table));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.classes) {
-    e = launch_classify_bricks(a, maps_dev, pyramid, tile_shape(cfg.variant, cfg.depth_is_f64 != 0).tk,
-                               const_cast<uint8_t *>(a.classes), stream);
+    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0);
+    e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), stream);
     if (e != hipSuccess) return e;
+    if (a.order) {
+      e = launch_order_bricks(a, sh.wx, sh.wy, order_scratch, const_cast<int *>(a.order), const_cast<int *>(a.n_order), stream);
+      if (e != hipSuccess) return e;
+    }
   }
   if (cfg.depth_is_f64) {
     if (cfg.grid_is_f64) return launch_types<double, double>(a, cfg, stream);
