@@ -10,8 +10,11 @@ region.  N = 1 workload = BASELINE.json configs[2]: 512^3 voxels x 256 depth map
 For N > 1 every rank fuses its own shard of 256 maps (weak scaling: 256*N maps in total).
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
-  roofline      HBM view of the fusion kernel: algorithmic bytes / hipEvent kernel time vs 8 TB/s
-  roofline_valu the binding roof of this kernel: fp64 VALU issue (DESIGN.md "Roofline")
+  roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s
+  roofline_valu the binding roof of the per-voxel path: fp64 VALU issue (DESIGN.md "Roofline"), measured on
+                the same workload with brick classes switched off (every projection computed), plus how many
+                (brick, view) pairs the default path proved uniform
+  ablation      the same fusion without brick classes / with workgroups in spatial order
   cpu_baseline  the CPU oracle (restated reference arithmetic) timed on this host's cores on a
                 bounded sample of the same workload (N = 1 only)
 """
@@ -99,6 +102,7 @@ def main():
     ap.add_argument("--grid-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ablation", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--secondary", action="store_true", help="also time the other scene variant (N = 1)")
     args = ap.parse_args()
@@ -184,6 +188,30 @@ def main():
     total_maps = maps_per_gpu * world
     value = n_vox * total_maps * args.steps / dt / 1e9
 
+    # ablations on the same resident views (N = 1): brick classes off = every voxel-projection computed
+    ablation = None
+    hist = ctx.brick_class_histogram()
+    if world == 1 and not args.no_ablation:
+        ablation = {}
+        for name, var in (("no_brick_classes", capi.VARIANT_NO_BRICK_CLASSES), ("spatial_order", capi.VARIANT_SPATIAL_ORDER)):
+            g2 = torch.zeros(n_vox, dtype=torch_dtype, device="cuda")
+            c2 = capi.FusionContext(grid, ray, device=local_rank, grid_dtype=args.grid_dtype, depth_storage="auto",
+                                    kernel_variant=args.variant | var, stream=stream, external_grid=g2.data_ptr())
+            c2.add_views(views)
+            for i in range(3):
+                c2.reset_grid()
+                c2.fuse()
+                c2.synchronize()
+                if i == 0:
+                    k0 = c2.timings().total_fuse_kernel_ms
+            ms = (c2.timings().total_fuse_kernel_ms - k0) / 2
+            ablation[name] = {"kernel_ms": ms, "value": n_vox * maps_per_gpu / ms / 1e6}
+            if name == "no_brick_classes":
+                same = bool(torch.equal(g2, grid_t))
+                ablation[name]["grid_bit_identical_to_default"] = same
+            c2.close()
+            del g2
+
     secondary = None
     if args.secondary and world == 1:
         other = "sparse" if args.scene == "dense" else "dense"
@@ -207,7 +235,9 @@ def main():
         except Exception:
             traffic = None
     proj_per_launch = float(n_vox) * maps_per_gpu
-    valu_tflops = FLOP_PER_PROJECTION * proj_per_launch / (kern_ms * 1e-3) / 1e12
+    # fp64 VALU view: meaningful for the path that computes every projection (brick classes off)
+    valu_ms = ablation["no_brick_classes"]["kernel_ms"] if ablation else kern_ms
+    valu_tflops = FLOP_PER_PROJECTION * proj_per_launch / (valu_ms * 1e-3) / 1e12
 
     out = {
         "metric": "Gvoxel-projections/s",
@@ -244,7 +274,8 @@ def main():
             "kernel": "dmi::fuse_tile_kernel" if info.tiled_kernel else "dmi::fuse_kernel",
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": b_alg,
-            "note": "fused voxel-stationary order is fp64-VALU bound, not HBM bound: see roofline_valu and DESIGN.md",
+            "note": "kernel_ms = hipEvent time of one dmi_fuse (cz table + brick classification + ordering + fusion "
+                    "kernel); the path is bound by fp64 VALU issue, not HBM: see roofline_valu and DESIGN.md",
         },
         "roofline_valu": {
             "bound": "valu_fp64",
@@ -253,8 +284,14 @@ def main():
             "unit": "TFLOP/s",
             "frac": valu_tflops / FP64_VECTOR_PEAK_TFLOPS,
             "flop_per_projection": FLOP_PER_PROJECTION,
+            "kernel_ms": valu_ms,
+            "note": "per-voxel path only (brick classes off): 48 algorithmic fp64 flop x every voxel-projection / time; "
+                    "the default path proves most (brick, view) pairs uniform and skips their projections",
         },
+        "brick_classes": hist,
     }
+    if ablation:
+        out["ablation"] = ablation
     if secondary:
         out["secondary"] = secondary
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
