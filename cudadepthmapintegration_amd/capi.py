@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
+    "dmi_color_mesh", "dmi_color_last_error",
 ]
 
 _lib = None
@@ -113,6 +114,10 @@ def load() -> ctypes.CDLL:
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.dmi_free_pinned.argtypes = [vp]
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L.dmi_color_mesh.argtypes = [dp, ctypes.c_int64, u8p, dp, dp, i32, i32, i32, i32, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
+    L.dmi_color_last_error.argtypes = []
+    L.dmi_color_last_error.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:
@@ -268,6 +273,27 @@ class FusionContext:
         return i
 
 
+def color_mesh(points, colors, K4, RT4, device: int = 0):
+    """MeshColoration::ProcessColoration on the GPU (include/dmi.h: dmi_color_mesh).
+    points [nv,3] f64; colors [n,H,W,3] u8 in vtk row order; returns (mean u8[nv,3], median u8[nv,3], count i32[nv])."""
+    L = load()
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    col = np.ascontiguousarray(colors, dtype=np.uint8)
+    n, H, W, _ = col.shape
+    k = np.ascontiguousarray(K4, dtype=np.float64).reshape(n, 16)
+    rt = np.ascontiguousarray(RT4, dtype=np.float64).reshape(n, 16)
+    nv = pts.shape[0]
+    mean = np.zeros((nv, 3), dtype=np.uint8)
+    median = np.zeros((nv, 3), dtype=np.uint8)
+    count = np.zeros(nv, dtype=np.int32)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    rc = L.dmi_color_mesh(_dp(pts), nv, col.ctypes.data_as(u8), _dp(k), _dp(rt), n, W, H, device, mean.ctypes.data_as(u8),
+                          median.ctypes.data_as(u8), count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    if rc != DMI_OK:
+        raise DmiError(rc, L.dmi_color_last_error().decode())
+    return mean, median, count
+
+
 def fuse_once(grid: GridDesc, ray: RayPotential, views: Views, *, threshold: float | None = None,
               init_grid: np.ndarray | None = None, count_hits: bool = True, **ctx_kwargs):
     """create -> (upload grid) -> add views -> fuse -> download.  Returns (grid, voxel_hits, map_hits)."""
@@ -290,7 +316,7 @@ HOST_ABI_SYMBOLS = [
     "dmi_filter_set_kernel_variant", "dmi_filter_update", "dmi_filter_get_execution_time",
     "dmi_filter_get_fuse_kernel_ms", "dmi_filter_get_number_of_cells", "dmi_filter_get_output",
     "dmi_filter_last_error", "dmi_read_krtd_file", "dmi_extract_all_file_path", "dmi_k3_to_k4",
-    "dmi_apply_depth_threshold", "dmi_read_depth_map",
+    "dmi_apply_depth_threshold", "dmi_read_depth_map", "dmi_mesh_coloration_from_lists",
 ]
 
 _host_bound = False
@@ -333,6 +359,9 @@ def load_host() -> ctypes.CDLL:
     L.dmi_k3_to_k4.restype, L.dmi_k3_to_k4.argtypes = None, [dp, dp]
     L.dmi_apply_depth_threshold.restype, L.dmi_apply_depth_threshold.argtypes = i64, [dp, dp, i64, dbl]
     L.dmi_read_depth_map.restype, L.dmi_read_depth_map.argtypes = ctypes.c_int, [ctypes.c_char_p, ip, dp, dp, ip]
+    L.dmi_mesh_coloration_from_lists.restype = ctypes.c_int
+    L.dmi_mesh_coloration_from_lists.argtypes = [dp, i64, ctypes.c_char_p, ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_uint8),
+                                                 ctypes.POINTER(ctypes.c_uint8), ip, ctypes.c_char_p, ctypes.c_size_t]
     _host_bound = True
     return L
 
@@ -463,3 +492,21 @@ def read_depth_map(path):
     L.dmi_read_depth_map(os.fsencode(path), dims, _dp(d), _dp(bc), ctypes.byref(has))
     shape = (dims[1], dims[0])
     return d.reshape(shape), (bc.reshape(shape) if has.value else None)
+
+
+def mesh_coloration_from_lists(points, vti_list, krtd_list, device: int = 0):
+    """MeshColoration(mesh, vtiList, krtdList).ProcessColoration() through the host mirror (reads the .vti/.krtd files)."""
+    L = load_host()
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    nv = pts.shape[0]
+    mean = np.zeros((nv, 3), dtype=np.uint8)
+    median = np.zeros((nv, 3), dtype=np.uint8)
+    count = np.zeros(nv, dtype=np.int32)
+    err = ctypes.create_string_buffer(512)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    ok = L.dmi_mesh_coloration_from_lists(_dp(pts), nv, os.fsencode(vti_list), os.fsencode(krtd_list), device,
+                                          mean.ctypes.data_as(u8), median.ctypes.data_as(u8),
+                                          count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), err, len(err))
+    if not ok:
+        raise RuntimeError(err.value.decode())
+    return mean, median, count

@@ -128,4 +128,23 @@ int dmi_read_depth_map(const char *path, int32_t dims[3], double *depths, double
   return 1;
 }
 
+int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const char *vti_list, const char *krtd_list,
+                                   int32_t device, uint8_t *mean, uint8_t *median, int32_t *count, char *err, size_t errlen) {
+  auto fail = [&](const std::string &m) {
+    if (err && errlen > 0) {
+      std::strncpy(err, m.c_str(), errlen - 1);
+      err[errlen - 1] = 0;
+    }
+    return 0;
+  };
+  if (!points || !vti_list || !krtd_list || !mean || !median || !count || n_points < 0) return fail("null argument");
+  dmi::host::MeshColoration mc(points, n_points, vti_list, krtd_list);
+  mc.SetDevice(device);
+  if (!mc.ProcessColoration()) return fail(mc.LastError());
+  std::memcpy(mean, mc.GetMeanColoration().data(), (size_t)n_points * 3);
+  std::memcpy(median, mc.GetMedianColoration().data(), (size_t)n_points * 3);
+  for (int64_t i = 0; i < n_points; ++i) count[i] = mc.GetNbProjectedDepthMap()[(size_t)i];
+  return 1;
+}
+
 }  // extern "C"

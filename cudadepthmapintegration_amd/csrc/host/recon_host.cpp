@@ -144,6 +144,30 @@ void ReconstructionData::SetMatrixK(const double K3[9]) {
 
 void ReconstructionData::SetMatrixTR(const double RT[16]) { std::memcpy(MatrixTR, RT, sizeof(MatrixTR)); }
 
+bool ReconstructionData::GetColorValue(const int pixelPosition[2], double rgb[3]) const {
+  if (!HasDepthMap || DepthMap.color.empty()) {
+    std::cerr << "Error, no 'Color' array exists" << std::endl;  // RD.cxx:97-101
+    return false;
+  }
+  const int W = DepthMap.dims[0], H = DepthMap.dims[1];
+  const size_t id = ((size_t)(H - 1 - pixelPosition[1]) * W + (size_t)pixelPosition[0]) * 3;  // RD.cxx:105-110
+  for (int i = 0; i < 3; ++i) rgb[i] = DepthMap.color[id + i];
+  return true;
+}
+
+void ReconstructionData::TransformWorldToDepthMapPosition(const double *w, int pixelCoordinate[2]) const {
+  // vtkTransform::TransformPoint / TransformVector restated (see oracle/coloration_oracle.c header)
+  double c[3], d[3];
+  for (int i = 0; i < 3; ++i) c[i] = MatrixTR[4 * i] * w[0] + MatrixTR[4 * i + 1] * w[1] + MatrixTR[4 * i + 2] * w[2] + MatrixTR[4 * i + 3];
+  for (int i = 0; i < 3; ++i) d[i] = Matrix4K[4 * i] * c[0] + Matrix4K[4 * i + 1] * c[1] + Matrix4K[4 * i + 2] * c[2];
+  d[0] = d[0] / d[2];
+  d[1] = d[1] / d[2];
+  const double ru = std::round(d[0]), rv = std::round(d[1]);
+  // out-of-range conversions are undefined in the reference; here they land outside every image
+  pixelCoordinate[0] = (ru > -2147483648.0 && ru < 2147483648.0) ? (int)ru : -1;
+  pixelCoordinate[1] = (rv > -2147483648.0 && rv < 2147483648.0) ? (int)rv : -1;
+}
+
 void ReconstructionData::ApplyDepthThresholdFilter(double thresholdBestCost) {
   if (!HasDepthMap) return;  // RD.cxx:140-141
   if (DepthMap.depths.empty()) {
@@ -195,6 +219,7 @@ bool ReconstructionData::ReadDepthMap(const std::string &path, DepthImage *out) 
   const size_t n = (size_t)out->dims[0] * out->dims[1] * out->dims[2];
   out->depths.clear();
   out->best_cost.clear();
+  out->color.clear();
   std::string::size_type p = 0;
   while ((p = text.find("<DataArray", p)) != std::string::npos) {
     const std::string::size_type tag_end = text.find('>', p);
@@ -205,6 +230,22 @@ bool ReconstructionData::ReadDepthMap(const std::string &path, DepthImage *out) 
     xml_attr(tag, "format", &format);
     xml_attr(tag, "type", &type);
     p = tag_end + 1;
+    if (name == "Color") {  // RD.cxx:94-95: unsigned char, 3 components
+      if (format != "ascii" || type != "UInt8") {
+        std::cerr << "ReadDepthMap: array 'Color' is " << type << "/" << format << "; only UInt8 ascii is read without VTK"
+                  << std::endl;
+        return false;
+      }
+      const std::string::size_type cclose = text.find("</DataArray>", p);
+      if (cclose == std::string::npos) return false;
+      std::istringstream cs(text.substr(p, cclose - p));
+      out->color.clear();
+      out->color.reserve(n * 3);
+      int c;
+      while (cs >> c) out->color.push_back((unsigned char)c);
+      if (out->color.size() != n * 3) return false;
+      continue;
+    }
     std::vector<double> *dst = name == "Depths" ? &out->depths : (name == "Best Cost Values" ? &out->best_cost : nullptr);
     if (!dst) continue;
     if (format != "ascii" || type != "Float64") {
@@ -506,6 +547,79 @@ int ReconstructionFilter::Compute(int gridDims[3], double gridOrig[3], double gr
     return -1;
   }
   return 0;
+}
+
+// ====================================================================================================
+// Coloration/MeshColoration
+// ====================================================================================================
+MeshColoration::MeshColoration() {}
+
+MeshColoration::MeshColoration(const double *meshPoints, int64_t nbMeshPoint, const std::string &vti, const std::string &krtd) {
+  SetInput(meshPoints, nbMeshPoint);
+  const std::vector<std::string> vtiList = help::ExtractAllFilePath(vti.c_str());
+  const std::vector<std::string> krtdList = help::ExtractAllFilePath(krtd.c_str());
+  if (krtdList.size() < vtiList.size()) {  // MC.cxx:59-63
+    std::cerr << "Error, not enough krtd file for each vti file" << std::endl;
+    return;
+  }
+  for (size_t id = 0; id < vtiList.size(); id++) {  // MC.cxx:67-71
+    ReconstructionData *data = new ReconstructionData(vtiList[id], krtdList[id]);
+    Owned.push_back(data);
+    DataList.push_back(data);
+  }
+}
+
+MeshColoration::~MeshColoration() {
+  for (ReconstructionData *d : Owned) delete d;
+}
+
+void MeshColoration::SetInput(const double *meshPoints, int64_t nbMeshPoint) {
+  Points.assign(meshPoints, meshPoints + 3 * nbMeshPoint);
+  HasInput = true;
+}
+
+void MeshColoration::AddView(ReconstructionData *data) { DataList.push_back(data); }
+
+bool MeshColoration::ProcessColoration() {
+  Error.clear();
+  const int nbDepthMap = (int)DataList.size();
+  if (!HasInput || nbDepthMap == 0) {  // MC.cxx:102-106
+    Error = "Error when input has been set or during reading vti/krtd file path";
+    std::cerr << Error << std::endl;
+    return false;
+  }
+  const int64_t nv = (int64_t)Points.size() / 3;
+  DepthImage *first = DataList[0]->GetDepthMap();
+  if (!first) {
+    Error = "MeshColoration: view 0 has no image";
+    return false;
+  }
+  const int W = first->dims[0], H = first->dims[1];  // MC.cxx:111: dimensions of view 0
+  const size_t npix = (size_t)W * H;
+  std::vector<unsigned char> colors(npix * 3 * (size_t)nbDepthMap);
+  std::vector<double> K4(16 * (size_t)nbDepthMap), RT(16 * (size_t)nbDepthMap);
+  for (int m = 0; m < nbDepthMap; ++m) {
+    DepthImage *img = DataList[m]->GetDepthMap();
+    if (!img || img->dims[0] != W || img->dims[1] != H || img->color.size() != npix * 3) {
+      Error = "MeshColoration: view " + std::to_string(m) + " has no 'Color' array of the size of view 0";  // RD.cxx:97-101
+      std::cerr << Error << std::endl;
+      return false;
+    }
+    std::memcpy(&colors[(size_t)m * npix * 3], img->color.data(), npix * 3);
+    std::memcpy(&K4[16 * (size_t)m], DataList[m]->Get4MatrixK(), 16 * sizeof(double));
+    std::memcpy(&RT[16 * (size_t)m], DataList[m]->GetMatrixTR(), 16 * sizeof(double));
+  }
+  Mean.assign((size_t)nv * 3, 0);   // MC.cxx:113-133: arrays start at 0
+  Median.assign((size_t)nv * 3, 0);
+  std::vector<int32_t> count((size_t)nv, 0);
+  const int rc = dmi_color_mesh(Points.data(), nv, colors.data(), K4.data(), RT.data(), nbDepthMap, W, H, Device, Mean.data(),
+                                Median.data(), count.data());
+  if (rc != DMI_OK) {
+    Error = dmi_color_last_error();
+    return false;
+  }
+  Count.assign(count.begin(), count.end());
+  return true;
 }
 
 }  // namespace host

@@ -39,6 +39,7 @@ struct DepthImage {
   int dims[3] = {0, 0, 1};
   std::vector<double> depths;     // "Depths"
   std::vector<double> best_cost;  // "Best Cost Values"; may be empty
+  std::vector<unsigned char> color;  // "Color", 3 components per point (RD.cxx:94-95); may be empty
 };
 
 // Sources/ReconstructionData.h:40-79, minus the colour helpers of the Coloration tool.
@@ -57,6 +58,11 @@ class ReconstructionData {
   void SetDepthMap(const DepthImage &data);  // RD.cxx:184-190
   void SetMatrixK(const double K3[9]);       // RD.cxx:192-212: also builds the identity-padded 4x4
   void SetMatrixTR(const double RT[16]);     // RD.cxx:214-221
+
+  // RD.cxx:92-116: RGB of image pixel (x, y) = vtk point (x, H-1-y); false (and a message) without a "Color" array.
+  bool GetColorValue(const int pixelPosition[2], double rgb[3]) const;
+  // RD.cxx:169-182: RT as a point transform, K as a vector transform, divide, std::round.  No z-sign test.
+  void TransformWorldToDepthMapPosition(const double *worldCoordinate, int pixelCoordinate[2]) const;
 
   // RD.cxx:138-167: best cost > threshold => depth = -1.  No-op without depths or when the two arrays
   // differ in length (the reference dereferences a null "Best Cost Values"; here that is a no-op too).
@@ -177,6 +183,35 @@ class ReconstructionFilter {
   std::string Error;
   int Device = 0, KernelVariant = 0;
   double FuseKernelMs = 0.0;
+};
+
+// ---- Coloration/MeshColoration ---------------------------------------------------------------------------
+// MC.h:42-61.  The mesh contributes only its points (MC.cxx:109-110); the output is the three point-data arrays
+// the reference adds to the mesh (MC.cxx:194-196).  ProcessColoration runs on the GPU (dmi_color_mesh).
+class MeshColoration {
+ public:
+  MeshColoration();
+  // MC.cxx:52-72: reads every view named by the two list files (needs "Color" arrays in the .vti files)
+  MeshColoration(const double *meshPoints, int64_t nbMeshPoint, const std::string &vtiList, const std::string &krtdList);
+  ~MeshColoration();
+  void SetInput(const double *meshPoints, int64_t nbMeshPoint);  // MC.cxx:85-91 (vtkPolyData points, [n][3])
+  void AddView(ReconstructionData *data);                        // in-memory alternative to the list files; not owned
+  bool ProcessColoration();                                      // MC.cxx:98-199
+  const std::vector<unsigned char> &GetMeanColoration() const { return Mean; }      // "MeanColoration", u8 x 3
+  const std::vector<unsigned char> &GetMedianColoration() const { return Median; }  // "MedianColoration", u8 x 3
+  const std::vector<int> &GetNbProjectedDepthMap() const { return Count; }          // "NbProjectedDepthMap"
+  const std::string &LastError() const { return Error; }
+  void SetDevice(int d) { Device = d; }
+
+ private:
+  std::vector<double> Points;
+  bool HasInput = false;
+  std::vector<ReconstructionData *> DataList;
+  std::vector<ReconstructionData *> Owned;
+  std::vector<unsigned char> Mean, Median;
+  std::vector<int> Count;
+  std::string Error;
+  int Device = 0;
 };
 
 }  // namespace host

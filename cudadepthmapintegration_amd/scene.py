@@ -173,13 +173,18 @@ def write_krtd(path: str, K3: np.ndarray, RT4: np.ndarray) -> None:
         fh.write("\n".join(lines) + "\n")
 
 
-def write_vti_ascii(path: str, depth: np.ndarray, best_cost: np.ndarray | None = None) -> None:
-    """Minimal ascii VTK XML ImageData with the point arrays the path reads ("Depths", "Best Cost Values")."""
+def write_vti_ascii(path: str, depth: np.ndarray, best_cost: np.ndarray | None = None,
+                    color: np.ndarray | None = None) -> None:
+    """Minimal ascii VTK XML ImageData with the point arrays the path reads ("Depths", "Best Cost Values", "Color")."""
     H, W = depth.shape
     def arr(name, a):
         vals = " ".join("%.17g" % float(v) for v in np.asarray(a, dtype=np.float64).reshape(-1))
         return f'        <DataArray type="Float64" Name="{name}" format="ascii">\n          {vals}\n        </DataArray>\n'
     body = arr("Depths", depth) + (arr("Best Cost Values", best_cost) if best_cost is not None else "")
+    if color is not None:
+        vals = " ".join(str(int(v)) for v in np.asarray(color, dtype=np.uint8).reshape(-1))
+        body += ('        <DataArray type="UInt8" Name="Color" NumberOfComponents="3" format="ascii">\n'
+                 f'          {vals}\n        </DataArray>\n')
     with open(path, "w") as fh:
         fh.write('<?xml version="1.0"?>\n<VTKFile type="ImageData" version="0.1" byte_order="LittleEndian">\n'
                  f'  <ImageData WholeExtent="0 {W - 1} 0 {H - 1} 0 0" Origin="0 0 0" Spacing="1 1 1">\n'
@@ -187,13 +192,14 @@ def write_vti_ascii(path: str, depth: np.ndarray, best_cost: np.ndarray | None =
                  '      </PointData>\n    </Piece>\n  </ImageData>\n</VTKFile>\n')
 
 
-def write_view_files(directory: str, views: "Views"):
+def write_view_files(directory: str, views: "Views", colors: np.ndarray | None = None):
     """Writes frame_XXXX.vti / .krtd plus vtiList.txt / krtdList.txt; returns the two list paths."""
     import os
     vti, krtd = [], []
     for m in range(views.n):
         v, k = f"frame_{m:04d}.vti", f"frame_{m:04d}.krtd"
-        write_vti_ascii(os.path.join(directory, v), views.depth[m], None if views.best_cost is None else views.best_cost[m])
+        write_vti_ascii(os.path.join(directory, v), views.depth[m], None if views.best_cost is None else views.best_cost[m],
+                        None if colors is None else colors[m])
         write_krtd(os.path.join(directory, k), views.K4[m][:3, :3], views.RT4[m])
         vti.append(v)
         krtd.append(k)
@@ -203,3 +209,27 @@ def write_view_files(directory: str, views: "Views"):
     with open(lk, "w") as fh:
         fh.write("".join(f"{i} {p}\n" for i, p in enumerate(krtd)))
     return lv, lk
+
+
+def make_colors(n: int, W: int, H: int, seed: int = 0) -> np.ndarray:
+    """Synthetic "Color" arrays [n, H, W, 3] u8 (vtk row order): smooth gradients plus noise, different per view."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = np.empty((n, H, W, 3), dtype=np.uint8)
+    for m in range(n):
+        base = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy + 37 * m) % 256)], axis=-1)
+        noise = rng.integers(-20, 21, size=(H, W, 3))
+        out[m] = np.clip(base + noise, 0, 255).astype(np.uint8)
+    return out
+
+
+def make_mesh_points(n: int, seed: int = 0, radius: float = 0.6) -> np.ndarray:
+    """Vertices of the synthetic scene's surface (the sphere) plus a share of points elsewhere in and around the
+    grid (some outside every frustum), as a mesh extracted from the TSDF would have."""
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = radius * d
+    k = n // 4
+    pts[:k] = rng.uniform(-1.6, 1.6, size=(k, 3))
+    return pts

@@ -189,6 +189,19 @@ int dmi_get_info(dmi_context *ctx, dmi_info *out);
 int dmi_alloc_pinned(size_t bytes, void **out);
 int dmi_free_pinned(void *ptr);
 
+/* ---- MeshColoration pass (Coloration/MeshColoration.cxx:98-199; the reference runs it on the CPU) ----
+ * For every mesh vertex: the views whose projection of the vertex (RD.cxx:169-182: no z-sign test, no depth
+ * test) falls inside the image contribute that pixel's RGB (RD.cxx:92-116); outputs are the reference's three
+ * point-data arrays "MeanColoration" (u8 x 3, integer mean), "MedianColoration" (u8 x 3) and
+ * "NbProjectedDepthMap" (i32), zero where no view sees the vertex.
+ *   points [n_points][3] f64 (vtkPoints of the mesh); colors [n_views][H][W][3] u8, the "Color" arrays in vtk
+ *   point order; K4, RT4 [n_views][16] row-major (Get4MatrixK / GetMatrixTR).  One-shot: uploads, runs two
+ *   kernels, downloads.  Bit-identical to the reference arithmetic (everything after the projection is integer). */
+int dmi_color_mesh(const double *points, int64_t n_points, const uint8_t *colors, const double *K4, const double *RT4,
+                   int32_t n_views, int32_t width, int32_t height, int32_t device, uint8_t *mean, uint8_t *median,
+                   int32_t *count);
+const char *dmi_color_last_error(void);
+
 int dmi_abi_version(void);
 int dmi_device_count(void);
 

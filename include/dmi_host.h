@@ -60,6 +60,12 @@ int64_t dmi_apply_depth_threshold(double *depths, const double *best_cost, int64
  * caller (width*height each, best_cost may be NULL); pass depths == NULL to query dims only. */
 int dmi_read_depth_map(const char *path, int32_t dims[3], double *depths, double *best_cost, int32_t *has_best_cost);
 
+/* MeshColoration(mesh, vtiList, krtdList) + ProcessColoration() (Coloration/MeshColoration.cxx:52-72, :98-199) on mesh
+ * points [n_points][3]; fills mean / median [n_points][3] and count [n_points].  1 on success, 0 on error (message in
+ * err, truncated to errlen). */
+int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const char *vti_list, const char *krtd_list,
+                                   int32_t device, uint8_t *mean, uint8_t *median, int32_t *count, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,8 +38,8 @@ class _Params(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with the committed Makefile (gcc, -ffp-contract=off)."""
-    src = os.path.join(_HERE, "tsdf_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "tsdf_oracle.c"), os.path.join(_HERE, "coloration_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
@@ -68,6 +68,10 @@ def lib() -> ctypes.CDLL:
         L.oracle_ray_potential.restype = ctypes.c_double
         L.oracle_ray_potential.argtypes = [ctypes.POINTER(_Params), ctypes.c_double, ctypes.c_double]
         L.oracle_max_threads.restype = ctypes.c_int
+        L.oracle_color_mesh.restype = None
+        L.oracle_color_mesh.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint8), dp, dp, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8),
+                                        ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)]
         _lib = L
     return _lib
 
@@ -161,3 +165,21 @@ def k3_to_k4(K3) -> np.ndarray:
 
 def ray_potential(params: _Params, real_distance: float, depth_map_distance: float) -> float:
     return float(lib().oracle_ray_potential(ctypes.byref(params), real_distance, depth_map_distance))
+
+
+def color_mesh(points, colors, K4, RT4):
+    """MeshColoration::ProcessColoration (Coloration/MeshColoration.cxx:98-199).
+    points [nv,3] f64; colors [n,H,W,3] u8 in vtk row order.  Returns (mean u8[nv,3], median u8[nv,3], count i32[nv])."""
+    pts = _c64(points).reshape(-1, 3)
+    col = np.ascontiguousarray(colors, dtype=np.uint8)
+    n, H, W, _ = col.shape
+    K4 = _c64(K4, (n, 16))
+    RT4 = _c64(RT4, (n, 16))
+    nv = pts.shape[0]
+    mean = np.zeros((nv, 3), dtype=np.uint8)
+    median = np.zeros((nv, 3), dtype=np.uint8)
+    count = np.zeros(nv, dtype=np.int32)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    lib().oracle_color_mesh(_dp(pts), nv, col.ctypes.data_as(u8), _dp(K4), _dp(RT4), n, W, H, mean.ctypes.data_as(u8),
+                            median.ctypes.data_as(u8), count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return mean, median, count

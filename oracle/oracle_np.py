@@ -78,3 +78,45 @@ def fuse(cell_dims, origin, spacing, grid_matrix, thick, rho, eta, delta, depths
             vhits += ok.astype(np.uint32)
             mhits[m] = np.count_nonzero(ok)
     return grid, vhits, mhits
+
+
+def color_mesh_np(points, colors, K4, RT4):
+    """Independent numpy restatement of MeshColoration::ProcessColoration (Coloration/MeshColoration.cxx:98-199,
+    Sources/ReconstructionData.cxx:92-116,169-182, Sources/Helper.h:174-187) for cross-checking the C oracle."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    col = np.asarray(colors, dtype=np.uint8)
+    n, H, W, _ = col.shape
+    nv = pts.shape[0]
+    mean = np.zeros((nv, 3), dtype=np.uint8)
+    median = np.zeros((nv, 3), dtype=np.uint8)
+    count = np.zeros(nv, dtype=np.int32)
+    for i in range(nv):
+        x, y, z = (np.float64(v) for v in pts[i])
+        lists = [[], [], []]
+        for m in range(n):
+            RT = np.asarray(RT4[m], dtype=np.float64).reshape(4, 4)
+            K = np.asarray(K4[m], dtype=np.float64).reshape(4, 4)
+            c = [((RT[r, 0] * x + RT[r, 1] * y) + RT[r, 2] * z) + RT[r, 3] for r in range(3)]   # TransformPoint
+            d = [(K[r, 0] * c[0] + K[r, 1] * c[1]) + K[r, 2] * c[2] for r in range(3)]           # TransformVector
+            with np.errstate(all="ignore"):
+                u, v = np.float64(d[0]) / np.float64(d[2]), np.float64(d[1]) / np.float64(d[2])
+            if not (np.isfinite(u) and np.isfinite(v)):
+                continue
+            ru = np.sign(u) * np.floor(np.abs(u) + 0.5)     # std::round: half away from zero
+            rv = np.sign(v) * np.floor(np.abs(v) + 0.5)
+            if not (abs(ru) < 2.0 ** 31 and abs(rv) < 2.0 ** 31):
+                continue
+            px, py = int(ru), int(rv)
+            if px < 0 or py < 0 or px >= W or py >= H:
+                continue
+            rgb = col[m, H - 1 - py, px]
+            for ch in range(3):
+                lists[ch].append(int(rgb[ch]))
+        if lists[0]:
+            k = len(lists[0])
+            count[i] = k
+            for ch in range(3):
+                mean[i, ch] = int(float(sum(lists[ch])) / float(k))
+                s = sorted(lists[ch])
+                median[i, ch] = int((s[k // 2] + s[k // 2 - 1]) / 2) if k % 2 == 0 else s[k // 2]
+    return mean, median, count

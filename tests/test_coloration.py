@@ -1,0 +1,96 @@
+"""MeshColoration pass: oracle cross-checks on the CPU, GPU parity through the C ABI.
+All three outputs are integers: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+from cudadepthmapintegration_amd import capi, scene
+from oracle import oracle, oracle_np
+
+
+def _views(n, W, H, seed, radius=3.0):
+    v = scene.make_views(n, W, H, seed=seed, radius=radius)
+    return v.K4, v.RT4, scene.make_colors(n, W, H, seed=seed + 1)
+
+
+def test_known_answers_single_pixel():
+    """One vertex on the optical axis of identity-pose cameras: pixel = (cx, cy) of K; mean / median / count follow
+    MC.cxx:174-186 (integer mean, median of an even count = mean of the middle two, truncated)."""
+    W, H, n = 8, 6, 4
+    K4 = np.tile(np.eye(4), (n, 1, 1))
+    K4[:, 0, 0] = K4[:, 1, 1] = 10.0
+    K4[:, 0, 2], K4[:, 1, 2] = 3.0, 2.0
+    RT4 = np.tile(np.eye(4), (n, 1, 1))
+    colors = np.zeros((n, H, W, 3), dtype=np.uint8)
+    vals = [10, 13, 200, 20]
+    for m in range(n):
+        colors[m, H - 1 - 2, 3] = (vals[m], 255 - vals[m], m)      # image pixel (3, 2) lives in vtk row H-1-2
+    mean, median, count = oracle.color_mesh(np.array([[0.0, 0.0, 1.0]]), colors, K4, RT4)
+    assert count[0] == 4
+    assert list(mean[0]) == [sum(vals) // 4, (4 * 255 - sum(vals)) // 4, 1]          # 243/4 = 60.75 -> 60
+    assert list(median[0]) == [(13 + 20) // 2, ((255 - 20) + (255 - 13)) // 2, 1]     # (1 + 2) / 2 = 1.5 -> 1
+    # a vertex behind the cameras still projects (no z test in RD.cxx:169-182): (0,0,-1) -> the same pixel
+    _, _, count = oracle.color_mesh(np.array([[0.0, 0.0, -1.0]]), colors, K4, RT4)
+    assert count[0] == 4
+    # z = 0: division by zero -> not a pixel
+    _, _, count = oracle.color_mesh(np.array([[0.5, 0.5, 0.0]]), colors, K4, RT4)
+    assert count[0] == 0
+
+
+def test_c_oracle_matches_numpy_restatement():
+    K4, RT4, colors = _views(7, 48, 36, seed=3)
+    pts = scene.make_mesh_points(300, seed=4)
+    a = oracle.color_mesh(pts, colors, K4, RT4)
+    b = oracle_np.color_mesh_np(pts, colors, K4, RT4)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[2].max() >= 3 and a[2].min() < a[2].max()
+
+
+def test_color_mesh_without_gpu_fails_loudly():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    K4, RT4, colors = _views(2, 16, 12, seed=1)
+    with pytest.raises(capi.DmiError) as e:
+        capi.color_mesh(np.zeros((4, 3)), colors, K4, RT4)
+    assert e.value.code == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_views,wh,nv,radius", [(5, (64, 48), 1000, 3.0), (33, (160, 120), 20000, 3.0),
+                                                   (8, (96, 72), 5000, 0.8)])
+def test_gpu_color_mesh_bit_exact(n_views, wh, nv, radius):
+    K4, RT4, colors = _views(n_views, wh[0], wh[1], seed=11, radius=radius)
+    pts = scene.make_mesh_points(nv, seed=12)
+    pts[:3] = [[0, 0, 0], [1e9, -1e9, 1e9], [np.nan, 0, 0]]       # degenerate vertices
+    want = oracle.color_mesh(pts, colors, K4, RT4)
+    got = capi.color_mesh(pts, colors, K4, RT4)
+    for name, g, w in zip(("mean", "median", "count"), got, want):
+        assert np.array_equal(g, w), name
+    assert want[2].max() >= min(n_views, 4)
+
+
+@pytest.mark.gpu
+def test_gpu_color_mesh_argument_errors():
+    K4, RT4, colors = _views(2, 16, 12, seed=1)
+    with pytest.raises(capi.DmiError):
+        capi.color_mesh(np.zeros((4, 3)), colors, K4, RT4, device=99)
+    m, d, c = capi.color_mesh(np.zeros((0, 3)), colors, K4, RT4)
+    assert m.shape == (0, 3) and c.shape == (0,)
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_coloration_from_list_files(tmp_path):
+    """The reference's own input form: MeshColoration(mesh, vtiList, krtdList) with "Color" arrays in the .vti files."""
+    views = scene.make_views(4, 40, 30, seed=21)
+    colors = scene.make_colors(4, 40, 30, seed=22)
+    lv, lk = scene.write_view_files(str(tmp_path), views, colors)
+    pts = scene.make_mesh_points(2000, seed=23)
+    want = oracle.color_mesh(pts, colors, views.K4, views.RT4)
+    got = capi.mesh_coloration_from_lists(pts, lv, lk)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_mesh_coloration_from_lists_reports_missing_files(tmp_path):
+    with pytest.raises(RuntimeError):
+        capi.mesh_coloration_from_lists(np.zeros((3, 3)), str(tmp_path / "a.txt"), str(tmp_path / "b.txt"))
