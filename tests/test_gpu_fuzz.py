@@ -1,0 +1,71 @@
+"""Randomised GPU parity: random axis-aligned and rotated grids, pinhole / skewed / general K, random poses (cameras
+inside and outside the grid), depth tables with sentinels, NaNs and f32-inexact values, ray-potential parameters
+including the degenerate ones the reference accepts (thickness 0, delta 0, negative eta).  Every case runs the default
+path (tiled kernel with brick classes when eligible), the tiled kernel without classes and the general kernel, and
+all three must equal the oracle bit for bit (fp64 grid, hit counters)."""
+import numpy as np
+import pytest
+
+from cudadepthmapintegration_amd import capi, scene
+from oracle import oracle
+from helpers import bits_equal, oracle_params_from_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    dims = tuple(int(v) for v in rng.integers(5, 45, size=3))
+    extent = rng.uniform(0.5, 3.0, size=3)
+    origin = tuple(-extent / 2 + rng.uniform(-0.3, 0.3, size=3))
+    spacing = tuple(extent / np.array(dims))
+    gm = np.eye(4)
+    kind = rng.integers(0, 4)
+    if kind == 1:                                   # scaled / flipped / translated axes: still axis-aligned
+        gm[:3, :3] = np.diag(rng.choice([-1.5, -1.0, 0.5, 1.0, 2.0], size=3))
+        gm[:3, 3] = rng.uniform(-0.5, 0.5, size=3)
+    elif kind == 2:                                 # rotated grid: general kernel
+        a = rng.uniform(-1, 1)
+        gm[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    grid = scene.GridDesc(dims, origin, spacing, gm)
+    n = int(rng.integers(1, 9))
+    W, H = int(rng.integers(8, 90)), int(rng.integers(6, 70))
+    radius = float(rng.choice([0.3, 1.2, 3.0, 6.0]))
+    views = scene.make_views(n, W, H, seed=int(rng.integers(1 << 30)), dense=bool(rng.integers(0, 2)), radius=radius,
+                             focal_scale=float(rng.uniform(0.4, 1.5)))
+    kk = rng.integers(0, 4)
+    if kk == 1:
+        views.K4[:, 0, 1] = rng.uniform(-0.5, 0.5)  # skew
+    elif kk == 2:
+        views.K4[:, 2, 0] = 1e-3                    # general K (h.z != c.z)
+    depth = views.depth
+    m = rng.random(depth.shape)
+    depth[m < 0.05] = -1.0
+    if rng.integers(0, 3) == 0:
+        depth[m > 0.995] = np.nan
+    if rng.integers(0, 2) == 0:                     # values that are not f32-representable -> f64 storage
+        depth[:] = np.where(np.isfinite(depth) & (depth != -1.0), depth * (1 + 2.0 ** -45), depth)
+    s = float(max(spacing))
+    thick = float(rng.choice([0.0, 0.5 * s, 2.5 * s]))
+    delta = float(rng.choice([0.0, thick, 4 * s, 10 * s]))
+    rho = float(rng.choice([0.8, -0.5, 1.0]))
+    eta = float(rng.choice([0.03, 0.0, -0.2, 1.0]))
+    if rho == 0 and thick == 0:
+        rho = 0.8
+    return grid, scene.RayPotential(thick, rho, eta, delta), views
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_bit_exact(seed):
+    grid, rp, views = _random_case(seed)
+    init = None
+    if seed % 5 == 0:
+        init = np.random.default_rng(seed).normal(size=(grid.cell_dims[2], grid.cell_dims[1], grid.cell_dims[0]))
+    with np.errstate(all="ignore"):
+        want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                       init_grid=init, n_threads=oracle.max_threads())
+    for variant in (0, capi.VARIANT_NO_BRICK_CLASSES, 96, capi.VARIANT_FORCE_GENERAL):
+        out, vh, mh = capi.fuse_once(grid, rp, views, init_grid=init, kernel_variant=variant)
+        assert np.array_equal(mh, mh_w), (seed, variant)
+        assert np.array_equal(vh, vh_w), (seed, variant)
+        assert bits_equal(out, want), (seed, variant)
