@@ -91,6 +91,26 @@ def cpu_baseline(grid, ray, views, target_seconds: float = 15.0):
     }
 
 
+def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int = 64):
+    """Secondary measurement: the MeshColoration pass on the GPU, one-shot call including its
+    uploads and downloads (dmi_color_mesh), on synthetic vertices x views of the bench's image size."""
+    views = scene.make_views(n_views, 8, 8, seed=77)          # cameras only; the depth tables are not used
+    # per-pixel content is irrelevant to the timing: one byte pattern, tiled over all views (fast to generate)
+    colors = np.empty((n_views, H, W, 3), dtype=np.uint8)
+    colors[:] = (np.arange(H * W * 3, dtype=np.uint32) % 251).astype(np.uint8).reshape(1, H, W, 3)
+    K4 = views.K4.copy()
+    K4[:, 0, 0] = K4[:, 1, 1] = 0.9 * W
+    K4[:, 0, 2], K4[:, 1, 2] = W / 2.0, H / 2.0
+    pts = scene.make_mesh_points(n_vertices, seed=78)
+    capi.color_mesh(pts[:1000], colors[:2], K4[:2], views.RT4[:2])   # warm-up
+    t0 = time.perf_counter()
+    mean, median, count = capi.color_mesh(pts, colors, K4, views.RT4)
+    dt = time.perf_counter() - t0
+    return {"value": n_vertices * n_views / dt / 1e9, "unit": "Gvertex-projections/s (PCIe-inclusive one-shot call)",
+            "vertices": n_vertices, "views": n_views, "image": f"{W}x{H}", "seconds": dt,
+            "mean_views_per_vertex": float(count.mean())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +123,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ablation", action="store_true")
+    ap.add_argument("--no-coloration", action="store_true")
+    ap.add_argument("--coloration-vertices", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--secondary", action="store_true", help="also time the other scene variant (N = 1)")
     args = ap.parse_args()
@@ -294,6 +316,8 @@ def main():
         out["ablation"] = ablation
     if secondary:
         out["secondary"] = secondary
+    if rank == 0 and world == 1 and not args.no_coloration:
+        out["coloration"] = coloration_probe(scene, capi, args.coloration_vertices, W, H)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(grid, ray, views, args.cpu_seconds)
     ctx.close()

@@ -118,17 +118,19 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
   return acc;
 }
 
-// one thread per (wave brick, map)
+// one thread per (wave brick, map): threadIdx.x runs over 64 consecutive maps (coalesced class bytes), threadIdx.y
+// over 4 consecutive bricks; all index arithmetic in 32 bits
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
-  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_bricks * a.n_maps) return;
-  const int64_t brick = idx / a.n_maps;
-  const int m = a.first_map + (int)(idx - brick * a.n_maps);
-  const int bx = (int)(brick % a.wbricks_x);
-  const int by = (int)((brick / a.wbricks_x) % a.wbricks_y);
-  const int bz = (int)(brick / ((int64_t)a.wbricks_x * a.wbricks_y));
+  const int n_bricks = a.wbricks_x * a.wbricks_y * a.bricks_z;
+  const int brick = blockIdx.x * 4 + threadIdx.y;
+  const int mm = blockIdx.y * 64 + threadIdx.x;
+  if (brick >= n_bricks || mm >= a.n_maps) return;
+  const int m = a.first_map + mm;
+  const int bx = brick % a.wbricks_x;
+  const int bt = brick / a.wbricks_x;
+  const int by = bt % a.wbricks_y;
+  const int bz = bt / a.wbricks_y;
   const MapRec *__restrict__ mr = maps + m;
 
   double czmin = __builtin_inf(), czmax = -__builtin_inf();
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
       }
     }
   }
-  classes[brick * a.class_pitch + m] = cls;
+  classes[(int64_t)brick * a.class_pitch + m] = cls;
 }
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
@@ -314,10 +316,11 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 
 hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, const PyramidDesc &P, int tk, uint8_t *classes,
                                   hipStream_t stream) {
-  const int64_t n = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z * a.n_maps;
-  if (n <= 0) return hipSuccess;
-  if (n > (int64_t)0x7fffffff * 256) return hipErrorInvalidConfiguration;
-  hipLaunchKernelGGL(classify_kernel, dim3(blocks_of(n)), dim3(256), 0, stream, a, maps_dev, P, tk, classes);
+  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z;
+  if (n_bricks <= 0 || a.n_maps <= 0) return hipSuccess;
+  if (n_bricks > (int64_t)0x7fffffff || (a.n_maps + 63) / 64 > 65535) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((n_bricks + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4), 0,
+                     stream, a, maps_dev, P, tk, classes);
   return hipGetLastError();
 }
 

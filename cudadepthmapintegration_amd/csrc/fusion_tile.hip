@@ -436,9 +436,9 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       case 2: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 4>(a, cfg, s);  // 64 + 32 = 96: 5 waves, tight compiler budget
       case 3: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 4>(a, cfg, s);   // 80 + 16 = 96: 5 waves
       case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 2>(a, cfg, s);
-      case 5: return launch_shape<DepthT, GridT, 8, 2, 2, 5, 4>(a, cfg, s);   // 96 + 16 = 112: 4 waves
+      case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 2>(a, cfg, s);  // 64 + 32 = 96: 5 waves, loads in flight: 2
       case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
-      case 7: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);   // 72 + 16 = 88: 5 waves
+      case 7: return launch_shape<DepthT, GridT, 12, 2, 2, 7, 4>(a, cfg, s);  // 72 + 24 = 96: 5 waves
       default: break;
     }
   }
@@ -452,9 +452,8 @@ int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VA
 TileShape tile_shape(int variant, bool depth_is_f64) {
   switch (depth_is_f64 ? 0 : tile_shape_index(variant)) {
     case 3:
-    case 4:
-    case 5:
-    case 7: return TileShape{8, 2, 2};
+    case 4: return TileShape{8, 2, 2};
+    case 7: return TileShape{12, 2, 2};
     default: return TileShape{16, 2, 2};
   }
 }
