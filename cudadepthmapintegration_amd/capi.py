@@ -24,7 +24,7 @@ VARIANT_FORCE_GENERAL = 16  # never use the register-tiled kernel
 VARIANT_NO_BRICK_CLASSES = 256  # tiled kernel without the proven per-brick shortcuts
 VARIANT_SPATIAL_ORDER = 512  # tiled kernel: workgroups in spatial order instead of heaviest bricks first
 VARIANT_TILE_SHAPE = {"tk16_w5": 0, "tk16_w6": 32, "tk16_w8": 64, "tk8_w6": 96, "tk8_w6_g2": 128, "tk16_w8_g2": 160,
-                      "tk16_w6_g2": 192, "tk12_w7": 224}  # tiled kernel: column height / compiler register budget / group
+                      "tk16_w6_g2": 192, "tk8_w7": 224}  # tiled kernel: column height / compiler register budget / group
 
 
 class GridDescC(ctypes.Structure):
@@ -59,7 +59,7 @@ class InfoC(ctypes.Structure):
 # every symbol include/dmi.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
     "dmi_default_options", "dmi_create", "dmi_destroy", "dmi_last_error", "dmi_add_views", "dmi_add_views_f32",
-    "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_synchronize",
+    "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_fuse_slab", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error",
@@ -104,6 +104,7 @@ def load() -> ctypes.CDLL:
     L.dmi_upload_grid.argtypes = [vp, dp]
     L.dmi_fuse.argtypes = [vp]
     L.dmi_fuse_range.argtypes = [vp, i32, i32]
+    L.dmi_fuse_slab.argtypes = [vp, i32, i32]
     L.dmi_synchronize.argtypes = [vp]
     L.dmi_download_grid_f64.argtypes = [vp, dp]
     L.dmi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -229,6 +230,10 @@ class FusionContext:
             self._check(self._lib.dmi_fuse(self._h))
         else:
             self._check(self._lib.dmi_fuse_range(self._h, int(first), int(count)))
+
+    def fuse_slab(self, z_first: int, z_count: int):
+        """Fuse every resident view into cell layers [z_first, z_first + z_count) (multiples of 32 cells)."""
+        self._check(self._lib.dmi_fuse_slab(self._h, int(z_first), int(z_count)))
 
     def synchronize(self):
         self._check(self._lib.dmi_synchronize(self._h))

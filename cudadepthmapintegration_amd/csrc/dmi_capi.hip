@@ -625,8 +625,28 @@ int dmi_upload_grid(dmi_context *ctx, const double *grid) {
   return DMI_OK;
 }
 
+namespace {
+int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, int32_t z_count);
+}
+
 int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  return fuse_impl(ctx, first, count, 0, ctx->grid.cell_dims[2]);
+}
+
+int dmi_fuse_slab(dmi_context *ctx, int32_t z_first, int32_t z_count) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  const int32_t nz = ctx->grid.cell_dims[2];
+  if (z_first < 0 || z_count < 0 || z_first > nz || z_count > nz - z_first)
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_slab: layers outside the grid");
+  if (z_first % DMI_SLAB_ALIGNMENT != 0 || (z_first + z_count != nz && (z_first + z_count) % DMI_SLAB_ALIGNMENT != 0))
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_slab: slab boundaries must be multiples of DMI_SLAB_ALIGNMENT (32) cells");
+  if (z_count == 0) return DMI_OK;
+  return fuse_impl(ctx, 0, (int32_t)ctx->h_maps.size(), z_first, z_count);
+}
+
+namespace {
+int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, int32_t z_count) {
   const int32_t n_views = (int32_t)ctx->h_maps.size();
   if (n_views == 0) return fail(ctx, DMI_ERR_STATE, "dmi_fuse: no views resident (call dmi_add_views first)");
   if (first < 0 || count < 0 || first > n_views || count > n_views - first)
@@ -635,6 +655,12 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   int rc = sync_maps(ctx);
   if (rc != DMI_OK) return rc;
+  const bool whole_grid = z_first == 0 && z_count == ctx->grid.cell_dims[2];
+  if (!whole_grid) {
+    // a slab fuse writes only its layers: a deferred zero fill of the rest must happen now
+    rc = flush_zero_fill(ctx);
+    if (rc != DMI_OK) return rc;
+  }
 
   FuseArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -647,6 +673,8 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   a.n_maps = count;
   a.init_from_grid = ctx->grid_is_zero ? 0 : 1;
   a.kz0 = ctx->opt.z_first;
+  a.k_first = z_first;
+  a.k_count = z_count;
   a.ox = ctx->grid.origin[0];
   a.oy = ctx->grid.origin[1];
   a.oz = ctx->grid.origin[2];
@@ -688,6 +716,10 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
     t.super_x = (t.bricks_x + 3) / 4;
     t.super_y = (t.bricks_y + 3) / 4;
     t.super_z = (t.bricks_z + 1) / 2;
+    if (!whole_grid) {  // slab: super-brick layers [sbz_first, sbz_first + super_z)
+      t.sbz_first = z_first / (2 * sh.tk);
+      t.super_z = (z_first + z_count + 2 * sh.tk - 1) / (2 * sh.tk) - t.sbz_first;
+    }
     // spatial order: one z-layer of super-bricks per XCD and round (long runs keep an XCD on one region of every
     // depth map); heaviest-first order: one super-brick's worth, so that the heavy bricks spread over all XCDs
     t.xcd_run_wg = 32 * std::max(1, t.super_x * t.super_y);
@@ -791,11 +823,15 @@ int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
   ctx->last_count = count;
   DMI_HIP(ctx, hipEventRecord(ev.stop, ctx->stream));
   ctx->pending.push_back(ev);
+  // after a whole-grid fuse every voxel has been written; after a slab fuse the other layers still hold what they
+  // held (zeros after a reset): later fuses read the grid, which is correct either way
   ctx->grid_is_zero = false;
-  ctx->zero_fill_pending = false;  // every voxel was just written
+  ctx->zero_fill_pending = false;
   if (ctx->pending.size() >= 256) return drain_events(ctx);
   return DMI_OK;
 }
+
+}  // namespace
 
 int dmi_fuse(dmi_context *ctx) {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;

@@ -22,6 +22,7 @@
 //      spans at most 2 x 2 tiles.
 //   4. class FREE: fl(czmax - dmin) < -delta implies fl(c.z - d) < -delta for every voxel and pixel (monotone
 //      rounding).  Class BEHIND: fl(czmin - dmax) > delta likewise.
+#include <algorithm>
 #include <cstring>
 
 #include "fusion_kernels.h"
@@ -122,15 +123,19 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
 // over 4 consecutive bricks; all index arithmetic in 32 bits
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
-  const int n_bricks = a.wbricks_x * a.wbricks_y * a.bricks_z;
-  const int brick = blockIdx.x * 4 + threadIdx.y;
+  // wave bricks of the slab being fused: layers [2*sbz_first, 2*(sbz_first + super_z)) clipped to the grid
+  const int bz_first = 2 * a.sbz_first;
+  const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
+  const int n_bricks = a.wbricks_x * a.wbricks_y * bz_count;
+  const int local = blockIdx.x * 4 + threadIdx.y;
   const int mm = blockIdx.y * 64 + threadIdx.x;
-  if (brick >= n_bricks || mm >= a.n_maps) return;
+  if (local >= n_bricks || mm >= a.n_maps) return;
   const int m = a.first_map + mm;
-  const int bx = brick % a.wbricks_x;
-  const int bt = brick / a.wbricks_x;
+  const int bx = local % a.wbricks_x;
+  const int bt = local / a.wbricks_x;
   const int by = bt % a.wbricks_y;
-  const int bz = bt / a.wbricks_y;
+  const int bz = bt / a.wbricks_y + bz_first;
+  const int brick = (bz * a.wbricks_y + by) * a.wbricks_x + bx;  // row of the class table (whole grid)
   const MapRec *__restrict__ mr = maps + m;
 
   double czmin = __builtin_inf(), czmax = -__builtin_inf();
@@ -205,11 +210,11 @@ __device__ __forceinline__ bool slot_to_brick(const TileArgs &a, int slot, int &
   const int sb = slot >> 5, within = slot & 31;
   const int sbx = sb % a.super_x;
   const int sbt = sb / a.super_x;
-  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
+  const int sby = sbt % a.super_y, sbz = sbt / a.super_y + a.sbz_first;
   bx = sbx * 4 + (within & 3);
   by = sby * 4 + ((within >> 2) & 3);
   bz = sbz * 2 + (within >> 4);
-  return bx < a.bricks_x && by < a.bricks_y && bz < a.bricks_z;
+  return sbt / a.super_y < a.super_z && bx < a.bricks_x && by < a.bricks_y && bz < a.bricks_z;
 }
 
 constexpr int kWorkLevels = 4;
@@ -316,7 +321,8 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 
 hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, const PyramidDesc &P, int tk, uint8_t *classes,
                                   hipStream_t stream) {
-  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z;
+  const int bz_count = std::min(2 * a.super_z, a.bricks_z - 2 * a.sbz_first);
+  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
   if (n_bricks <= 0 || a.n_maps <= 0) return hipSuccess;
   if (n_bricks > (int64_t)0x7fffffff || (a.n_maps + 63) / 64 > 65535) return hipErrorInvalidConfiguration;
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((n_bricks + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4), 0,

@@ -71,6 +71,7 @@ struct FuseArgs {
   int32_t first_map, n_maps;
   int32_t init_from_grid;  // 0: grid is known to be all zero, skip the read
   int32_t kz0, pad1;       // global cell index of this context's first z layer (dmi_options::z_first)
+  int32_t k_first, k_count;  // cell layers [k_first, k_first + k_count) of the context's grid to fuse (dmi_fuse_slab)
   double ox, oy, oz;       // c_gridOrig
   double sx, sy, sz;       // c_gridSpacing
   double g[12];            // rows 0..2 of c_gridMatrix
@@ -90,7 +91,8 @@ struct TileArgs {
   int32_t nx, ny, nz, W, H, first_map, n_maps, init_from_grid;
   int32_t kpad;                          // row pitch of cz_table (nz rounded up to the column height)
   int32_t bricks_x, bricks_y, bricks_z;  // workgroup bricks per axis
-  int32_t super_x, super_y, super_z;     // super-bricks (4 x 4 x 2 bricks) per axis, XCD-aware ordering
+  int32_t super_x, super_y, super_z;     // super-bricks (4 x 4 x 2 bricks) per axis to fuse, XCD-aware ordering
+  int32_t sbz_first, pad3;               // first super-brick layer of the slab being fused (dmi_fuse_slab); 0 = whole grid
   int32_t depth_bytes;                   // W * H * sizeof(depth element): buffer range of one depth table
   int32_t kz0, pad1;                     // global cell index of the first z layer
   double ox, oy, oz, sx, sy, sz;         // c_gridOrig, c_gridSpacing

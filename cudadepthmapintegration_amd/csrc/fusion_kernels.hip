@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs a) {
   // lane -> voxel: x is the wave dimension (cu:163 uses threadIdx.x for x as well)
   const int i = blockIdx.x * kWave + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
-  const bool inside = i < a.nx && j < a.ny && k < a.nz;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z + a.k_first;  // slab [k_first, k_first + k_count)
+  const bool inside = i < a.nx && j < a.ny && k < a.k_first + a.k_count;
 
   // cu:78-83 computeVoxelCenter, cu:168 grid matrix -- once per voxel instead of once per map
   const double gx = a.ox + (i + 0.5) * a.sx;
@@ -193,7 +193,7 @@ hipError_t launch_fuse(const FuseArgs &a, const FuseConfig &cfg, hipStream_t str
     case 3: block = dim3(kWave, 1, 1); break;
     default: break;
   }
-  dim3 grid((a.nx + kWave - 1) / kWave, (a.ny + block.y - 1) / block.y, (a.nz + block.z - 1) / block.z);
+  dim3 grid((a.nx + kWave - 1) / kWave, (a.ny + block.y - 1) / block.y, (a.k_count + block.z - 1) / block.z);
   if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidConfiguration;
   if (cfg.depth_is_f64) {
     if (cfg.grid_is_f64) return launch_kmode<double, double>(a, cfg, grid, block, stream);

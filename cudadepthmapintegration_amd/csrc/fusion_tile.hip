@@ -172,9 +172,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int sb = slot >> 5, within = slot & 31;
   const int sbx = sb % a.super_x;
   const int sbt = sb / a.super_x;
-  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
+  const int sby = sbt % a.super_y, sbz = sbt / a.super_y + a.sbz_first;  // absolute brick coordinates
   const int bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
-  if (bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
+  if (sbt / a.super_y >= a.super_z || bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and provably so
@@ -438,7 +438,7 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 2>(a, cfg, s);
       case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 2>(a, cfg, s);  // 64 + 32 = 96: 5 waves, loads in flight: 2
       case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
-      case 7: return launch_shape<DepthT, GridT, 12, 2, 2, 7, 4>(a, cfg, s);  // 72 + 24 = 96: 5 waves
+      case 7: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);   // 72 + 16 = 88: 5 waves
       default: break;
     }
   }
@@ -452,8 +452,8 @@ int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VA
 TileShape tile_shape(int variant, bool depth_is_f64) {
   switch (depth_is_f64 ? 0 : tile_shape_index(variant)) {
     case 3:
-    case 4: return TileShape{8, 2, 2};
-    case 7: return TileShape{12, 2, 2};
+    case 4:
+    case 7: return TileShape{8, 2, 2};
     default: return TileShape{16, 2, 2};
   }
 }

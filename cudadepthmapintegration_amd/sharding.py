@@ -47,3 +47,36 @@ def sharded_tolerance(world: int, abs_partial_sum):
     (2^-24 relative), the reduction adds world-1 f32 roundings of partial sums, fp64 reordering is
     below that."""
     return (2 * world) * 2.0 ** -24 * abs_partial_sum + 1e-30
+
+
+def slab_ranges(nz: int, n_slabs: int, align: int = 32) -> list[tuple[int, int]]:
+    """nz cell layers split into at most n_slabs contiguous (z_first, z_count) ranges whose inner boundaries are
+    multiples of `align` (dmi.h: DMI_SLAB_ALIGNMENT)."""
+    units = -(-int(nz) // align)
+    n = max(1, min(int(n_slabs), units))
+    out = []
+    for s in range(n):
+        lo, hi = view_shard(units, s, n)
+        z0, z1 = min(lo * align, nz), min(hi * align, nz)
+        if z1 > z0:
+            out.append((z0, z1 - z0))
+    return out
+
+
+def fuse_and_all_reduce(ctx, grid_t, cell_dims, n_slabs, fuse_stream, comm_stream, group=None):
+    """One fusion step of the depth-map-sharded multi-GPU path with the exchange hidden behind the compute:
+    the grid is fused slab by slab (dmi_fuse_slab, on `fuse_stream`, the stream the context was created with) and
+    the all-reduce of slab i runs on `comm_stream` while slab i+1 is being fused.  Same result as ctx.fuse()
+    followed by one all-reduce of the whole grid.  grid_t is the context's external grid ([nz*ny*nx] tensor)."""
+    import torch
+
+    nx, ny, nz = (int(c) for c in cell_dims)
+    plane = nx * ny
+    for z0, zc in slab_ranges(nz, n_slabs):
+        ctx.fuse_slab(z0, zc)
+        done = torch.cuda.Event()
+        done.record(fuse_stream)
+        comm_stream.wait_event(done)
+        with torch.cuda.stream(comm_stream):
+            all_reduce_grid(grid_t[z0 * plane:(z0 + zc) * plane], group=group)
+    fuse_stream.wait_stream(comm_stream)  # whoever touches the grid next on fuse_stream sees the reduced values

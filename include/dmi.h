@@ -163,6 +163,13 @@ int dmi_fuse(dmi_context *ctx);
 /* Fuse only views [first, first+count): lets a caller shard or batch the resident views. */
 int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count);
 
+/* Fuse every resident view into the cell layers [z_first, z_first + z_count) only.  Lets a caller pipeline a
+ * fusion with what consumes the grid (bench.py overlaps the RCCL all-reduce of slab i with the fusion of slab
+ * i+1).  Slabs fused one after the other give the same bits as one dmi_fuse.  z_first and z_first + z_count
+ * must be multiples of DMI_SLAB_ALIGNMENT or the end of the grid. */
+#define DMI_SLAB_ALIGNMENT 32
+int dmi_fuse_slab(dmi_context *ctx, int32_t z_first, int32_t z_count);
+
 int dmi_synchronize(dmi_context *ctx);
 
 /* Replace the D2H copy and the per-tuple copy into io_scalar (cu:368-371).  They synchronise. */

@@ -5,6 +5,12 @@ import sys
 import numpy as np
 import pytest
 
+try:  # load torch's bundled HIP runtime BEFORE libdmi_hip.so pulls in the system one: a process that ends up with
+    # the two in the other order finds no GPU when torch initialises (the distributed GPU test needs torch)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for everything but the distributed tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

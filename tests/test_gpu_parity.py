@@ -345,3 +345,65 @@ def test_brick_classes_with_fuse_range_and_initial_grid():
         out = ctx.download_grid()
         vh, mh = ctx.download_hits()
     assert bits_equal(out, want) and np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w)
+
+
+@pytest.mark.parametrize("variant", [0, NC, G])
+def test_slab_fuses_equal_one_fuse(variant):
+    """dmi_fuse_slab: the grid fused slab by slab (what bench.py overlaps with the all-reduce) is bit-identical."""
+    from cudadepthmapintegration_amd import sharding
+    grid = scene.default_grid((40, 24, 100))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(5, 80, 60, seed=19, dense=True)
+    want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                   n_threads=oracle.max_threads())
+    with capi.FusionContext(grid, rp, count_hits=True, kernel_variant=variant) as ctx:
+        ctx.add_views(views)
+        for z0, zc in sharding.slab_ranges(100, 3):
+            ctx.fuse_slab(z0, zc)
+        out = ctx.download_grid()
+        vh, mh = ctx.download_hits()
+        assert bits_equal(out, want) and np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w)
+        with pytest.raises(capi.DmiError):
+            ctx.fuse_slab(8, 32)        # not aligned
+        with pytest.raises(capi.DmiError):
+            ctx.fuse_slab(96, 32)       # beyond the grid
+
+
+def test_overlapped_fuse_and_all_reduce_single_rank(tmp_path):
+    """sharding.fuse_and_all_reduce with a one-rank RCCL group on this GPU: streams, events and the slab API work
+    together and the result equals a plain fuse (the N > 1 arithmetic is covered by tests/test_sharding.py)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from cudadepthmapintegration_amd import sharding
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        grid = scene.default_grid((48, 40, 96))
+        rp = scene.default_ray_potential(grid)
+        views = scene.make_views(4, 80, 60, seed=23, dense=True, dtype=np.float32)
+        torch.cuda.set_device(0)
+        grid_t = torch.zeros(grid.n_voxels, dtype=torch.float32, device="cuda")
+        fuse_stream, comm_stream = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with capi.FusionContext(grid, rp, grid_dtype="f32", stream=fuse_stream.cuda_stream,
+                                external_grid=grid_t.data_ptr()) as ctx:
+            ctx.add_views(views)
+            for _ in range(2):
+                ctx.reset_grid()
+                sharding.fuse_and_all_reduce(ctx, grid_t, grid.cell_dims, 3, fuse_stream, comm_stream)
+            torch.cuda.synchronize()
+            got = grid_t.cpu().numpy().copy()
+            ctx.reset_grid()
+            ctx.fuse()
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            plain = grid_t.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)) and np.abs(plain).max() > 0
+    finally:
+        dist.destroy_process_group()

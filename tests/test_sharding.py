@@ -35,6 +35,15 @@ def test_z_slab_respects_column_height():
                 assert all(lo % mult == 0 for lo, hi in r if lo < nz)
 
 
+def test_slab_ranges_cover_the_grid_on_aligned_boundaries():
+    for nz in (1, 31, 32, 100, 512, 1000):
+        for n in (1, 2, 4, 7, 64):
+            r = sharding.slab_ranges(nz, n)
+            assert r[0][0] == 0 and r[-1][0] + r[-1][1] == nz and len(r) <= n
+            assert all(a[0] + a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert all(z0 % 32 == 0 for z0, _ in r)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
