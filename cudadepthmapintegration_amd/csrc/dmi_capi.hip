@@ -720,6 +720,8 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
       t.sbz_first = z_first / (2 * sh.tk);
       t.super_z = (z_first + z_count + 2 * sh.tk - 1) / (2 * sh.tk) - t.sbz_first;
     }
+    t.slot_base = t.sbz_first * t.super_x * t.super_y * 32;
+    t.slot_count = t.super_x * t.super_y * t.super_z * 32;
     // spatial order: one z-layer of super-bricks per XCD and round (long runs keep an XCD on one region of every
     // depth map); heaviest-first order: one super-brick's worth, so that the heavy bricks spread over all XCDs
     t.xcd_run_wg = 32 * std::max(1, t.super_x * t.super_y);

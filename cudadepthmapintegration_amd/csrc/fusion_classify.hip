@@ -205,26 +205,27 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
 // (23 % of the wave slots idle at cfg 3).  So workgroup bricks are partitioned by their share of BRICK_MIXED
 // pairs, heaviest level first, each level kept in spatial (super-brick) order for L2 locality.
 
-// slot = super_brick * 32 + brick within the 4 x 4 x 2 super-brick
+// slot = super_brick * 32 + brick within the 4 x 4 x 2 super-brick, over the whole grid (absolute)
 __device__ __forceinline__ bool slot_to_brick(const TileArgs &a, int slot, int &bx, int &by, int &bz) {
   const int sb = slot >> 5, within = slot & 31;
   const int sbx = sb % a.super_x;
   const int sbt = sb / a.super_x;
-  const int sby = sbt % a.super_y, sbz = sbt / a.super_y + a.sbz_first;
+  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
   bx = sbx * 4 + (within & 3);
   by = sby * 4 + ((within >> 2) & 3);
   bz = sbz * 2 + (within >> 4);
-  return sbt / a.super_y < a.super_z && bx < a.bricks_x && by < a.bricks_y && bz < a.bricks_z;
+  return bx < a.bricks_x && by < a.bricks_y && bz < a.bricks_z;
 }
 
 constexpr int kWorkLevels = 4;
 
 __global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int wx, int wy, int n_slots,
                                                          uint8_t *__restrict__ level) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n_slots) return;
+  const int local = blockIdx.x * blockDim.x + threadIdx.x;  // slot within the slab being fused
+  if (local >= n_slots) return;
+  const int slot = local;
   int bx, by, bz;
-  if (!slot_to_brick(a, slot, bx, by, bz)) {
+  if (!slot_to_brick(a, local + a.slot_base, bx, by, bz)) {
     level[slot] = 255;  // padding of the super-brick grid: no workgroup needed
     return;
   }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int w
 }
 
 // stable partition of the valid slots by level; one workgroup of 1024 threads, each owning a run of slots
-__global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__restrict__ level, int n_slots,
+__global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__restrict__ level, int n_slots, int slot_base,
                                                            int *__restrict__ order, int *__restrict__ n_valid) {
   __shared__ int cnt[kWorkLevels][1024];
   __shared__ int base[kWorkLevels + 1];
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__rest
   for (int l = 0; l < kWorkLevels; ++l) pos[l] = base[l] + cnt[l][t];
   for (int s = lo; s < hi; ++s) {
     const int l = level[s];
-    if (l < kWorkLevels) order[pos[l]++] = s;
+    if (l < kWorkLevels) order[pos[l]++] = s + slot_base;  // absolute slot
   }
 }
 
@@ -336,7 +337,7 @@ hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level
   hipLaunchKernelGGL(brick_work_kernel, dim3(blocks_of(n_slots)), dim3(256), 0, stream, a, wx, wy, n_slots, level);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, stream, level, n_slots, order, n_valid);
+  hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, stream, level, n_slots, a.slot_base, order, n_valid);
   return hipGetLastError();
 }
 

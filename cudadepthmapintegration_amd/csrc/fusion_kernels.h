@@ -93,6 +93,7 @@ struct TileArgs {
   int32_t bricks_x, bricks_y, bricks_z;  // workgroup bricks per axis
   int32_t super_x, super_y, super_z;     // super-bricks (4 x 4 x 2 bricks) per axis to fuse, XCD-aware ordering
   int32_t sbz_first, pad3;               // first super-brick layer of the slab being fused (dmi_fuse_slab); 0 = whole grid
+  int32_t slot_base, slot_count;         // = sbz_first * super_x * super_y * 32, super_x * super_y * super_z * 32
   int32_t depth_bytes;                   // W * H * sizeof(depth element): buffer range of one depth table
   int32_t kz0, pad1;                     // global cell index of the first z layer
   double ox, oy, oz, sx, sy, sz;         // c_gridOrig, c_gridSpacing

@@ -164,17 +164,20 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int run = a.xcd_run_wg;                 // workgroups dealt to one XCD in a row
   const int p = (q / run) * (8 * run) + (b & 7) * run + q % run;
   // heaviest bricks first when the classification has ordered them (fusion_classify.hip), else spatial order
-  int slot = p;
+  // slots are absolute (whole grid); a slab fuse (dmi_fuse_slab) covers slots [slot_base, slot_base + slot_count)
+  int slot = p + a.slot_base;
   if (a.order) {
     if (p >= cload(a.n_order)) return;
     slot = cload(a.order + p);
+  } else if (p >= a.slot_count) {
+    return;
   }
   const int sb = slot >> 5, within = slot & 31;
   const int sbx = sb % a.super_x;
   const int sbt = sb / a.super_x;
-  const int sby = sbt % a.super_y, sbz = sbt / a.super_y + a.sbz_first;  // absolute brick coordinates
+  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
   const int bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
-  if (sbt / a.super_y >= a.super_z || bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
+  if (bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and provably so
