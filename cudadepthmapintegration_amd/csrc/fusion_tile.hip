@@ -227,9 +227,13 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                       a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch)
                 : nullptr;
 
-  unsigned long long cword = 0ull;  // all BRICK_MIXED when classes are off
+  unsigned long long cword = 0ull, cnext = 0ull;  // all BRICK_MIXED when classes are off
+  if (crow) cnext = cload(crow + (a.first_map >> 3));
   for (int m = a.first_map; m < m_end; ++m) {
-    if (crow && ((m & 7) == 0 || m == a.first_map)) cword = cload(crow + (m >> 3));
+    if (crow && ((m & 7) == 0 || m == a.first_map)) {
+      cword = cnext;  // fetched one block ahead: its latency hides behind the previous eight maps
+      if ((((m >> 3) + 1) << 3) < m_end) cnext = cload(crow + (m >> 3) + 1);
+    }
     if (cword == 0x0303030303030303ull) {  // none of this block's eight maps touches the brick
       m |= 7;
       continue;
