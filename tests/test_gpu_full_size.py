@@ -82,3 +82,26 @@ def test_cfg3_512cubed_256_maps_720p_f32_grid():
     got = out["tiled"].reshape(-1)[ids]
     assert np.array_equal(got, want.astype(np.float32))            # exactly the f32 rounding of the f64 sum
     assert np.abs(want).max() > 1.0
+
+
+def test_1024cubed_grid_indexing():
+    """BASELINE configs[4] grid size (1024^3 voxels = 4.3 GB f32, 2^30 cells): 64-bit indexing of the grid, the class
+    table and the brick order.  Fewer and smaller views than config 5 to keep the test short."""
+    grid = scene.default_grid(1024)
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(24, 640, 480, seed=1234, dense=True, layout="sphere", dtype=np.float32)
+    out = {}
+    for name, variant in (("tiled", 0), ("general", G)):
+        with capi.FusionContext(grid, rp, grid_dtype="f32", kernel_variant=variant) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            out[name] = ctx.download_grid(np.float32)
+            if name == "tiled":
+                hist = ctx.brick_class_histogram()
+                assert sum(hist.values()) == 128 * 128 * 64 * views.n and hist["free"] > 0 and hist["mixed"] > 0
+    assert np.array_equal(out["tiled"].view(np.uint32), out["general"].view(np.uint32))
+    ids = _sample_ids(grid, 4096, 3)
+    want, _ = oracle.fuse_voxels(oracle_params_from_scene(grid, rp, views), views.depth.astype(np.float64), views.K4,
+                                 views.RT4, ids, n_threads=oracle.max_threads())
+    assert np.array_equal(out["tiled"].reshape(-1)[ids], want.astype(np.float32))
+    assert np.abs(want).max() > 0.5
