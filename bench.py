@@ -243,6 +243,21 @@ def main():
             c2.close()
             del g2
 
+    # the step right after the path: cell data -> point data of the fused grid, HBM-bound
+    cell_to_point = None
+    if world == 1:
+        ts = []
+        for _ in range(4):
+            ctx.cell_to_point()
+            ctx.synchronize()
+            ts.append(ctx.timings().last_cell_to_point_ms)
+        c2p_ms = float(np.median(ts[1:]))
+        n_pts = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+        c2p_bytes = float((4 if args.grid_dtype == "f32" else 8) * n_vox + 8 * n_pts)
+        cell_to_point = {"kernel": "dmi::cell_to_point_kernel", "kernel_ms": c2p_ms, "bound": "hbm",
+                         "algorithmic_bytes": c2p_bytes, "achieved": c2p_bytes / (c2p_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c2p_bytes / (c2p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
     secondary = None
     if args.secondary and world == 1:
         other = "sparse" if args.scene == "dense" else "dense"
@@ -326,6 +341,8 @@ def main():
         out["ablation"] = ablation
     if secondary:
         out["secondary"] = secondary
+    if cell_to_point:
+        out["cell_to_point"] = cell_to_point
     if rank == 0 and world == 1 and not args.no_coloration:
         out["coloration"] = coloration_probe(scene, capi, args.coloration_vertices, W, H)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

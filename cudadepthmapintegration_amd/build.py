@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libdmi_hip.so")
 
-SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "dmi_capi.hip", "host/recon_host.cpp", "host/dmi_host_capi.cpp"]
+SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "host/recon_host.cpp", "host/dmi_host_capi.cpp"]
 HEADERS = ["fusion_kernels.h", "fusion_device.h", "fusion_tile_acc.inc", os.path.join("host", "recon_host.h"),
            os.path.join("..", "..", "include", "dmi.h"), os.path.join("..", "..", "include", "dmi_host.h")]
 

@@ -46,7 +46,7 @@ class OptionsC(ctypes.Structure):
 class TimingsC(ctypes.Structure):
     _fields_ = [("last_fuse_kernel_ms", ctypes.c_double), ("total_fuse_kernel_ms", ctypes.c_double),
                 ("fuse_launches", ctypes.c_uint64), ("last_upload_ms", ctypes.c_double),
-                ("last_download_ms", ctypes.c_double)]
+                ("last_download_ms", ctypes.c_double), ("last_cell_to_point_ms", ctypes.c_double)]
 
 
 class InfoC(ctypes.Structure):
@@ -62,7 +62,8 @@ ABI_SYMBOLS = [
     "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_fuse_slab", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
-    "dmi_color_mesh", "dmi_color_last_error",
+    "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
+    "dmi_point_data_device_pointer",
 ]
 
 _lib = None
@@ -110,6 +111,9 @@ def load() -> ctypes.CDLL:
     L.dmi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.dmi_download_hits.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_grid_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
+    L.dmi_cell_to_point.argtypes = [vp]
+    L.dmi_download_point_data_f64.argtypes = [vp, dp]
+    L.dmi_point_data_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
     L.dmi_get_brick_class_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
@@ -260,6 +264,17 @@ class FusionContext:
         p = ctypes.c_void_p()
         self._check(self._lib.dmi_grid_device_pointer(self._h, ctypes.byref(p)))
         return int(p.value)
+
+    def cell_to_point(self):
+        """vtkCellDataToPointData of the grid on the device (asynchronous; Reconstruction/main.cxx:151-155)."""
+        self._check(self._lib.dmi_cell_to_point(self._h))
+
+    def download_point_data(self) -> np.ndarray:
+        """The point-data form of the grid, [nz+1, ny+1, nx+1] f64."""
+        nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        out = np.empty((nz + 1) * (ny + 1) * (nx + 1), dtype=np.float64)
+        self._check(self._lib.dmi_download_point_data_f64(self._h, _dp(out)))
+        return out.reshape(nz + 1, ny + 1, nx + 1)
 
     def brick_class_histogram(self) -> dict:
         """(brick, view) pairs of the last fuse by proven class (diagnostic)."""

@@ -84,6 +84,11 @@ struct dmi_context {
   int32_t *d_order = nullptr;
   size_t order_capacity = 0;     // slots
 
+  double *d_points = nullptr;     // vtkCellDataToPointData of the grid, (nx+1)(ny+1)(nz+1) f64 (grid_post.hip)
+  bool points_valid = false;      // d_points matches the grid's current contents
+  hipEvent_t c2p_start = nullptr, c2p_stop = nullptr;
+  bool c2p_pending = false;
+
   double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
   size_t stage_capacity = 0;  // elements per staging buffer
   unsigned long long *d_lossy = nullptr;
@@ -558,6 +563,9 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
   if (ctx->d_stage_cost) (void)hipFree(ctx->d_stage_cost);
   if (ctx->d_lossy) (void)hipFree(ctx->d_lossy);
+  if (ctx->d_points) (void)hipFree(ctx->d_points);
+  if (ctx->c2p_start) (void)hipEventDestroy(ctx->c2p_start);
+  if (ctx->c2p_stop) (void)hipEventDestroy(ctx->c2p_stop);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -605,6 +613,7 @@ int dmi_reset_grid(dmi_context *ctx) {
   if (ctx->d_map_hits)
     DMI_HIP(ctx, hipMemsetAsync(ctx->d_map_hits, 0, ctx->map_hits_capacity * sizeof(unsigned long long), ctx->stream));
   ctx->grid_is_zero = true;
+  ctx->points_valid = false;
   return DMI_OK;
 }
 
@@ -622,6 +631,7 @@ int dmi_upload_grid(dmi_context *ctx, const double *grid) {
     DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   ctx->grid_is_zero = false;
+  ctx->points_valid = false;
   return DMI_OK;
 }
 
@@ -829,6 +839,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   // held (zeros after a reset): later fuses read the grid, which is correct either way
   ctx->grid_is_zero = false;
   ctx->zero_fill_pending = false;
+  ctx->points_valid = false;
   if (ctx->pending.size() >= 256) return drain_events(ctx);
   return DMI_OK;
 }
@@ -915,6 +926,66 @@ int dmi_grid_device_pointer(dmi_context *ctx, void **ptr) {
   return DMI_OK;
 }
 
+namespace {
+int64_t n_points(const dmi_context *c) {
+  return (int64_t)(c->grid.cell_dims[0] + 1) * (c->grid.cell_dims[1] + 1) * (c->grid.cell_dims[2] + 1);
+}
+int drain_c2p(dmi_context *ctx) {
+  if (!ctx->c2p_pending) return DMI_OK;
+  DMI_HIP(ctx, hipEventSynchronize(ctx->c2p_stop));
+  float ms = 0.f;
+  DMI_HIP(ctx, hipEventElapsedTime(&ms, ctx->c2p_start, ctx->c2p_stop));
+  ctx->timings.last_cell_to_point_ms = ms;
+  ctx->c2p_pending = false;
+  return DMI_OK;
+}
+}  // namespace
+
+int dmi_cell_to_point(dmi_context *ctx) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  // an external grid can be changed by its owner (e.g. an all-reduce) without the context knowing: always recompute
+  if (ctx->points_valid && ctx->own_grid) return DMI_OK;
+  int rc = flush_zero_fill(ctx);
+  if (rc != DMI_OK) return rc;
+  rc = drain_c2p(ctx);
+  if (rc != DMI_OK) return rc;
+  if (!ctx->d_points) {
+    DMI_HIP(ctx, hipMalloc(&ctx->d_points, (size_t)n_points(ctx) * 8));
+    ctx->device_bytes += (uint64_t)n_points(ctx) * 8;
+  }
+  if (!ctx->c2p_start) {
+    DMI_HIP(ctx, hipEventCreate(&ctx->c2p_start));
+    DMI_HIP(ctx, hipEventCreate(&ctx->c2p_stop));
+  }
+  DMI_HIP(ctx, hipEventRecord(ctx->c2p_start, ctx->stream));
+  DMI_HIP(ctx, dmi::launch_cell_to_point(ctx->d_grid, ctx->opt.grid_dtype == DMI_F64 ? 1 : 0, ctx->d_points,
+                                         ctx->grid.cell_dims[0], ctx->grid.cell_dims[1], ctx->grid.cell_dims[2], ctx->stream));
+  DMI_HIP(ctx, hipEventRecord(ctx->c2p_stop, ctx->stream));
+  ctx->c2p_pending = true;
+  ctx->points_valid = true;
+  return DMI_OK;
+}
+
+int dmi_download_point_data_f64(dmi_context *ctx, double *out) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_download_point_data_f64: null argument");
+  int rc = dmi_cell_to_point(ctx);
+  if (rc != DMI_OK) return rc;
+  DMI_HIP(ctx, hipMemcpyAsync(out, ctx->d_points, (size_t)n_points(ctx) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = drain_c2p(ctx);
+  if (rc != DMI_OK) return rc;
+  return drain_events(ctx);
+}
+
+int dmi_point_data_device_pointer(dmi_context *ctx, void **ptr) {
+  if (!ctx || !ptr) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_point_data_device_pointer: null argument");
+  int rc = dmi_cell_to_point(ctx);
+  if (rc != DMI_OK) return rc;
+  *ptr = ctx->d_points;
+  return DMI_OK;
+}
+
 int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]) {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_brick_class_histogram: null argument");
   out[0] = out[1] = out[2] = out[3] = 0;
@@ -935,6 +1006,8 @@ int dmi_get_timings(dmi_context *ctx, dmi_timings *out) {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_timings: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   int rc = drain_events(ctx);
+  if (rc != DMI_OK) return rc;
+  rc = drain_c2p(ctx);
   if (rc != DMI_OK) return rc;
   *out = ctx->timings;
   return DMI_OK;

@@ -183,4 +183,9 @@ hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, 
 hipError_t launch_order_bricks(const TileArgs &args, int wx, int wy, uint8_t *level, int *order, int *n_valid,
                                hipStream_t stream);
 
+// vtkCellDataToPointData over the fused grid (Reconstruction/main.cxx:151-155): points[(nz+1)][(ny+1)][(nx+1)] f64
+// from cells[nz][ny][nx] (grid_post.hip)
+hipError_t launch_cell_to_point(const void *cells, int cells_are_f64, double *points, int nx, int ny, int nz,
+                                hipStream_t stream);
+
 }  // namespace dmi

@@ -101,6 +101,7 @@ typedef struct dmi_timings {
   uint64_t fuse_launches;
   double last_upload_ms; /* host wall time of the last dmi_add_views (copy + convert, synchronised) */
   double last_download_ms;
+  double last_cell_to_point_ms; /* hipEvent time of the last dmi_cell_to_point kernel */
 } dmi_timings;
 
 typedef struct dmi_info {
@@ -182,6 +183,16 @@ int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits
 
 /* Device pointer of the grid (context-owned or external) for zero-copy consumers. */
 int dmi_grid_device_pointer(dmi_context *ctx, void **ptr);
+
+/* The step right after the filter in the reference's CLI (Reconstruction/main.cxx:151-155): vtkCellDataToPointData
+ * over "reconstruction_scalar".  Point (i, j, k) of the (nx+1)(ny+1)(nz+1) lattice gets the mean of its 1..8
+ * adjacent cells, accumulated as VTK does (w = 1/count; c += w*v in vtkStructuredData::GetPointCells order), f64.
+ * dmi_cell_to_point runs the kernel on the context's stream into a context-owned device buffer (asynchronous);
+ * dmi_download_point_data_f64 runs it if the grid changed since, then copies (nx+1)(ny+1)(nz+1) doubles, x fastest,
+ * to `out` and synchronises; dmi_point_data_device_pointer hands the device buffer to a zero-copy consumer. */
+int dmi_cell_to_point(dmi_context *ctx);
+int dmi_download_point_data_f64(dmi_context *ctx, double *out);
+int dmi_point_data_device_pointer(dmi_context *ctx, void **ptr);
 
 /* Diagnostic: how many (8 x 8 x column brick, view) pairs of the last dmi_fuse were proven to be handled
  * uniformly.  out[0] mixed (per-voxel path), out[1] all voxels accumulate -eta*rho, out[2] all accumulate 0,

@@ -72,6 +72,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_color_mesh.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint8), dp, dp, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8),
                                         ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)]
+        L.oracle_cell_to_point.restype = None
+        L.oracle_cell_to_point.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
         _lib = L
     return _lib
 
@@ -183,3 +185,13 @@ def color_mesh(points, colors, K4, RT4):
     lib().oracle_color_mesh(_dp(pts), nv, col.ctypes.data_as(u8), _dp(K4), _dp(RT4), n, W, H, mean.ctypes.data_as(u8),
                             median.ctypes.data_as(u8), count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     return mean, median, count
+
+
+def cell_to_point(cells) -> np.ndarray:
+    """vtkCellDataToPointData on an image grid (Reconstruction/main.cxx:151-155).  cells [nz,ny,nx] f64 ->
+    points [nz+1,ny+1,nx+1] f64."""
+    c = _c64(cells)
+    nz, ny, nx = c.shape
+    out = np.zeros((nz + 1, ny + 1, nx + 1), dtype=np.float64)
+    lib().oracle_cell_to_point(_dp(c), nx, ny, nz, _dp(out))
+    return out

@@ -120,3 +120,29 @@ def color_mesh_np(points, colors, K4, RT4):
                 s = sorted(lists[ch])
                 median[i, ch] = int((s[k // 2] + s[k // 2 - 1]) / 2) if k % 2 == 0 else s[k // 2]
     return mean, median, count
+
+
+def cell_to_point_np(cells):
+    """vtkCellDataToPointData on an image grid (Reconstruction/main.cxx:151-155), written independently of
+    oracle_cell_to_point: padded arrays and masks instead of per-point id lists; same offset order
+    (vtkStructuredData::GetPointCells) and the same c = 0; c += w*v accumulation."""
+    c = np.asarray(cells, dtype=np.float64)
+    nz, ny, nx = c.shape
+    pad = np.zeros((nz + 2, ny + 2, nx + 2))
+    pad[1:-1, 1:-1, 1:-1] = c
+    valid = np.zeros((nz + 2, ny + 2, nx + 2), dtype=bool)
+    valid[1:-1, 1:-1, 1:-1] = True
+    offsets = [(-1, 0, 0), (-1, -1, 0), (-1, -1, -1), (-1, 0, -1), (0, 0, 0), (0, -1, 0), (0, -1, -1), (0, 0, -1)]
+
+    def shifted(a, dx, dy, dz):  # value of cell (i+dx, j+dy, k+dz) for every point (i, j, k)
+        return a[1 + dz:nz + 2 + dz, 1 + dy:ny + 2 + dy, 1 + dx:nx + 2 + dx]
+
+    count = np.zeros((nz + 1, ny + 1, nx + 1))
+    for dx, dy, dz in offsets:
+        count += shifted(valid, dx, dy, dz)
+    w = 1.0 / count
+    out = np.zeros((nz + 1, ny + 1, nx + 1))
+    for dx, dy, dz in offsets:
+        m = shifted(valid, dx, dy, dz)
+        out = np.where(m, out + w * shifted(pad, dx, dy, dz), out)
+    return out

@@ -226,6 +226,40 @@ void oracle_k3_to_k4(const double K3[9], double K4[16])
       K4[i * 4 + j] = K3[i * 3 + j];
 }
 
+/* Reconstruction/main.cxx:151-155: vtkCellDataToPointData on the filter's output, the step right after the path.
+ * VTK is a third-party dependency (unpinned by the reference's CMakeLists.txt:8-17, absent from this image);
+ * restated from its published algorithm, vtkCellDataToPointData::InterpolatePointData:
+ *   for every point: cellIds = vtkStructuredData::GetPointCells(point); w = 1.0 / numCells;
+ *   value = sum over cellIds IN THAT ORDER of w * cell value (vtkDataArray::InterpolateTuple: c = 0; c += w*v).
+ * GetPointCells walks the eight offsets below and skips cells outside the grid.  numCells is 1, 2, 4 or 8 on an
+ * image grid, so w*v is exact; only the order of additions can matter (a different order moves the result by at
+ * most 3 ulp of the largest partial sum; tests/test_cell_to_point.py states that bound next to the bit-exact
+ * comparison with this loop).
+ * cells [nz][ny][nx] x fastest, points [(nz+1)][(ny+1)][(nx+1)] x fastest. */
+void oracle_cell_to_point(const double *cells, int nx, int ny, int nz, double *points)
+{
+  static const int offset[8][3] = {{-1, 0, 0}, {-1, -1, 0}, {-1, -1, -1}, {-1, 0, -1},
+                                   {0, 0, 0},  {0, -1, 0},  {0, -1, -1},  {0, 0, -1}};
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k <= nz; ++k)
+    for (int j = 0; j <= ny; ++j)
+      for (int i = 0; i <= nx; ++i) {
+        int64_t ids[8];
+        int n = 0;
+        for (int o = 0; o < 8; ++o) {
+          const int ci = i + offset[o][0], cj = j + offset[o][1], ck = k + offset[o][2];
+          if (ci < 0 || ci >= nx || cj < 0 || cj >= ny || ck < 0 || ck >= nz)
+            continue;
+          ids[n++] = ((int64_t)ck * ny + cj) * nx + ci;
+        }
+        const double w = 1.0 / (double)n; /* n >= 1: every lattice point touches a cell */
+        double c = 0;
+        for (int q = 0; q < n; ++q)
+          c += w * cells[ids[q]];
+        points[((int64_t)k * (ny + 1) + j) * (nx + 1) + i] = c;
+      }
+}
+
 /* Exposed for known-answer tests of the ray-potential function alone. */
 double oracle_ray_potential(const oracle_params *p, double real_distance, double depth_map_distance)
 {
