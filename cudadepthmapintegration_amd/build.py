@@ -18,8 +18,9 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libdmi_hip.so")
 
-SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "host/recon_host.cpp", "host/dmi_host_capi.cpp"]
+SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "host/recon_host.cpp", "host/vti_reader.cpp", "host/dmi_host_capi.cpp"]
 HEADERS = ["fusion_kernels.h", "fusion_device.h", "fusion_tile_acc.inc", os.path.join("host", "recon_host.h"),
+           os.path.join("host", "vti_reader.h"),
            os.path.join("..", "..", "include", "dmi.h"), os.path.join("..", "..", "include", "dmi_host.h")]
 
 # -ffp-contract=off: no FMA contraction anywhere on the result path (parity contract).
@@ -82,7 +83,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, _sources()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-lz", "-o", LIB_PATH]  # zlib: compressed .vti arrays (host/vti_reader.cpp)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

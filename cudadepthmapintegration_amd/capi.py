@@ -336,7 +336,7 @@ HOST_ABI_SYMBOLS = [
     "dmi_filter_set_kernel_variant", "dmi_filter_update", "dmi_filter_get_execution_time",
     "dmi_filter_get_fuse_kernel_ms", "dmi_filter_get_number_of_cells", "dmi_filter_get_output",
     "dmi_filter_last_error", "dmi_read_krtd_file", "dmi_extract_all_file_path", "dmi_k3_to_k4",
-    "dmi_apply_depth_threshold", "dmi_read_depth_map", "dmi_mesh_coloration_from_lists",
+    "dmi_apply_depth_threshold", "dmi_read_depth_map", "dmi_read_depth_map_color", "dmi_mesh_coloration_from_lists",
 ]
 
 _host_bound = False
@@ -379,6 +379,8 @@ def load_host() -> ctypes.CDLL:
     L.dmi_k3_to_k4.restype, L.dmi_k3_to_k4.argtypes = None, [dp, dp]
     L.dmi_apply_depth_threshold.restype, L.dmi_apply_depth_threshold.argtypes = i64, [dp, dp, i64, dbl]
     L.dmi_read_depth_map.restype, L.dmi_read_depth_map.argtypes = ctypes.c_int, [ctypes.c_char_p, ip, dp, dp, ip]
+    L.dmi_read_depth_map_color.restype = ctypes.c_int
+    L.dmi_read_depth_map_color.argtypes = [ctypes.c_char_p, ip, ctypes.POINTER(ctypes.c_uint8), ip]
     L.dmi_mesh_coloration_from_lists.restype = ctypes.c_int
     L.dmi_mesh_coloration_from_lists.argtypes = [dp, i64, ctypes.c_char_p, ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_uint8),
                                                  ctypes.POINTER(ctypes.c_uint8), ip, ctypes.c_char_p, ctypes.c_size_t]
@@ -512,6 +514,18 @@ def read_depth_map(path):
     L.dmi_read_depth_map(os.fsencode(path), dims, _dp(d), _dp(bc), ctypes.byref(has))
     shape = (dims[1], dims[0])
     return d.reshape(shape), (bc.reshape(shape) if has.value else None)
+
+
+def read_depth_map_color(path):
+    """The "Color" array of a depth-map .vti as [H, W, 3] u8 (vtk row order), or None when the file has none."""
+    L = load_host()
+    dims = (ctypes.c_int32 * 3)()
+    has = ctypes.c_int32(0)
+    if not L.dmi_read_depth_map_color(os.fsencode(path), dims, None, ctypes.byref(has)) or not has.value:
+        return None
+    c = np.zeros(dims[0] * dims[1] * dims[2] * 3, dtype=np.uint8)
+    L.dmi_read_depth_map_color(os.fsencode(path), dims, c.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(has))
+    return c.reshape(dims[1], dims[0], 3)
 
 
 def mesh_coloration_from_lists(points, vti_list, krtd_list, device: int = 0):

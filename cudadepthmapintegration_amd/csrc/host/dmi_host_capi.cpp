@@ -128,6 +128,16 @@ int dmi_read_depth_map(const char *path, int32_t dims[3], double *depths, double
   return 1;
 }
 
+int dmi_read_depth_map_color(const char *path, int32_t dims[3], uint8_t *color, int32_t *has_color) {
+  if (!path || !dims) return 0;
+  DepthImage img;
+  if (!ReconstructionData::ReadDepthMap(path, &img)) return 0;
+  for (int a = 0; a < 3; ++a) dims[a] = img.dims[a];
+  if (has_color) *has_color = img.color.empty() ? 0 : 1;
+  if (color && !img.color.empty()) std::memcpy(color, img.color.data(), img.color.size());
+  return 1;
+}
+
 int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const char *vti_list, const char *krtd_list,
                                    int32_t device, uint8_t *mean, uint8_t *median, int32_t *count, char *err, size_t errlen) {
   auto fail = [&](const std::string &m) {

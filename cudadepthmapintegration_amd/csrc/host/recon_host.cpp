@@ -1,6 +1,7 @@
 // recon_host.cpp -- host side of the fusion path above the C ABI; see recon_host.h for what each piece
 // mirrors in the reference.  Calls only include/dmi.h entry points; no TSDF arithmetic lives here.
 #include "recon_host.h"
+#include "vti_reader.h"
 
 #include <unistd.h>
 
@@ -180,86 +181,38 @@ void ReconstructionData::ApplyDepthThresholdFilter(double thresholdBestCost) {
     if (DepthMap.best_cost[i] > thresholdBestCost) DepthMap.depths[i] = -1;  // RD.cxx:159-166
 }
 
-namespace {
-
-// attribute value of `name="..."` inside an XML tag text
-bool xml_attr(const std::string &tag, const std::string &name, std::string *out) {
-  const std::string key = name + "=\"";
-  std::string::size_type p = tag.find(key);
-  while (p != std::string::npos && p > 0 && !std::isspace((unsigned char)tag[p - 1])) p = tag.find(key, p + 1);
-  if (p == std::string::npos) return false;
-  const std::string::size_type b = p + key.size(), e = tag.find('"', b);
-  if (e == std::string::npos) return false;
-  *out = tag.substr(b, e - b);
-  return true;
-}
-
-}  // namespace
-
 bool ReconstructionData::ReadDepthMap(const std::string &path, DepthImage *out) {
-  std::ifstream f(path.c_str(), std::ios::binary);
-  if (!f.is_open()) {
-    std::cerr << "Unable to open depth map : " << path << std::endl;
+  // RD.cxx:223-229 (vtkXMLImageDataReader) through the VTK-free reader; the arrays are then taken by name and
+  // type exactly as the reference does: "Depths" and "Best Cost Values" must be vtkDoubleArrays (SafeDownCast,
+  // RD.cxx:143-146, cu:249-250), "Color" a vtkUnsignedCharArray with 3 components (RD.cxx:94-95).
+  vti::Image img;
+  std::string err;
+  if (!vti::ReadImageData(path, {"Depths", "Best Cost Values", "Color"}, &img, &err)) {
+    std::cerr << "Unable to read depth map : " << err << std::endl;
     return false;
   }
-  std::stringstream ss;
-  ss << f.rdbuf();
-  const std::string text = ss.str();
-  const std::string::size_type img = text.find("<ImageData");
-  if (img == std::string::npos) return false;
-  const std::string img_tag = text.substr(img, text.find('>', img) - img);
-  std::string extent;
-  if (!xml_attr(img_tag, "WholeExtent", &extent)) return false;
-  int e[6] = {0, 0, 0, 0, 0, 0};
-  std::istringstream es(extent);
-  for (int i = 0; i < 6; ++i) es >> e[i];
-  out->dims[0] = e[1] - e[0] + 1;
-  out->dims[1] = e[3] - e[2] + 1;
-  out->dims[2] = e[5] - e[4] + 1;
+  for (int a = 0; a < 3; ++a) out->dims[a] = img.dims(a);
   const size_t n = (size_t)out->dims[0] * out->dims[1] * out->dims[2];
   out->depths.clear();
   out->best_cost.clear();
   out->color.clear();
-  std::string::size_type p = 0;
-  while ((p = text.find("<DataArray", p)) != std::string::npos) {
-    const std::string::size_type tag_end = text.find('>', p);
-    if (tag_end == std::string::npos) break;
-    const std::string tag = text.substr(p, tag_end - p);
-    std::string name, format, type;
-    xml_attr(tag, "Name", &name);
-    xml_attr(tag, "format", &format);
-    xml_attr(tag, "type", &type);
-    p = tag_end + 1;
-    if (name == "Color") {  // RD.cxx:94-95: unsigned char, 3 components
-      if (format != "ascii" || type != "UInt8") {
-        std::cerr << "ReadDepthMap: array 'Color' is " << type << "/" << format << "; only UInt8 ascii is read without VTK"
-                  << std::endl;
+  for (const vti::Array &a : img.point_data) {
+    if (a.name == "Color") {
+      if (a.type != "UInt8" || a.components != 3) {
+        std::cerr << "ReadDepthMap: array 'Color' is " << a.type << " x " << a.components << ", not UInt8 x 3" << std::endl;
         return false;
       }
-      const std::string::size_type cclose = text.find("</DataArray>", p);
-      if (cclose == std::string::npos) return false;
-      std::istringstream cs(text.substr(p, cclose - p));
-      out->color.clear();
-      out->color.reserve(n * 3);
-      int c;
-      while (cs >> c) out->color.push_back((unsigned char)c);
-      if (out->color.size() != n * 3) return false;
+      out->color = a.bytes;
       continue;
     }
-    std::vector<double> *dst = name == "Depths" ? &out->depths : (name == "Best Cost Values" ? &out->best_cost : nullptr);
-    if (!dst) continue;
-    if (format != "ascii" || type != "Float64") {
-      std::cerr << "ReadDepthMap: array '" << name << "' is " << type << "/" << format
-                << "; only Float64 ascii is read without VTK" << std::endl;
+    std::vector<double> *dst = a.name == "Depths" ? &out->depths : &out->best_cost;
+    if (a.type != "Float64" || a.components != 1) {
+      std::cerr << "ReadDepthMap: array '" << a.name << "' is " << a.type << " x " << a.components
+                << ", not a 1-component Float64 array (the reference down-casts to vtkDoubleArray)" << std::endl;
       return false;
     }
-    const std::string::size_type close = text.find("</DataArray>", p);
-    if (close == std::string::npos) return false;
-    std::istringstream vs(text.substr(p, close - p));
-    dst->reserve(n);
-    double v;
-    while (vs >> v) dst->push_back(v);
-    if (dst->size() != n) return false;
+    dst->resize(n);
+    std::memcpy(dst->data(), a.bytes.data(), n * sizeof(double));
   }
   return !out->depths.empty();
 }

@@ -56,9 +56,14 @@ int dmi_extract_all_file_path(const char *list_path, char *buf, size_t buflen);
 void dmi_k3_to_k4(const double K3[9], double K4[16]);
 /* RD.cxx:138-167 on a bare table; returns how many depths were set to -1. */
 int64_t dmi_apply_depth_threshold(double *depths, const double *best_cost, int64_t n, double threshold);
-/* RD.cxx:223-229 for the ascii Float64 subset of .vti; 1 on success.  dims[3]; depths / best_cost sized by the
- * caller (width*height each, best_cost may be NULL); pass depths == NULL to query dims only. */
+/* RD.cxx:223-229 (vtkXMLImageDataReader) without VTK: every data mode vtkXMLImageDataWriter produces (ascii, binary,
+ * appended raw / base64; with or without vtkZLibDataCompressor; UInt32 / UInt64 headers; either byte order), see
+ * csrc/host/vti_reader.h.  1 on success.  dims[3]; depths / best_cost sized by the caller (width*height each,
+ * best_cost may be NULL); pass depths == NULL to query dims only. */
 int dmi_read_depth_map(const char *path, int32_t dims[3], double *depths, double *best_cost, int32_t *has_best_cost);
+/* The "Color" array of the same file (RD.cxx:94-95: unsigned char x 3, vtk point order): color sized by the caller
+ * (width*height*3) or NULL to query; *has_color = 0 when the file has none.  1 on success. */
+int dmi_read_depth_map_color(const char *path, int32_t dims[3], uint8_t *color, int32_t *has_color);
 
 /* MeshColoration(mesh, vtiList, krtdList) + ProcessColoration() (Coloration/MeshColoration.cxx:52-72, :98-199) on mesh
  * points [n_points][3]; fills mean / median [n_points][3] and count [n_points].  1 on success, 0 on error (message in

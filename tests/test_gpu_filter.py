@@ -63,6 +63,25 @@ def test_filter_from_list_files_bit_exact(tmp_path):
     assert bits_equal(out, _oracle(grid, rp, views, thr))
 
 
+def test_filter_from_compressed_appended_vti_files_bit_exact(tmp_path):
+    """Depth maps as vtkXMLImageDataWriter writes them by default (appended, base64, zlib): same bits as the ascii form."""
+    from vti_writer import write_vti
+    grid = scene.default_grid((24, 20, 16))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(3, 48, 36, seed=4, dense=True, with_best_cost=True)
+    lv, lk = scene.write_view_files(str(tmp_path), views)
+    for m, name in enumerate(capi.extract_all_file_path(lv)):
+        write_vti(name, {"Depths": views.depth[m], "Best Cost Values": views.best_cost[m]}, views.width, views.height,
+                  mode="appended-base64", compress=True, block=4096)
+    with capi.ReconstructionFilter() as f:
+        _configure(f, grid, rp, 0.7)
+        f.SetFilePathVTI(lv)
+        f.SetFilePathKRTD(lk)
+        assert f.Update() == 1, f.LastError()
+        out = f.GetOutputScalars()
+    assert bits_equal(out, _oracle(grid, rp, views, 0.7))
+
+
 def test_filter_rejects_mismatching_view_sizes():
     grid = scene.default_grid(8)
     rp = scene.default_ray_potential(grid)

@@ -160,3 +160,45 @@ def test_filter_list_files_missing_is_an_error(tmp_path):
         f.SetFilePathKRTD(str(tmp_path / "krtdList.txt"))
         f.SetFilePathVTI(str(tmp_path / "vtiList.txt"))
         assert f.Update() == 0 and "no enough vti files" in f.LastError()
+
+
+MODES = [("ascii", False, "UInt32", False), ("binary", False, "UInt32", False), ("binary", True, "UInt32", False),
+         ("binary", True, "UInt64", False), ("appended-raw", False, "UInt32", False), ("appended-raw", True, "UInt64", False),
+         ("appended-base64", False, "UInt64", False), ("appended-base64", True, "UInt32", False),   # the writer's default
+         ("appended-raw", True, "UInt32", True), ("binary", False, "UInt64", True)]
+
+
+@pytest.mark.parametrize("mode,compress,header,big_endian", MODES)
+def test_read_depth_map_every_vti_data_mode(tmp_path, mode, compress, header, big_endian):
+    """RD.cxx:223-229 reads whatever vtkXMLImageDataWriter wrote: every data mode must give back the same arrays."""
+    from vti_writer import write_vti
+    rng = np.random.default_rng(7)
+    W, H = 37, 23                     # 851 points: several compression blocks of 1000 bytes, a partial last one
+    depths = rng.uniform(0.5, 9.0, size=(H, W))
+    depths[rng.random((H, W)) < 0.2] = -1.0
+    cost = rng.random((H, W))
+    color = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    p = tmp_path / "d.vti"
+    write_vti(str(p), {"Depths": depths, "Other": depths.astype(np.float32), "Best Cost Values": cost, "Color": color}, W, H,
+              mode=mode, compress=compress, header=header, big_endian=big_endian, block=1000)
+    d, bc = capi.read_depth_map(str(p))
+    assert d.shape == (H, W) and np.array_equal(d, depths) and np.array_equal(bc, cost)
+    assert np.array_equal(capi.read_depth_map_color(str(p)), color)
+
+
+def test_read_depth_map_rejects_what_the_reference_cannot_use(tmp_path):
+    from vti_writer import write_vti
+    W, H = 5, 4
+    # "Depths" as Float32: the reference's SafeDownCast to vtkDoubleArray gives NULL (cu:249-250); here an error
+    write_vti(str(tmp_path / "f32.vti"), {"Depths": np.ones((H, W), dtype=np.float32)}, W, H, mode="binary")
+    assert capi.read_depth_map(str(tmp_path / "f32.vti")) is None
+    # truncated appended data
+    write_vti(str(tmp_path / "ok.vti"), {"Depths": np.ones((H, W))}, W, H, mode="appended-raw", compress=True)
+    raw = (tmp_path / "ok.vti").read_bytes()
+    cut = raw.index(b"_") + 20
+    (tmp_path / "cut.vti").write_bytes(raw[:cut])
+    assert capi.read_depth_map(str(tmp_path / "ok.vti")) is not None
+    assert capi.read_depth_map(str(tmp_path / "cut.vti")) is None
+    # no depth array at all
+    write_vti(str(tmp_path / "none.vti"), {"Best Cost Values": np.ones((H, W))}, W, H)
+    assert capi.read_depth_map(str(tmp_path / "none.vti")) is None
