@@ -63,7 +63,8 @@ ABI_SYMBOLS = [
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
-    "dmi_point_data_device_pointer",
+    "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
+    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms",
 ]
 
 _lib = None
@@ -121,6 +122,13 @@ def load() -> ctypes.CDLL:
     L.dmi_free_pinned.argtypes = [vp]
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.dmi_color_mesh.argtypes = [dp, ctypes.c_int64, u8p, dp, dp, i32, i32, i32, i32, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
+    L.dmi_color_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.dmi_color_destroy.argtypes = [vp]
+    L.dmi_color_destroy.restype = None
+    L.dmi_color_add_views.argtypes = [vp, u8p, dp, dp, i32, i32, i32]
+    L.dmi_color_clear_views.argtypes = [vp]
+    L.dmi_color_process.argtypes = [vp, dp, ctypes.c_int64, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
+    L.dmi_color_get_kernel_ms.argtypes = [vp, dp]
     L.dmi_color_last_error.argtypes = []
     L.dmi_color_last_error.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
@@ -312,6 +320,66 @@ def color_mesh(points, colors, K4, RT4, device: int = 0):
     if rc != DMI_OK:
         raise DmiError(rc, L.dmi_color_last_error().decode())
     return mean, median, count
+
+
+class ColorContext:
+    """MeshColoration with resident views (dmi_color_create ... dmi_color_destroy)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.dmi_color_create(device, ctypes.byref(self._h))
+        if rc != DMI_OK:
+            self._h = ctypes.c_void_p()
+            raise DmiError(rc, self._lib.dmi_color_last_error().decode())
+
+    def _check(self, rc):
+        if rc != DMI_OK:
+            raise DmiError(rc, self._lib.dmi_color_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dmi_color_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_views(self, colors, K4, RT4):
+        col = np.ascontiguousarray(colors, dtype=np.uint8)
+        n, H, W, _ = col.shape
+        k = np.ascontiguousarray(K4, dtype=np.float64).reshape(n, 16)
+        rt = np.ascontiguousarray(RT4, dtype=np.float64).reshape(n, 16)
+        self._check(self._lib.dmi_color_add_views(self._h, col.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dp(k), _dp(rt),
+                                                  n, W, H))
+
+    def clear_views(self):
+        self._check(self._lib.dmi_color_clear_views(self._h))
+
+    def process(self, points):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        nv = pts.shape[0]
+        mean = np.zeros((nv, 3), dtype=np.uint8)
+        median = np.zeros((nv, 3), dtype=np.uint8)
+        count = np.zeros(nv, dtype=np.int32)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        self._check(self._lib.dmi_color_process(self._h, _dp(pts), nv, mean.ctypes.data_as(u8), median.ctypes.data_as(u8),
+                                                count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return mean, median, count
+
+    def kernel_ms(self) -> float:
+        v = ctypes.c_double(0)
+        self._check(self._lib.dmi_color_get_kernel_ms(self._h, ctypes.byref(v)))
+        return float(v.value)
 
 
 def fuse_once(grid: GridDesc, ray: RayPotential, views: Views, *, threshold: float | None = None,

@@ -6,15 +6,21 @@
 // inside the image, fetch that pixel's RGB (GetColorValue, RD.cxx:92-116: row flip) and store per vertex the mean
 // (integer accumulation, MC.cxx:176-180), the median (Helper.h:174-187) and the number of views.
 //
-// Here: one lane per vertex.  Kernel 1 loops over the views (camera records through scalar loads), projects with
-// the reference's expression in fp64 (correctly rounded divisions: the pixel decides which colour is read),
-// accumulates count and integer sums and writes the fetched colour of every (view, vertex) pair to a scratch table
-// [view][vertex] (uchar4, alpha = valid).  Kernel 2 finds the median per channel by an 8-step radix selection over
-// that table (coalesced: consecutive lanes read consecutive entries).  Everything after the projection is integer
-// arithmetic, so the three outputs are bit-identical to the reference's.
+// Here: one lane per vertex, colour planes and camera records resident in HBM (dmi_color_context).  The planes are
+// repacked at upload to RGBA dwords, top image row first, so a vertex-view pair costs one dword gather.  Kernel 1
+// loops over the views (camera records through scalar loads), projects with the reference's expression in fp64
+// (correctly rounded divisions: the pixel decides which colour is read), accumulates count and integer sums and
+// writes the fetched colour of every (view, vertex) pair to a scratch table [view][vertex] (uchar4, alpha = valid).
+// Kernel 2 finds the medians by a bit-by-bit radix selection over that table: 8 coalesced passes, each serving the
+// three channels and both middle elements at once.  Vertices are processed in chunks that bound the scratch table.
+// Everything after the projection is integer arithmetic, so the three outputs are bit-identical to the reference's.
 #include "../../include/dmi.h"
 #include "fusion_kernels.h"
 
+#include <stdlib.h>
+
+#include <algorithm>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -23,14 +29,31 @@ namespace {
 struct ColorView {
   double rt[12];           // rows 0..2 of [R|T]
   double k[9];             // rows 0..2, columns 0..2 of the 4x4 K (TransformVector ignores column 3)
-  const uint8_t *color;    // [H][W][3], vtk row order (row 0 = bottom)
+  const uchar4 *color;     // [H][W] RGBA, TOP image row first (the reference's vtk order is flipped at upload)
 };
+
+template <typename T>
+__device__ __forceinline__ T cload(const T *p) {  // wave-uniform address -> scalar load
+  return *reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(p));
+}
 
 __device__ __forceinline__ bool to_pixel(double u, int &p) {  // round half away from zero; NaN/inf/|x| >= 2^31 outside
   const double r = round(u);
   if (!(r > -2147483648.0 && r < 2147483648.0)) return false;
   p = (int)r;
   return true;
+}
+
+// [n][H][W][3] in vtk point order (row 0 = bottom, RD.cxx:106-108) -> [n][H][W] RGBA, top row first
+__global__ __launch_bounds__(256) void pack_color_kernel(const uint8_t *__restrict__ rgb, uchar4 *__restrict__ rgba, int W,
+                                                         int H, int64_t n_pixels_total) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_pixels_total) return;
+  const int64_t npix = (int64_t)W * H;
+  const int64_t m = id / npix, r = id % npix;
+  const int y = (int)(r / W), x = (int)(r % W);
+  const uint8_t *c = rgb + (m * npix + (int64_t)(H - 1 - y) * W + x) * 3;
+  rgba[id] = make_uchar4(c[0], c[1], c[2], 255);
 }
 
 __global__ __launch_bounds__(256) void project_color_kernel(const double *__restrict__ points, int64_t nv,
@@ -42,25 +65,25 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
   const double x = points[3 * id], y = points[3 * id + 1], z = points[3 * id + 2];
   int cnt = 0, s0 = 0, s1 = 0, s2 = 0;
   for (int m = 0; m < n; ++m) {
-    const ColorView *__restrict__ v = views + m;  // wave-uniform
+    const ColorView *v = views + m;  // wave-uniform
     // vtkTransform::TransformPoint with MatrixTR (RD.cxx:173): M[i][0]*x + M[i][1]*y + M[i][2]*z + M[i][3], left to right
-    const double cx = ((v->rt[0] * x + v->rt[1] * y) + v->rt[2] * z) + v->rt[3];
-    const double cy = ((v->rt[4] * x + v->rt[5] * y) + v->rt[6] * z) + v->rt[7];
-    const double cz = ((v->rt[8] * x + v->rt[9] * y) + v->rt[10] * z) + v->rt[11];
+    const double cx = ((cload(&v->rt[0]) * x + cload(&v->rt[1]) * y) + cload(&v->rt[2]) * z) + cload(&v->rt[3]);
+    const double cy = ((cload(&v->rt[4]) * x + cload(&v->rt[5]) * y) + cload(&v->rt[6]) * z) + cload(&v->rt[7]);
+    const double cz = ((cload(&v->rt[8]) * x + cload(&v->rt[9]) * y) + cload(&v->rt[10]) * z) + cload(&v->rt[11]);
     // vtkTransform::TransformVector with Matrix4K (RD.cxx:175): no translation
-    const double dx = (v->k[0] * cx + v->k[1] * cy) + v->k[2] * cz;
-    const double dy = (v->k[3] * cx + v->k[4] * cy) + v->k[5] * cz;
-    const double dz = (v->k[6] * cx + v->k[7] * cy) + v->k[8] * cz;
+    const double dx = (cload(&v->k[0]) * cx + cload(&v->k[1]) * cy) + cload(&v->k[2]) * cz;
+    const double dy = (cload(&v->k[3]) * cx + cload(&v->k[4]) * cy) + cload(&v->k[5]) * cz;
+    const double dz = (cload(&v->k[6]) * cx + cload(&v->k[7]) * cy) + cload(&v->k[8]) * cz;
     uchar4 out = make_uchar4(0, 0, 0, 0);
     int px, py;
     if (to_pixel(dx / dz, px) && to_pixel(dy / dz, py) &&           // RD.cxx:177-181
         px >= 0 && py >= 0 && px < W && py < H) {                   // MC.cxx:158-163
-      const uint8_t *c = v->color + ((int64_t)(H - 1 - py) * W + px) * 3;  // RD.cxx:106-108
-      out = make_uchar4(c[0], c[1], c[2], 1);
+      const uchar4 c = cload(&v->color)[(int64_t)py * W + px];      // RD.cxx:106-108 (row flip done at upload)
+      out = make_uchar4(c.x, c.y, c.z, 1);
       cnt += 1;
-      s0 += c[0];  // std::accumulate(..., 0): integer running sums (MC.cxx:176-178)
-      s1 += c[1];
-      s2 += c[2];
+      s0 += c.x;  // std::accumulate(..., 0): integer running sums (MC.cxx:176-178)
+      s1 += c.y;
+      s2 += c.z;
     }
     scratch[(int64_t)m * nv + id] = out;
   }
@@ -71,46 +94,100 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
   mean[3 * id + 2] = cnt ? (uint8_t)(s2 / cnt) : 0;
 }
 
-// k-th smallest (0-based) of the valid entries of one channel, by radix selection from the top bit down
-__device__ __forceinline__ int select_kth(const uchar4 *__restrict__ scratch, int64_t nv, int64_t id, int n, int channel,
-                                          int k) {
-  int prefix = 0;
-  for (int bit = 7; bit >= 0; --bit) {
-    int zeros = 0;  // valid entries that match the prefix above `bit` and have a 0 at `bit`
-    for (int m = 0; m < n; ++m) {
-      const uchar4 e = scratch[(int64_t)m * nv + id];
-      const int val = channel == 0 ? e.x : (channel == 1 ? e.y : e.z);
-      zeros += (e.w != 0 && (val >> (bit + 1)) == prefix && ((val >> bit) & 1) == 0) ? 1 : 0;
-    }
-    if (k < zeros) {
-      prefix = prefix << 1;
-    } else {
-      k -= zeros;
-      prefix = (prefix << 1) | 1;
-    }
-  }
-  return prefix;
-}
-
+// Medians of the valid entries of the three channels (Helper.h:174-187: sorted[cnt/2], or the mean of sorted[cnt/2]
+// and sorted[cnt/2 - 1] for an even count).  Radix selection from the top bit down; one pass over the vertex's column
+// of the scratch table per bit serves all six (channel, middle element) selections.
 __global__ __launch_bounds__(256) void median_kernel(const uchar4 *__restrict__ scratch, int64_t nv, int n,
                                                      const int32_t *__restrict__ count, uint8_t *__restrict__ median) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nv) return;
   const int cnt = count[id];
+  int prefix[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  int k[3][2];
   for (int c = 0; c < 3; ++c) {
-    int med = 0;
-    if (cnt > 0) {
-      // Helper.h:174-187: sorted[n/2], or the mean of sorted[n/2] and sorted[n/2 - 1] for an even count;
-      // (a + b) / 2 in double, then static_cast<unsigned char> (MC.cxx:185): the integer (a + b) >> 1
-      const int hi = select_kth(scratch, nv, id, n, c, cnt / 2);
-      med = hi;
-      if ((cnt & 1) == 0) med = (hi + select_kth(scratch, nv, id, n, c, cnt / 2 - 1)) >> 1;
-    }
-    median[3 * id + c] = (uint8_t)med;
+    k[c][0] = cnt / 2;                                // 0-based rank of the upper middle element
+    k[c][1] = (cnt & 1) == 0 ? cnt / 2 - 1 : cnt / 2;  // the lower one (the same element for an odd count)
   }
+  if (cnt > 0) {
+    for (int bit = 7; bit >= 0; --bit) {
+      int zeros[3][2] = {{0, 0}, {0, 0}, {0, 0}};  // valid entries matching the prefix above `bit` with a 0 at `bit`
+      for (int m = 0; m < n; ++m) {
+        const uchar4 e = scratch[(int64_t)m * nv + id];
+        const int val[3] = {e.x, e.y, e.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int high = val[c] >> (bit + 1), is_zero = ((val[c] >> bit) & 1) == 0;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) zeros[c][t] += (e.w != 0 && high == prefix[c][t] && is_zero) ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (k[c][t] < zeros[c][t]) {
+            prefix[c][t] = prefix[c][t] << 1;
+          } else {
+            k[c][t] -= zeros[c][t];
+            prefix[c][t] = (prefix[c][t] << 1) | 1;
+          }
+        }
+    }
+  }
+  // (a + b) / 2 in double, then static_cast<unsigned char> (MC.cxx:185): the integer (a + b) >> 1; a == b for odd counts
+  for (int c = 0; c < 3; ++c) median[3 * id + c] = cnt > 0 ? (uint8_t)((prefix[c][0] + prefix[c][1]) >> 1) : 0;
 }
 
 thread_local std::string g_color_error;
+
+struct ColorBatch {
+  uchar4 *d_rgba = nullptr;
+  int32_t n = 0;
+};
+
+}  // namespace
+
+struct dmi_color_context {
+  int32_t device = 0;
+  hipStream_t stream = nullptr;
+  int32_t W = 0, H = 0;
+  std::vector<ColorBatch> batches;
+  std::vector<ColorView> h_views;
+  ColorView *d_views = nullptr;
+  size_t d_views_capacity = 0;
+  bool views_dirty = false;
+  // per-chunk work buffers, grown on demand
+  double *d_points = nullptr;
+  uchar4 *d_scratch = nullptr;
+  uint8_t *d_mean = nullptr, *d_median = nullptr;
+  int32_t *d_count = nullptr;
+  size_t chunk_capacity = 0, scratch_capacity = 0;
+  uint8_t *d_stage = nullptr;
+  size_t stage_capacity = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_kernel_ms = 0.0;
+  std::string err;
+};
+
+namespace {
+
+int cfail(dmi_color_context *c, int code, const std::string &msg) {
+  g_color_error = msg;
+  if (c) c->err = msg;
+  return code;
+}
+
+#define DMI_COLOR_HIP(c, call)                                                                               \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      (void)hipGetLastError();                                                                               \
+      return cfail(c, e_ == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_DEVICE,                    \
+                   std::string(#call) + ": " + hipGetErrorString(e_));                                       \
+    }                                                                                                        \
+  } while (0)
+
+constexpr size_t kScratchBudget = size_t(1) << 30;  // bytes of [view][vertex] scratch per chunk
 
 }  // namespace
 
@@ -118,78 +195,202 @@ extern "C" {
 
 const char *dmi_color_last_error(void) { return g_color_error.c_str(); }
 
-int dmi_color_mesh(const double *points, int64_t n_points, const uint8_t *colors, const double *K4, const double *RT4,
-                   int32_t n_views, int32_t width, int32_t height, int32_t device, uint8_t *mean, uint8_t *median,
-                   int32_t *count) {
-  if (!points || !colors || !K4 || !RT4 || !mean || !median || !count) {
-    g_color_error = "dmi_color_mesh: null argument";
-    return DMI_ERR_INVALID_ARGUMENT;
-  }
-  if (n_points < 0 || n_views < 1 || width < 1 || height < 1) {
-    g_color_error = "dmi_color_mesh: n_points >= 0, n_views >= 1, width >= 1, height >= 1 required";  // MC.cxx:102-106
-    return DMI_ERR_INVALID_ARGUMENT;
-  }
-  if (n_points == 0) return DMI_OK;
-  void *d_points = nullptr, *d_colors = nullptr, *d_views = nullptr, *d_scratch = nullptr, *d_mean = nullptr,
-       *d_median = nullptr, *d_count = nullptr;
-  hipStream_t stream = nullptr;
-  auto cleanup = [&]() {
-    for (void *p : {d_points, d_colors, d_views, d_scratch, d_mean, d_median, d_count})
-      if (p) (void)hipFree(p);
-    if (stream) (void)hipStreamDestroy(stream);
-  };
-  auto check = [&](hipError_t e, const char *what) {
-    if (e == hipSuccess) return true;
-    (void)hipGetLastError();
-    g_color_error = std::string("dmi_color_mesh: ") + what + ": " + hipGetErrorString(e);
-    cleanup();
-    return false;
-  };
+int dmi_color_create(int32_t device, dmi_color_context **out) {
+  if (!out) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_create: null argument");
+  *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
-    g_color_error = "dmi_color_mesh: no HIP device available";
-    return DMI_ERR_DEVICE;
+    return cfail(nullptr, DMI_ERR_DEVICE, "dmi_color_create: no HIP device available");
   }
-  if (device < 0 || device >= ndev) {
-    g_color_error = "dmi_color_mesh: device ordinal out of range";
-    return DMI_ERR_INVALID_ARGUMENT;
+  if (device < 0 || device >= ndev) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_create: device ordinal out of range");
+  dmi_color_context *c = new (std::nothrow) dmi_color_context();
+  if (!c) return cfail(nullptr, DMI_ERR_OUT_OF_MEMORY, "dmi_color_create: host allocation failed");
+  c->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    const std::string msg = std::string("dmi_color_create: ") + hipGetErrorString(e);
+    dmi_color_destroy(c);
+    return cfail(nullptr, DMI_ERR_DEVICE, msg);
   }
-  if (!check(hipSetDevice(device), "hipSetDevice")) return DMI_ERR_DEVICE;
-  if (!check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate")) return DMI_ERR_DEVICE;
-  const size_t npix = (size_t)width * height;
-  const size_t color_bytes = npix * 3 * (size_t)n_views;
-  if (!check(hipMalloc(&d_points, (size_t)n_points * 24), "hipMalloc(points)")) return DMI_ERR_OUT_OF_MEMORY;
-  if (!check(hipMalloc(&d_colors, color_bytes), "hipMalloc(colors)")) return DMI_ERR_OUT_OF_MEMORY;
-  if (!check(hipMalloc(&d_views, sizeof(ColorView) * (size_t)n_views), "hipMalloc(views)")) return DMI_ERR_OUT_OF_MEMORY;
-  if (!check(hipMalloc(&d_scratch, (size_t)n_points * (size_t)n_views * 4), "hipMalloc(scratch)")) return DMI_ERR_OUT_OF_MEMORY;
-  if (!check(hipMalloc(&d_mean, (size_t)n_points * 3), "hipMalloc(mean)")) return DMI_ERR_OUT_OF_MEMORY;
-  if (!check(hipMalloc(&d_median, (size_t)n_points * 3), "hipMalloc(median)")) return DMI_ERR_OUT_OF_MEMORY;
-  if (!check(hipMalloc(&d_count, (size_t)n_points * 4), "hipMalloc(count)")) return DMI_ERR_OUT_OF_MEMORY;
-  std::vector<ColorView> views((size_t)n_views);
-  for (int m = 0; m < n_views; ++m) {
-    for (int i = 0; i < 12; ++i) views[m].rt[i] = RT4[16 * (size_t)m + i];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) views[m].k[3 * r + c] = K4[16 * (size_t)m + 4 * r + c];
-    views[m].color = static_cast<const uint8_t *>(d_colors) + (size_t)m * npix * 3;
-  }
-  if (!check(hipMemcpyAsync(d_points, points, (size_t)n_points * 24, hipMemcpyHostToDevice, stream), "copy points")) return DMI_ERR_DEVICE;
-  if (!check(hipMemcpyAsync(d_colors, colors, color_bytes, hipMemcpyHostToDevice, stream), "copy colors")) return DMI_ERR_DEVICE;
-  if (!check(hipMemcpyAsync(d_views, views.data(), sizeof(ColorView) * (size_t)n_views, hipMemcpyHostToDevice, stream), "copy views")) return DMI_ERR_DEVICE;
-  const unsigned blocks = (unsigned)((n_points + 255) / 256);
-  hipLaunchKernelGGL(project_color_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const double *>(d_points),
-                     n_points, static_cast<const ColorView *>(d_views), n_views, width, height,
-                     static_cast<uchar4 *>(d_scratch), static_cast<uint8_t *>(d_mean), static_cast<int32_t *>(d_count));
-  if (!check(hipGetLastError(), "project_color_kernel")) return DMI_ERR_DEVICE;
-  hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const uchar4 *>(d_scratch), n_points,
-                     n_views, static_cast<const int32_t *>(d_count), static_cast<uint8_t *>(d_median));
-  if (!check(hipGetLastError(), "median_kernel")) return DMI_ERR_DEVICE;
-  if (!check(hipMemcpyAsync(mean, d_mean, (size_t)n_points * 3, hipMemcpyDeviceToHost, stream), "copy mean")) return DMI_ERR_DEVICE;
-  if (!check(hipMemcpyAsync(median, d_median, (size_t)n_points * 3, hipMemcpyDeviceToHost, stream), "copy median")) return DMI_ERR_DEVICE;
-  if (!check(hipMemcpyAsync(count, d_count, (size_t)n_points * 4, hipMemcpyDeviceToHost, stream), "copy count")) return DMI_ERR_DEVICE;
-  if (!check(hipStreamSynchronize(stream), "synchronize")) return DMI_ERR_DEVICE;
-  cleanup();
+  *out = c;
   return DMI_OK;
+}
+
+void dmi_color_destroy(dmi_color_context *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (ColorBatch &b : c->batches) (void)hipFree(b.d_rgba);
+  for (void *p : {(void *)c->d_views, (void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median,
+                  (void *)c->d_count, (void *)c->d_stage})
+    if (p) (void)hipFree(p);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const double *K4, const double *RT4, int32_t n,
+                        int32_t width, int32_t height) {
+  if (!c) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_add_views: null context");
+  if (!colors || !K4 || !RT4) return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_add_views: null argument");
+  if (n < 1 || width < 1 || height < 1 || width > 32768 || height > 32768)
+    return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_add_views: n >= 1 and image dimensions in [1, 32768] required");
+  if (!c->batches.empty() && (width != c->W || height != c->H))
+    return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_add_views: every view must have the size of view 0 (MC.cxx:111)");
+  DMI_COLOR_HIP(c, hipSetDevice(c->device));
+  c->W = width;
+  c->H = height;
+  const size_t npix = (size_t)width * height;
+  ColorBatch b;
+  b.n = n;
+  DMI_COLOR_HIP(c, hipMalloc(&b.d_rgba, npix * (size_t)n * sizeof(uchar4)));
+  // stage <= 256 MiB of RGB at a time, repack on the device
+  const size_t per_chunk = std::max<size_t>(1, (size_t(256) << 20) / (npix * 3));
+  const size_t chunk = std::min<size_t>(per_chunk, (size_t)n);
+  if (c->stage_capacity < chunk * npix * 3) {
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_capacity = 0;
+    hipError_t e = hipMalloc(&c->d_stage, chunk * npix * 3);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(b.d_rgba);
+      return cfail(c, DMI_ERR_OUT_OF_MEMORY, std::string("hipMalloc(stage): ") + hipGetErrorString(e));
+    }
+    c->stage_capacity = chunk * npix * 3;
+  }
+  for (size_t m0 = 0; m0 < (size_t)n; m0 += chunk) {
+    const size_t cnt = std::min(chunk, (size_t)n - m0);
+    hipError_t e = hipMemcpyAsync(c->d_stage, colors + m0 * npix * 3, cnt * npix * 3, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      const int64_t total = (int64_t)(cnt * npix);
+      hipLaunchKernelGGL(pack_color_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_stage,
+                         b.d_rgba + m0 * npix, width, height, total);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the stage buffer is reused by the next chunk
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(b.d_rgba);
+      return cfail(c, DMI_ERR_DEVICE, std::string("colour upload: ") + hipGetErrorString(e));
+    }
+  }
+  c->batches.push_back(b);
+  for (int32_t m = 0; m < n; ++m) {
+    ColorView v;
+    for (int i = 0; i < 12; ++i) v.rt[i] = RT4[16 * (size_t)m + i];
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 3; ++q) v.k[3 * r + q] = K4[16 * (size_t)m + 4 * r + q];
+    v.color = b.d_rgba + (size_t)m * npix;
+    c->h_views.push_back(v);
+  }
+  c->views_dirty = true;
+  return DMI_OK;
+}
+
+int dmi_color_clear_views(dmi_color_context *c) {
+  if (!c) return DMI_ERR_INVALID_ARGUMENT;
+  DMI_COLOR_HIP(c, hipSetDevice(c->device));
+  DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
+  for (ColorBatch &b : c->batches) (void)hipFree(b.d_rgba);
+  c->batches.clear();
+  c->h_views.clear();
+  c->views_dirty = true;
+  c->W = c->H = 0;
+  return DMI_OK;
+}
+
+int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_points, uint8_t *mean, uint8_t *median,
+                      int32_t *count) {
+  if (!c) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_process: null context");
+  if (n_points < 0 || (n_points > 0 && (!points || !mean || !median || !count)))
+    return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_process: null argument");
+  const size_t n_views = c->h_views.size();
+  if (n_views == 0) return cfail(c, DMI_ERR_STATE, "dmi_color_process: no views resident (MC.cxx:102-106)");
+  c->last_kernel_ms = 0.0;
+  if (n_points == 0) return DMI_OK;
+  DMI_COLOR_HIP(c, hipSetDevice(c->device));
+  if (c->d_views_capacity < n_views) {
+    if (c->d_views) (void)hipFree(c->d_views);
+    c->d_views = nullptr;
+    c->d_views_capacity = 0;
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_views, n_views * sizeof(ColorView)));
+    c->d_views_capacity = n_views;
+    c->views_dirty = true;
+  }
+  if (c->views_dirty) {
+    DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_views, c->h_views.data(), n_views * sizeof(ColorView), hipMemcpyHostToDevice, c->stream));
+    DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
+    c->views_dirty = false;
+  }
+  // vertices per chunk: the scratch table [view][vertex] stays within its budget
+  size_t budget = kScratchBudget;
+  if (const char *e = getenv("DMI_COLOR_SCRATCH_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);  // tests: force chunking
+  size_t chunk = std::max<size_t>(256, budget / (n_views * sizeof(uchar4)) / 256 * 256);
+  chunk = std::min<size_t>(chunk, ((size_t)n_points + 255) / 256 * 256);
+  if (c->chunk_capacity < chunk || c->scratch_capacity < chunk * n_views) {
+    for (void *p : {(void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median, (void *)c->d_count})
+      if (p) (void)hipFree(p);
+    c->d_points = nullptr; c->d_scratch = nullptr; c->d_mean = nullptr; c->d_median = nullptr; c->d_count = nullptr;
+    c->chunk_capacity = c->scratch_capacity = 0;
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_points, chunk * 24));
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_scratch, chunk * n_views * sizeof(uchar4)));
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_mean, chunk * 3));
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_median, chunk * 3));
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_count, chunk * 4));
+    c->chunk_capacity = chunk;
+    c->scratch_capacity = chunk * n_views;
+  }
+  for (int64_t v0 = 0; v0 < n_points; v0 += (int64_t)chunk) {
+    const int64_t nv = std::min<int64_t>((int64_t)chunk, n_points - v0);
+    const unsigned blocks = (unsigned)((nv + 255) / 256);
+    DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_points, points + 3 * v0, (size_t)nv * 24, hipMemcpyHostToDevice, c->stream));
+    DMI_COLOR_HIP(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(project_color_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, c->d_views, (int)n_views,
+                       c->W, c->H, c->d_scratch, c->d_mean, c->d_count);
+    DMI_COLOR_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, c->d_count,
+                       c->d_median);
+    DMI_COLOR_HIP(c, hipGetLastError());
+    DMI_COLOR_HIP(c, hipEventRecord(c->ev1, c->stream));
+    DMI_COLOR_HIP(c, hipMemcpyAsync(mean + 3 * v0, c->d_mean, (size_t)nv * 3, hipMemcpyDeviceToHost, c->stream));
+    DMI_COLOR_HIP(c, hipMemcpyAsync(median + 3 * v0, c->d_median, (size_t)nv * 3, hipMemcpyDeviceToHost, c->stream));
+    DMI_COLOR_HIP(c, hipMemcpyAsync(count + v0, c->d_count, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+    DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    DMI_COLOR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_kernel_ms += ms;
+  }
+  return DMI_OK;
+}
+
+int dmi_color_get_kernel_ms(dmi_color_context *c, double *out) {
+  if (!c || !out) return DMI_ERR_INVALID_ARGUMENT;
+  *out = c->last_kernel_ms;
+  return DMI_OK;
+}
+
+int dmi_color_mesh(const double *points, int64_t n_points, const uint8_t *colors, const double *K4, const double *RT4,
+                   int32_t n_views, int32_t width, int32_t height, int32_t device, uint8_t *mean, uint8_t *median,
+                   int32_t *count) {
+  if (!points || !colors || !K4 || !RT4 || !mean || !median || !count)
+    return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_mesh: null argument");
+  if (n_points < 0 || n_views < 1 || width < 1 || height < 1)  // MC.cxx:102-106
+    return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_mesh: n_points >= 0, n_views >= 1, width >= 1, height >= 1 required");
+  if (n_points == 0) return DMI_OK;
+  dmi_color_context *c = nullptr;
+  int rc = dmi_color_create(device, &c);
+  if (rc != DMI_OK) return rc;
+  rc = dmi_color_add_views(c, colors, K4, RT4, n_views, width, height);
+  if (rc == DMI_OK) rc = dmi_color_process(c, points, n_points, mean, median, count);
+  dmi_color_destroy(c);  // g_color_error keeps the message
+  return rc;
 }
 
 }  // extern "C"

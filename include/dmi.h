@@ -220,6 +220,21 @@ int dmi_color_mesh(const double *points, int64_t n_points, const uint8_t *colors
                    int32_t *count);
 const char *dmi_color_last_error(void);
 
+/* The same pass with the colour planes and camera records RESIDENT in HBM: upload the views once, colour any number
+ * of vertex sets (BASELINE config 5: the mesh is sharded by vertex across the GPUs, every GPU holds all views, no
+ * exchange step).  dmi_color_process works through the vertices in chunks that bound its scratch memory (1 GiB). */
+typedef struct dmi_color_context dmi_color_context;
+int dmi_color_create(int32_t device, dmi_color_context **out);
+void dmi_color_destroy(dmi_color_context *ctx);
+/* appends n views: colors [n][H][W][3] u8 in vtk point order, K4 / RT4 [n][16] row-major */
+int dmi_color_add_views(dmi_color_context *ctx, const uint8_t *colors, const double *K4, const double *RT4, int32_t n,
+                        int32_t width, int32_t height);
+int dmi_color_clear_views(dmi_color_context *ctx);
+int dmi_color_process(dmi_color_context *ctx, const double *points, int64_t n_points, uint8_t *mean, uint8_t *median,
+                      int32_t *count);
+/* hipEvent time of the kernels (projection + median) of the last dmi_color_process, summed over its chunks */
+int dmi_color_get_kernel_ms(dmi_color_context *ctx, double *out);
+
 int dmi_abi_version(void);
 int dmi_device_count(void);
 

@@ -94,3 +94,37 @@ def test_gpu_mesh_coloration_from_list_files(tmp_path):
 def test_mesh_coloration_from_lists_reports_missing_files(tmp_path):
     with pytest.raises(RuntimeError):
         capi.mesh_coloration_from_lists(np.zeros((3, 3)), str(tmp_path / "a.txt"), str(tmp_path / "b.txt"))
+
+
+@pytest.mark.gpu
+def test_gpu_color_context_resident_views_chunks_and_batches(monkeypatch):
+    """dmi_color_context: views added in two batches stay resident, several vertex sets are coloured against them,
+    and a small scratch budget forces the chunked path -- all bit-identical to the oracle."""
+    K4, RT4, colors = _views(9, 80, 60, seed=31)
+    pts = scene.make_mesh_points(7000, seed=32)
+    want = oracle.color_mesh(pts, colors, K4, RT4)
+    with capi.ColorContext() as c:
+        with pytest.raises(capi.DmiError):
+            c.process(pts[:10])                      # no views yet (MC.cxx:102-106)
+        c.add_views(colors[:4], K4[:4], RT4[:4])
+        c.add_views(colors[4:], K4[4:], RT4[4:])
+        got = c.process(pts)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        assert c.kernel_ms() > 0
+        monkeypatch.setenv("DMI_COLOR_SCRATCH_BYTES", str(9 * 4 * 1024))   # 1024 vertices per chunk -> 7 chunks
+        got = c.process(pts)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        monkeypatch.delenv("DMI_COLOR_SCRATCH_BYTES")
+        sub = c.process(pts[100:1100])               # another vertex set, same resident views
+        for g, w in zip(sub, want):
+            assert np.array_equal(g, w[100:1100])
+        c.clear_views()
+        c.add_views(colors[:2], K4[:2], RT4[:2])
+        got2 = c.process(pts[:500])
+        want2 = oracle.color_mesh(pts[:500], colors[:2], K4[:2], RT4[:2])
+        for g, w in zip(got2, want2):
+            assert np.array_equal(g, w)
+        with pytest.raises(capi.DmiError):
+            c.add_views(colors[:1, :10], K4[:1], RT4[:1])   # a view of another size (MC.cxx:111 reads view 0's)
