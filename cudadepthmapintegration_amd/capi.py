@@ -22,6 +22,7 @@ VARIANT_EXACT_DIVISION = 1  # disable the checked-reciprocal fast path
 VARIANT_GENERAL_K = 2  # ignore K structure, evaluate the full 4x4 rows
 VARIANT_FORCE_GENERAL = 16  # never use the register-tiled kernel
 VARIANT_NO_BRICK_CLASSES = 256  # tiled kernel without the proven per-brick shortcuts
+VARIANT_KEEP_BEHIND_ADDS = 1024  # tiled kernel: perform +0.0 adds even when they cannot change a sum
 VARIANT_SPATIAL_ORDER = 512  # tiled kernel: workgroups in spatial order instead of heaviest bricks first
 VARIANT_TILE_SHAPE = {"tk16_w5": 0, "tk16_w6": 32, "tk16_w8": 64, "tk8_w6": 96, "tk8_w6_g2": 128, "tk16_w8_g2": 160,
                       "tk16_w6_g2": 192, "tk8_w7": 224}  # tiled kernel: column height / compiler register budget / group

@@ -805,6 +805,9 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
         t.xcd_run_wg = 32;
       }
     }
+    // +0.0 adds are no-ops unless a sum can be -0.0 (only an uploaded grid can bring one) or hits are counted
+    if (!a.init_from_grid && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS))
+      t.behind_mask = 0x0101010101010101ull;
     if (const char *e = std::getenv("DMI_XCD_RUN_WG")) t.xcd_run_wg = std::max(1, std::atoi(e));  // tuning experiments
     if (!ctx->d_fuse_args) DMI_HIP(ctx, hipMalloc(&ctx->d_fuse_args, sizeof(FuseArgs)));
     // pageable source: the copy has left the host buffer when the call returns

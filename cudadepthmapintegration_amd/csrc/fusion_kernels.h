@@ -114,6 +114,9 @@ struct TileArgs {
   // workgroup order (fusion_classify.hip): slot of the p-th workgroup, heaviest bricks first; nullptr = spatial order
   const int32_t *order;
   const int32_t *n_order;                // number of entries of `order` (device)
+  // 0x0101010101010101 when adding +0.0 cannot change any running sum (the grid starts at +0.0 and there are no hit
+  // counters): BRICK_BEHIND is then treated as BRICK_SKIP; 0 otherwise
+  unsigned long long behind_mask;
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
@@ -143,7 +146,8 @@ enum VariantBits : int {
   VAR_TILE_SHAPE_MASK = 0xE0,  // tiled kernel: bits 5..7 pick column height / workgroup shape
   VAR_TILE_SHAPE_SHIFT = 5,
   VAR_NO_BRICK_CLASSES = 256,  // tiled kernel: every (brick, map) pair takes the per-voxel path
-  VAR_SPATIAL_ORDER = 512      // tiled kernel: workgroups in spatial order, not heaviest bricks first
+  VAR_SPATIAL_ORDER = 512,     // tiled kernel: workgroups in spatial order, not heaviest bricks first
+  VAR_KEEP_BEHIND_ADDS = 1024  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

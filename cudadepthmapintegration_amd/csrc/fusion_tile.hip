@@ -231,7 +231,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   if (crow) cnext = cload(crow + (a.first_map >> 3));
   for (int m = a.first_map; m < m_end; ++m) {
     if (crow && ((m & 7) == 0 || m == a.first_map)) {
-      cword = cnext;  // fetched one block ahead: its latency hides behind the previous eight maps
+      // fetched one block ahead: its latency hides behind the previous eight maps.  behind_mask turns BEHIND (2) into
+      // SKIP (3) when x + 0.0 == x for every running sum: sums that start at +0.0 never become -0.0
+      cword = cnext | ((cnext >> 1) & a.behind_mask);
       if ((((m >> 3) + 1) << 3) < m_end) cnext = cload(crow + (m >> 3) + 1);
     }
     if (cword == 0x0303030303030303ull) {  // none of this block's eight maps touches the brick

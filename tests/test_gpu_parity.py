@@ -41,6 +41,43 @@ def test_golden_bit_exact_f64(golden, variant):
     assert bits_equal(out, golden["expected_grid"])
 
 
+@pytest.mark.parametrize("variant", [0, capi.VARIANT_KEEP_BEHIND_ADDS, 96, NC])
+def test_golden_bit_exact_without_hit_counters(golden, variant):
+    """Without hit counters and from a zero grid the kernel skips the +0.0 adds of bricks proven to lie behind every
+    surface (a sum that starts at +0.0 is never -0.0, so x + 0.0 == x): same bits, including the sign of zeros.  With
+    an uploaded grid (which may hold -0.0) the adds are kept."""
+    grid, rp, views, thr = _golden_inputs(golden)
+    out, _, _ = capi.fuse_once(grid, rp, views, threshold=thr, init_grid=golden.get("init_grid"), count_hits=False,
+                               kernel_variant=variant)
+    assert bits_equal(out, golden["expected_grid"])
+
+
+def test_behind_bricks_keep_minus_zero_semantics():
+    """A grid uploaded as -0.0 everywhere: voxels that only ever receive `+ 0` (far behind every surface, cu:115) must
+    come out as +0.0, untouched voxels stay -0.0 -- whether or not hits are counted."""
+    grid = scene.default_grid((64, 64, 64))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(3, 160, 120, seed=5, dense=False)   # sparse: many voxels see no depth in any view
+    init = np.full((64, 64, 64), -0.0)
+    p = oracle_params_from_scene(grid, rp, views)
+    want, _, _ = oracle.fuse(p, views.depth, views.K4, views.RT4, init_grid=init, n_threads=oracle.max_threads())
+    assert np.signbit(want[want == 0]).any() and (~np.signbit(want[want == 0])).any()
+    for count_hits in (False, True):
+        for variant in (0, capi.VARIANT_KEEP_BEHIND_ADDS):
+            out, _, _ = capi.fuse_once(grid, rp, views, init_grid=init, count_hits=count_hits, kernel_variant=variant)
+            assert bits_equal(out, want)
+    # zero grid, no counters: the skip is active; a second fuse accumulates onto the first (grid no longer known zero)
+    with capi.FusionContext(grid, rp) as ctx:
+        ctx.add_views(views)
+        ctx.fuse()
+        ctx.fuse()
+        twice = ctx.download_grid()
+    want2, _, _ = oracle.fuse(p, views.depth, views.K4, views.RT4,
+                              init_grid=oracle.fuse(p, views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0],
+                              n_threads=oracle.max_threads())
+    assert bits_equal(twice, want2)
+
+
 @pytest.mark.parametrize("storage", ["auto", "f64"])
 def test_golden_depth_storage_modes(golden, storage):
     grid, rp, views, thr = _golden_inputs(golden)
