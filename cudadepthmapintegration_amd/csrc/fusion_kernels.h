@@ -147,6 +147,7 @@ enum VariantBits : int {
   VAR_TILE_SHAPE_SHIFT = 5,
   VAR_NO_BRICK_CLASSES = 256,  // tiled kernel: every (brick, map) pair takes the per-voxel path
   VAR_SPATIAL_ORDER = 512,     // tiled kernel: workgroups in spatial order, not heaviest bricks first
+  VAR_FIXED_TILE_SHAPE = 4096,  // tiled kernel: tile-shape bits 0 mean shape 0 whatever the grid size (no automatic choice)
   VAR_KEEP_BEHIND_ADDS = 1024  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
 };
 

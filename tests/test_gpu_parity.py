@@ -17,10 +17,11 @@ NC = capi.VARIANT_NO_BRICK_CLASSES
 # 0 = default: the register-tiled kernel with brick classes when its preconditions hold, else the general
 # kernel; NC = tiled kernel, every pair on the per-voxel path; 32..224 = other tile shapes; G | x = the general
 # kernel with its own switches
-VARIANTS = [0, NC, capi.VARIANT_SPATIAL_ORDER, 32, 64, 96 | NC, 128, 160 | NC, 192, 224, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
+FX = capi.VARIANT_FIXED_TILE_SHAPE   # shape 0 (16-voxel columns) also on the small grids of these tests
+VARIANTS = [0, FX, FX | NC, NC, capi.VARIANT_SPATIAL_ORDER, 32, 64, 96 | NC, 128, 160 | NC, 192, 224, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
             G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K, G | 4, G | 8, G | 12]
 SO = capi.VARIANT_SPATIAL_ORDER
-TILE_SHAPES = [0, NC, SO, 32, 64 | NC, 96, 96 | SO, 128, 160, 192 | NC, 224]
+TILE_SHAPES = [0, FX, FX | NC, NC, SO, FX | SO, 32, 64 | NC, 96, 96 | SO, 128, 160, 192 | NC, 224]
 
 
 def _golden_inputs(g):
@@ -41,7 +42,7 @@ def test_golden_bit_exact_f64(golden, variant):
     assert bits_equal(out, golden["expected_grid"])
 
 
-@pytest.mark.parametrize("variant", [0, capi.VARIANT_KEEP_BEHIND_ADDS, 96, NC])
+@pytest.mark.parametrize("variant", [0, FX, FX | capi.VARIANT_KEEP_BEHIND_ADDS, 96, NC])
 def test_golden_bit_exact_without_hit_counters(golden, variant):
     """Without hit counters and from a zero grid the kernel skips the +0.0 adds of bricks proven to lie behind every
     surface (a sum that starts at +0.0 is never -0.0, so x + 0.0 == x): same bits, including the sign of zeros.  With
@@ -349,7 +350,7 @@ def test_brick_classes_cover_every_case_and_change_nothing():
                         np.concatenate([views.RT4, sparse.RT4]))
     want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                    n_threads=oracle.max_threads())
-    for variant in (0, 96, NC, G):
+    for variant in (FX, 0, 96, NC, G):   # FX: 16-voxel columns; 0 picks 8-voxel columns on a grid this small
         with capi.FusionContext(grid, rp, count_hits=True, kernel_variant=variant) as ctx:
             ctx.add_views(views)
             ctx.fuse()
@@ -358,9 +359,9 @@ def test_brick_classes_cover_every_case_and_change_nothing():
             hist = ctx.brick_class_histogram()
         assert bits_equal(out, want), variant
         assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w), variant
-        if variant in (0, 96):
+        if variant in (FX, 0, 96):
             assert all(hist[k] > 0 for k in ("mixed", "free", "behind", "skip")), hist
-            assert sum(hist.values()) == 8 * 7 * (48 // (16 if variant == 0 else 8)) * views.n
+            assert sum(hist.values()) == 8 * 7 * (48 // (16 if variant == FX else 8)) * views.n
         else:
             assert sum(hist.values()) == 0
 

@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--count", type=int, default=1000)
     ap.add_argument("--seconds", type=float, default=420.0, help="stop starting new cases after this long")
     args = ap.parse_args()
-    variants = [(0, True), (0, False), (capi.VARIANT_NO_BRICK_CLASSES, True), (96, True), (capi.VARIANT_FORCE_GENERAL, True)]
+    fx = capi.VARIANT_FIXED_TILE_SHAPE
+    variants = [(0, True), (0, False), (fx, True), (fx, False), (fx | capi.VARIANT_NO_BRICK_CLASSES, True), (96, True),
+                (capi.VARIANT_FORCE_GENERAL, True)]
     t0 = time.time()
     done = 0
     voxel_projections = 0
