@@ -712,12 +712,13 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   cfg.variant = ctx->opt.kernel_variant;
 
   cfg.use_tile = tile_eligible(ctx) ? 1 : 0;
-  // Tile shape when the caller did not pick one: grids below 512^3 do better with 8-voxel columns at five waves per
-  // SIMD (more, smaller work items: 0.65 vs 0.71 ms at 256^3 x 64 views, 4.39 vs 4.57 ms at 448^3 x 128), the large
-  // ones with 16-voxel columns (11.6 vs 12.0 ms at 512^3 x 256, 15.8 vs 19.5 ms at 1024^3 x 64); profiles/r01zc-ze_*
+  // Tile shape when the caller did not pick one: grids up to 512^3 do better with 8-voxel columns at five waves per
+  // SIMD (more, smaller work items and a finer brick classification: 0.65 vs 0.74 ms at 256^3 x 64 views, 11.2 vs 11.5
+  // ms at 512^3 x 256), 1024^3 with 16-voxel columns (15.5 vs 17.7 ms at 1024^3 x 64: the classification of twice as
+  // many bricks costs more than it saves); profiles/r01zc_*, r01zd_*, r01zi_*
   if (cfg.use_tile && !ctx->depth_f64 && !(cfg.variant & (dmi::VAR_TILE_SHAPE_MASK | dmi::VAR_FIXED_TILE_SHAPE))) {
     const int64_t bricks16 = (int64_t)((a.nx + 15) / 16) * ((a.ny + 15) / 16) * ((a.nz + 15) / 16);
-    if (bricks16 <= 24576) cfg.variant |= 7 << dmi::VAR_TILE_SHAPE_SHIFT;
+    if (bricks16 <= 32768) cfg.variant |= 7 << dmi::VAR_TILE_SHAPE_SHIFT;
   }
 
   TileArgs t;

@@ -138,23 +138,40 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   const int brick = (bz * a.wbricks_y + by) * a.wbricks_x + bx;  // row of the class table (whole grid)
   const MapRec *__restrict__ mr = maps + m;
 
-  double czmin = __builtin_inf(), czmax = -__builtin_inf();
-  double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
-  bool bad = false;
-  for (int c = 0; c < 8; ++c) {
-    // the brick's full extents, also where it sticks out of the grid: a superset is conservative
-    const int i = bx * 8 + ((c & 1) ? 7 : 0), j = by * 8 + ((c & 2) ? 7 : 0), k = bz * tk + ((c & 4) ? tk - 1 : 0);
+  // World coordinates of the brick's faces (cu:78-83 + cu:168).  With the axis-aligned grid the tiled kernel requires,
+  // wx depends on i only, wy on j, wz on k (fusion_tile.hip), so the eight corners share six values.  The brick's full
+  // extents are used also where it sticks out of the grid: a superset is conservative.
+  const TileMapRec *__restrict__ tr = a.tile_maps + m;
+  double wxs[2], wys[2], wzs[2];
+  for (int c = 0; c < 2; ++c) {
+    const int i = bx * 8 + (c ? 7 : 0), j = by * 8 + (c ? 7 : 0), k = bz * tk + (c ? tk - 1 : 0);
     const double gx = a.ox + (i + 0.5) * a.sx;  // cu:80-82
     const double gy = a.oy + (j + 0.5) * a.sy;
     const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
-    const double wx = row4(a.g + 0, gx, gy, gz);  // cu:168
-    const double wy = row4(a.g + 4, gx, gy, gz);
-    const double wz = row4(a.g + 8, gx, gy, gz);
-    const double cx = row4(mr->rt + 0, wx, wy, wz);  // cu:172
-    const double cy = row4(mr->rt + 4, wx, wy, wz);
-    const double cz = row4(mr->rt + 8, wx, wy, wz);  // exactly the value the fusion kernel computes
-    const double hx = row4(mr->k + 0, cx, cy, cz);   // cu:176
-    const double hy = row4(mr->k + 4, cx, cy, cz);
+    wxs[c] = row4(a.g + 0, gx, gy, gz);
+    wys[c] = row4(a.g + 4, gx, gy, gz);
+    wzs[c] = row4(a.g + 8, gx, gy, gz);
+  }
+  // c.z at the corners in the reference's order ((r20*wx + r21*wy) + r22*wz) + r23 (cu:92, cu:172): exactly the values
+  // the fusion kernel computes there.  h.x, h.y only bound the footprint: the affine form of the fusion kernel
+  // (rows of K*[R|T], error <= TileMapRec::err) is enough, see DESIGN.md 4b.2.
+  const double r20 = mr->rt[8], r21 = mr->rt[9], r22 = mr->rt[10], r23 = mr->rt[11];
+  const double zx[2] = {r20 * wxs[0], r20 * wxs[1]}, zy[2] = {r21 * wys[0], r21 * wys[1]}, zz[2] = {r22 * wzs[0], r22 * wzs[1]};
+  const double ux[2] = {tr->px * wxs[0], tr->px * wxs[1]};
+  const double uy[2] = {__builtin_fma(tr->py, wys[0], tr->p0), __builtin_fma(tr->py, wys[1], tr->p0)};
+  const double uz[2] = {tr->pz * wzs[0], tr->pz * wzs[1]};
+  const double vx[2] = {tr->qx * wxs[0], tr->qx * wxs[1]};
+  const double vy[2] = {__builtin_fma(tr->qy, wys[0], tr->q0), __builtin_fma(tr->qy, wys[1], tr->q0)};
+  const double vz[2] = {tr->qz * wzs[0], tr->qz * wzs[1]};
+  double czmin = __builtin_inf(), czmax = -__builtin_inf();
+  double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int cx = c & 1, cy = (c >> 1) & 1, ck = c >> 2;
+    const double cz = ((zx[cx] + zy[cy]) + zz[ck]) + r23;
+    const double hx = (ux[cx] + uy[cy]) + uz[ck];
+    const double hy = (vx[cx] + vy[cy]) + vz[ck];
     // h.z == c.z (pinhole K is a precondition of the tiled kernel).  The footprint only needs u, v to a small
     // fraction of the one-pixel dilation: a Newton-refined reciprocal (relative error < 2^-40) instead of two
     // fp64 divisions.
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
     vmax = fmax(vmax, v);
   }
   uint8_t cls = BRICK_MIXED;
-  const double err = a.tile_maps[m].err;
+  const double err = tr->err;
   if (!bad) {
     if (czmax < 0.0) {
       cls = BRICK_SKIP;  // every voxel is behind the camera (cu:177)

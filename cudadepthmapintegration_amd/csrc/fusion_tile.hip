@@ -236,27 +236,28 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       cword = cnext | ((cnext >> 1) & a.behind_mask);
       if ((((m >> 3) + 1) << 3) < m_end) cnext = cload(crow + (m >> 3) + 1);
     }
-    if (cword == 0x0303030303030303ull) {  // none of this block's eight maps touches the brick
+    // Step straight to the next view of this class word that needs work (not BRICK_SKIP): one bit per such view,
+    // shifted so that bit 0 is view m.  Skipped views cost no loop iteration.
+    const unsigned long long nonskip = cword ^ 0x0303030303030303ull;  // a BRICK_SKIP byte becomes 0
+    const unsigned long long todo = ((nonskip | (nonskip >> 1)) & 0x0101010101010101ull) >> ((m & 7) * 8);
+    if (todo == 0) {  // none of the remaining views of this word touches the brick
       m |= 7;
       continue;
     }
-    const unsigned cls = (unsigned)(cword >> ((m & 7) * 8)) & 0xffu;
+    m += __builtin_ctzll(todo) >> 3;
+    if (m >= m_end) break;  // the next view that needs work lies beyond the fused range
+    const unsigned cls = (unsigned)(cword >> ((m & 7) * 8)) & 3u;
     if (cls != BRICK_MIXED) {
       // proven: the reference does the same to every voxel of this brick for this map
-      if (cls != BRICK_SKIP) {
+      {
         const double v = cls == BRICK_FREE ? a.free_space : 0.0;  // cu:115 (adding 0 keeps -0.0 + 0.0 = +0.0)
-        if (kcount == TK) {
+        // all TK slots, also in a brick that sticks out of the top of the grid (kcount < TK): the slots above the grid
+        // are never stored, and treating them alike keeps per-slot predicates out of the loop
 #pragma unroll
-          for (int q = 0; q < TK; q += 8) acc_add8_s<BASE, TK>(q, m_lane_ok, v);
-        } else {
-#pragma unroll
-          for (int q = 0; q < TK; ++q)
-            if (q < kcount) acc_add_s<BASE, TK>(q, m_lane_ok, v);
-        }
+        for (int q = 0; q < TK; q += 8) acc_add8_s<BASE, TK>(q, m_lane_ok, v);
         if (COUNT) {
 #pragma unroll
-          for (int q = 0; q < TK; ++q)
-            if (q < kcount) nh[q] += lane_ok ? 1u : 0u;
+          for (int q = 0; q < TK; ++q) nh[q] += lane_ok ? 1u : 0u;
           const uint32_t hits = (uint32_t)__popcll(m_lane_ok) * (uint32_t)kcount;
           if (hits != 0 && lane == 0) atomicAdd(&a.map_hits[m], (unsigned long long)hits);
         }
