@@ -119,32 +119,19 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
   return acc;
 }
 
-// one thread per (wave brick, map): threadIdx.x runs over 64 consecutive maps (coalesced class bytes), threadIdx.y
-// over 4 consecutive bricks; all index arithmetic in 32 bits
-__global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
-                                                       const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
-  // wave bricks of the slab being fused: layers [2*sbz_first, 2*(sbz_first + super_z)) clipped to the grid
-  const int bz_first = 2 * a.sbz_first;
-  const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
-  const int n_bricks = a.wbricks_x * a.wbricks_y * bz_count;
-  const int local = blockIdx.x * 4 + threadIdx.y;
-  const int mm = blockIdx.y * 64 + threadIdx.x;
-  if (local >= n_bricks || mm >= a.n_maps) return;
-  const int m = a.first_map + mm;
-  const int bx = local % a.wbricks_x;
-  const int bt = local / a.wbricks_x;
-  const int by = bt % a.wbricks_y;
-  const int bz = bt / a.wbricks_y + bz_first;
-  const int brick = (bz * a.wbricks_y + by) * a.wbricks_x + bx;  // row of the class table (whole grid)
-  const MapRec *__restrict__ mr = maps + m;
+constexpr uint8_t kClassPending = 0xff;  // written by the coarse pass where the fine pass has to decide
 
-  // World coordinates of the brick's faces (cu:78-83 + cu:168).  With the axis-aligned grid the tiled kernel requires,
-  // wx depends on i only, wy on j, wz on k (fusion_tile.hip), so the eight corners share six values.  The brick's full
-  // extents are used also where it sticks out of the grid: a superset is conservative.
-  const TileMapRec *__restrict__ tr = a.tile_maps + m;
+// What the reference does to EVERY voxel centre of the box [i0, i1] x [j0, j1] x [k0, k1] (cell indices, inclusive; the
+// box may stick out of the grid: a superset is conservative) for one view, if that can be proven;
+// BRICK_MIXED otherwise.  A class proven for a box holds for every box inside it.
+__device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
+                                                const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
+                                                int j0, int j1, int k0, int k1) {
+  // World coordinates of the box's faces (cu:78-83 + cu:168).  With the axis-aligned grid the tiled kernel requires,
+  // wx depends on i only, wy on j, wz on k (fusion_tile.hip), so the eight corners share six values.
   double wxs[2], wys[2], wzs[2];
   for (int c = 0; c < 2; ++c) {
-    const int i = bx * 8 + (c ? 7 : 0), j = by * 8 + (c ? 7 : 0), k = bz * tk + (c ? tk - 1 : 0);
+    const int i = c ? i1 : i0, j = c ? j1 : j0, k = c ? k1 : k0;
     const double gx = a.ox + (i + 0.5) * a.sx;  // cu:80-82
     const double gy = a.oy + (j + 0.5) * a.sy;
     const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
@@ -213,8 +200,67 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
       }
     }
   }
-  classes[(int64_t)brick * a.class_pitch + m] = cls;
+  return cls;
 }
+
+// Coarse pass: one thread per (box of 32 x 32 x 32 voxels = 4 x 4 x 32/tk wave bricks, view).  Most of the volume is far
+// from every surface a view saw: there the whole box is proven at once and its bricks inherit the class; only the
+// bricks of unproven boxes are left to the fine pass (kClassPending).  threadIdx.x runs over 64 consecutive views, so
+// every child row receives 64 consecutive bytes per store.
+__global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, const MapRec *__restrict__ maps,
+                                                              const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
+  const int bz_first = 2 * a.sbz_first;
+  const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
+  const int per_z = 32 / tk;  // wave-brick layers per box
+  const int cx_n = (a.wbricks_x + 3) / 4, cy_n = (a.wbricks_y + 3) / 4, cz_n = (bz_count + per_z - 1) / per_z;
+  const int local = blockIdx.x * 4 + threadIdx.y;
+  const int mm = blockIdx.y * 64 + threadIdx.x;
+  if (local >= cx_n * cy_n * cz_n || mm >= a.n_maps) return;
+  const int m = a.first_map + mm;
+  const int cbx = local % cx_n;
+  const int ct = local / cx_n;
+  const int cby = ct % cy_n, cbz = ct / cy_n;
+  const int bz0 = bz_first + cbz * per_z;  // first wave-brick layer of the box (slab starts are multiples of 32 cells)
+  uint8_t cls = classify_box(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
+                             bz0 * tk + 31);
+  if (cls == BRICK_MIXED) cls = kClassPending;
+  for (int dz = 0; dz < per_z; ++dz) {
+    const int bz = bz0 + dz;
+    if (bz >= bz_first + bz_count) break;
+    for (int dy = 0; dy < 4; ++dy) {
+      const int by = cby * 4 + dy;
+      if (by >= a.wbricks_y) break;
+      for (int dx = 0; dx < 4; ++dx) {
+        const int bx = cbx * 4 + dx;
+        if (bx >= a.wbricks_x) break;
+        classes[(int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m] = cls;
+      }
+    }
+  }
+}
+
+// Fine pass: one thread per (wave brick, view) left pending by the coarse pass: threadIdx.x runs over 64 consecutive
+// views (coalesced class bytes), threadIdx.y over 4 consecutive bricks; all index arithmetic in 32 bits
+__global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
+                                                       const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
+  // wave bricks of the slab being fused: layers [2*sbz_first, 2*(sbz_first + super_z)) clipped to the grid
+  const int bz_first = 2 * a.sbz_first;
+  const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
+  const int n_bricks = a.wbricks_x * a.wbricks_y * bz_count;
+  const int local = blockIdx.x * 4 + threadIdx.y;
+  const int mm = blockIdx.y * 64 + threadIdx.x;
+  if (local >= n_bricks || mm >= a.n_maps) return;
+  const int m = a.first_map + mm;
+  const int bx = local % a.wbricks_x;
+  const int bt = local / a.wbricks_x;
+  const int by = bt % a.wbricks_y;
+  const int bz = bt / a.wbricks_y + bz_first;
+  const int brick = (bz * a.wbricks_y + by) * a.wbricks_x + bx;  // row of the class table (whole grid)
+  uint8_t *slot = classes + (int64_t)brick * a.class_pitch + m;
+  if (*slot != kClassPending) return;  // proven by the coarse pass
+  *slot = classify_box(a, maps + m, a.tile_maps + m, P, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+}
+
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
 // A workgroup whose brick is near a surface in every map runs the per-voxel path 256 times; one in free space
@@ -343,6 +389,12 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
   if (n_bricks <= 0 || a.n_maps <= 0) return hipSuccess;
   if (n_bricks > (int64_t)0x7fffffff || (a.n_maps + 63) / 64 > 65535) return hipErrorInvalidConfiguration;
+  const int per_z = 32 / tk;
+  const int64_t n_boxes = (int64_t)((a.wbricks_x + 3) / 4) * ((a.wbricks_y + 3) / 4) * ((bz_count + per_z - 1) / per_z);
+  hipLaunchKernelGGL(classify_coarse_kernel, dim3((unsigned)((n_boxes + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4),
+                     0, stream, a, maps_dev, P, tk, classes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((n_bricks + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4), 0,
                      stream, a, maps_dev, P, tk, classes);
   return hipGetLastError();
