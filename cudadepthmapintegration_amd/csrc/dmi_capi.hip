@@ -78,7 +78,8 @@ struct dmi_context {
   int64_t last_class_bricks = 0;  // wave bricks of the last fuse
   int32_t last_class_pitch = 0, last_first = 0, last_count = 0;
   dmi::PyramidDesc pyramid{};    // geometry of every view's depth min/max pyramid
-  uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch]
+  uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch], then the coarse table [boxes][class_pitch]
+  size_t coarse_offset = 0;      // byte offset of the coarse table within d_classes (last fuse)
   size_t classes_capacity = 0;   // bytes
   uint8_t *d_order_level = nullptr;  // workgroup order: scratch levels, order[], count
   int32_t *d_order = nullptr;
@@ -775,7 +776,10 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     t.wbricks_y = (a.ny + 7) / 8;
     t.class_pitch = (n_views + 15) / 16 * 16;
     if (!(cfg.variant & dmi::VAR_NO_BRICK_CLASSES)) {
-      const size_t cbytes = (size_t)t.wbricks_x * t.wbricks_y * t.bricks_z * (size_t)t.class_pitch;
+      const size_t fine_bytes = ((size_t)t.wbricks_x * t.wbricks_y * t.bricks_z * (size_t)t.class_pitch + 255) / 256 * 256;
+      // the coarse table (one row per box of 32^3 voxels) lives behind the brick table in the same allocation
+      const size_t cbytes = fine_bytes + (size_t)dmi::coarse_class_bytes(t, sh.tk);
+      ctx->coarse_offset = fine_bytes;
       if (ctx->classes_capacity < cbytes) {
         if (ctx->d_classes) {
           DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -832,7 +836,8 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     DMI_HIP(ctx, hipEventCreate(&ev.stop));
   }
   DMI_HIP(ctx, hipEventRecord(ev.start, ctx->stream));
-  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->pyramid, ctx->d_order_level, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
+  hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->pyramid, ctx->d_order_level,
+                                                         ctx->d_classes ? ctx->d_classes + ctx->coarse_offset : nullptr, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
   if (e != hipSuccess) {
     ctx->pool.push_back(ev);
     (void)hipGetLastError();

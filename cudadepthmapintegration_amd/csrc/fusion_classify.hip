@@ -119,8 +119,6 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
   return acc;
 }
 
-constexpr uint8_t kClassPending = 0xff;  // written by the coarse pass where the fine pass has to decide
-
 // What the reference does to EVERY voxel centre of the box [i0, i1] x [j0, j1] x [k0, k1] (cell indices, inclusive; the
 // box may stick out of the grid: a superset is conservative) for one view, if that can be proven;
 // BRICK_MIXED otherwise.  A class proven for a box holds for every box inside it.
@@ -204,14 +202,15 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
 }
 
 // Coarse pass: one thread per (box of 32 x 32 x 32 voxels = 4 x 4 x 32/tk wave bricks, view).  Most of the volume is far
-// from every surface a view saw: there the whole box is proven at once and its bricks inherit the class; only the
-// bricks of unproven boxes are left to the fine pass (kClassPending).  threadIdx.x runs over 64 consecutive views, so
-// every child row receives 64 consecutive bytes per store.
+// from every surface a view saw: there the whole box is proven at once and its bricks inherit the class; the bricks of
+// unproven boxes are left to the fine pass.  threadIdx.x runs over 64 consecutive views, so the box's own table row
+// and every child row receive 64 consecutive bytes per store.  Boxes are numbered over the whole grid.
 __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, const MapRec *__restrict__ maps,
-                                                              const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
+                                                              const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
+                                                              uint8_t *__restrict__ coarse) {
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
-  const int per_z = 32 / tk;  // wave-brick layers per box
+  const int per_z = 32 / tk;  // wave-brick layers per box; slab starts are multiples of 32 cells
   const int cx_n = (a.wbricks_x + 3) / 4, cy_n = (a.wbricks_y + 3) / 4, cz_n = (bz_count + per_z - 1) / per_z;
   const int local = blockIdx.x * 4 + threadIdx.y;
   const int mm = blockIdx.y * 64 + threadIdx.x;
@@ -219,11 +218,12 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   const int m = a.first_map + mm;
   const int cbx = local % cx_n;
   const int ct = local / cx_n;
-  const int cby = ct % cy_n, cbz = ct / cy_n;
-  const int bz0 = bz_first + cbz * per_z;  // first wave-brick layer of the box (slab starts are multiples of 32 cells)
-  uint8_t cls = classify_box(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
-                             bz0 * tk + 31);
-  if (cls == BRICK_MIXED) cls = kClassPending;
+  const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
+  const int bz0 = cbz * per_z;
+  const uint8_t cls = classify_box(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
+                                   bz0 * tk + 31);
+  coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] = cls;
+  if (cls == BRICK_MIXED) return;  // the fine pass decides brick by brick
   for (int dz = 0; dz < per_z; ++dz) {
     const int bz = bz0 + dz;
     if (bz >= bz_first + bz_count) break;
@@ -239,28 +239,34 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   }
 }
 
-// Fine pass: one thread per (wave brick, view) left pending by the coarse pass: threadIdx.x runs over 64 consecutive
-// views (coalesced class bytes), threadIdx.y over 4 consecutive bricks; all index arithmetic in 32 bits
+// Fine pass: one wave per (unproven box, view): the lanes are the box's wave bricks (4 x 4 x 4 of 8 voxels in z; with
+// 16-voxel columns 4 x 4 x 2, and the wave's upper half takes the next view), so a wave either has nothing to do or
+// works with all its lanes.  A block is four waves = four (eight) consecutive views of one box: their byte stores
+// land in the same cache lines.
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
-                                                       const PyramidDesc P, int tk, uint8_t *__restrict__ classes) {
-  // wave bricks of the slab being fused: layers [2*sbz_first, 2*(sbz_first + super_z)) clipped to the grid
+                                                       const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
+                                                       const uint8_t *__restrict__ coarse) {
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
-  const int n_bricks = a.wbricks_x * a.wbricks_y * bz_count;
-  const int local = blockIdx.x * 4 + threadIdx.y;
-  const int mm = blockIdx.y * 64 + threadIdx.x;
-  if (local >= n_bricks || mm >= a.n_maps) return;
+  const int per_z = 32 / tk;
+  const int cx_n = (a.wbricks_x + 3) / 4, cy_n = (a.wbricks_y + 3) / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int children = 16 * per_z;          // 64 or 32
+  const int views_per_wave = 64 / children;  // 1 or 2
+  const int mm = (blockIdx.y * 4 + wave) * views_per_wave + lane / children;
+  if (mm >= a.n_maps) return;
   const int m = a.first_map + mm;
-  const int bx = local % a.wbricks_x;
-  const int bt = local / a.wbricks_x;
-  const int by = bt % a.wbricks_y;
-  const int bz = bt / a.wbricks_y + bz_first;
-  const int brick = (bz * a.wbricks_y + by) * a.wbricks_x + bx;  // row of the class table (whole grid)
-  uint8_t *slot = classes + (int64_t)brick * a.class_pitch + m;
-  if (*slot != kClassPending) return;  // proven by the coarse pass
-  *slot = classify_box(a, maps + m, a.tile_maps + m, P, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+  const int local = blockIdx.x;  // box within the slab
+  const int cbx = local % cx_n;
+  const int ct = local / cx_n;
+  const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
+  if (coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] != BRICK_MIXED) return;
+  const int child = lane % children;
+  const int bx = cbx * 4 + (child & 3), by = cby * 4 + ((child >> 2) & 3), bz = cbz * per_z + (child >> 4);
+  if (bx >= a.wbricks_x || by >= a.wbricks_y || bz >= bz_first + bz_count) return;
+  classes[(int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m] =
+      classify_box(a, maps + m, a.tile_maps + m, P, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
 }
-
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
 // A workgroup whose brick is near a surface in every map runs the per-voxel path 256 times; one in free space
@@ -384,20 +390,26 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 }
 
 hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, const PyramidDesc &P, int tk, uint8_t *classes,
-                                  hipStream_t stream) {
+                                  uint8_t *coarse, hipStream_t stream) {
   const int bz_count = std::min(2 * a.super_z, a.bricks_z - 2 * a.sbz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
   if (n_bricks <= 0 || a.n_maps <= 0) return hipSuccess;
-  if (n_bricks > (int64_t)0x7fffffff || (a.n_maps + 63) / 64 > 65535) return hipErrorInvalidConfiguration;
+  if (n_bricks > (int64_t)0x7fffffff || (a.n_maps + 3) / 4 > 65535) return hipErrorInvalidConfiguration;
   const int per_z = 32 / tk;
   const int64_t n_boxes = (int64_t)((a.wbricks_x + 3) / 4) * ((a.wbricks_y + 3) / 4) * ((bz_count + per_z - 1) / per_z);
   hipLaunchKernelGGL(classify_coarse_kernel, dim3((unsigned)((n_boxes + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4),
-                     0, stream, a, maps_dev, P, tk, classes);
+                     0, stream, a, maps_dev, P, tk, classes, coarse);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((n_bricks + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4), 0,
-                     stream, a, maps_dev, P, tk, classes);
+  const int views_per_block = 4 * (64 / (16 * per_z));
+  hipLaunchKernelGGL(classify_kernel, dim3((unsigned)n_boxes, (unsigned)((a.n_maps + views_per_block - 1) / views_per_block)),
+                     dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
   return hipGetLastError();
+}
+
+int64_t coarse_class_bytes(const TileArgs &a, int tk) {
+  const int per_z = 32 / tk;
+  return (int64_t)((a.wbricks_x + 3) / 4) * ((a.wbricks_y + 3) / 4) * ((a.bricks_z + per_z - 1) / per_z) * (int64_t)a.class_pitch;
 }
 
 hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level, int *order, int *n_valid,

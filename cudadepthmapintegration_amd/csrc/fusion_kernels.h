@@ -163,7 +163,7 @@ hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t 
 // Tiled kernel: fills args.cz_table for maps [first_map, first_map + n_maps) and fuses them.
 // args.full must point to a device copy of the matching FuseArgs (read by the exact fallback).
 hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
-                             uint8_t *order_scratch, hipStream_t stream);
+                             uint8_t *order_scratch, uint8_t *coarse_classes, hipStream_t stream);
 
 // depth upload helpers ------------------------------------------------------------------
 // out[row-flipped i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64, n_maps
@@ -182,7 +182,9 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
                                  DepthTile *pyramids, hipStream_t stream);
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.
 hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, const PyramidDesc &desc, int tk,
-                                  uint8_t *classes, hipStream_t stream);
+                                  uint8_t *classes, uint8_t *coarse, hipStream_t stream);
+// bytes of the coarse class table (one row of class_pitch bytes per box of 32^3 voxels of the whole grid)
+int64_t coarse_class_bytes(const TileArgs &args, int tk);
 // order[p] = slot (super_brick * 32 + brick) of the p-th workgroup, bricks with the most BRICK_MIXED pairs first;
 // level: scratch of super_x*super_y*super_z*32 bytes; wx, wy: waves per workgroup
 hipError_t launch_order_bricks(const TileArgs &args, int wx, int wy, uint8_t *level, int *order, int *n_valid,

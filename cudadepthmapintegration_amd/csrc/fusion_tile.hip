@@ -469,7 +469,7 @@ TileShape tile_shape(int variant, bool depth_is_f64) {
 }
 
 hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
-                             uint8_t *order_scratch, hipStream_t stream) {
+                             uint8_t *order_scratch, uint8_t *coarse_classes, hipStream_t stream) {
   if (a.n_maps <= 0) return hipSuccess;
   hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
                      const_cast<double *>(a.cz_table));
@@ -477,7 +477,7 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
   if (e != hipSuccess) return e;
   if (a.classes) {
     const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0);
-    e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), stream);
+    e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, stream);
     if (e != hipSuccess) return e;
     if (a.order) {
       e = launch_order_bricks(a, sh.wx, sh.wy, order_scratch, const_cast<int *>(a.order), const_cast<int *>(a.n_order), stream);
