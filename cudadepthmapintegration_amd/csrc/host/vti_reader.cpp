@@ -108,12 +108,17 @@ uint64_t header_word(const unsigned char *p, const Format &f, size_t index) {
   return v;
 }
 
+// `expect` = the byte count the extent and the array's type call for: sizes read from the file are checked against
+// it BEFORE anything is allocated, so a corrupt header cannot ask for terabytes.
 bool inflate_blocks(const unsigned char *src, size_t src_len, const std::vector<uint64_t> &csize, uint64_t block,
-                    uint64_t last, std::vector<unsigned char> *out, std::string *err) {
+                    uint64_t last, size_t expect, std::vector<unsigned char> *out, std::string *err) {
   const size_t nb = csize.size();
+  // block is the nominal block size (an array smaller than one block has nb = 1, last = its size)
+  if (last > block || (nb > 1 && block > expect) || nb > (uint64_t)expect + 1)
+    return fail(err, "compression header does not match the array's size");
   uint64_t total = 0;
   for (size_t b = 0; b < nb; ++b) total += (b + 1 == nb && last != 0) ? last : block;
-  if (total > (uint64_t(1) << 40)) return fail(err, "compressed array claims an absurd size");
+  if (total != expect) return fail(err, "compressed array does not have the size its extent and type call for");
   out->resize((size_t)total);
   size_t in_off = 0, out_off = 0;
   for (size_t b = 0; b < nb; ++b) {
@@ -129,11 +134,13 @@ bool inflate_blocks(const unsigned char *src, size_t src_len, const std::vector<
 }
 
 // raw (not base64) payload at data[0 .. len)
-bool decode_raw(const unsigned char *data, size_t len, const Format &f, std::vector<unsigned char> *out, std::string *err) {
+bool decode_raw(const unsigned char *data, size_t len, const Format &f, size_t expect, std::vector<unsigned char> *out,
+                std::string *err) {
   const size_t hw = f.header_word;
   if (!f.zlib) {
     if (len < hw) return fail(err, "appended data: truncated header");
     const uint64_t n = header_word(data, f, 0);
+    if (n != expect) return fail(err, "appended data: array does not have the size its extent and type call for");
     if (n > len - hw) return fail(err, "appended data: array runs past the end of the file");
     out->assign(data + hw, data + hw + (size_t)n);
     return true;
@@ -144,12 +151,12 @@ bool decode_raw(const unsigned char *data, size_t len, const Format &f, std::vec
   std::vector<uint64_t> csize((size_t)nb);
   for (size_t b = 0; b < (size_t)nb; ++b) csize[b] = header_word(data, f, 3 + b);
   const size_t hbytes = (3 + (size_t)nb) * hw;
-  return inflate_blocks(data + hbytes, len - hbytes, csize, block, last, out, err);
+  return inflate_blocks(data + hbytes, len - hbytes, csize, block, last, expect, out, err);
 }
 
 // base64 payload starting at text[pos] (inline "binary" arrays and base64 appended data)
-bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f, std::vector<unsigned char> *out,
-                std::string *err) {
+bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f, size_t expect,
+                std::vector<unsigned char> *out, std::string *err) {
   const size_t hw = f.header_word;
   if (!f.zlib) {
     // one unit: [n_bytes] DATA
@@ -157,7 +164,7 @@ bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f
     size_t p = pos;
     if (!b64_decode(text, &p, end, hw, &head)) return fail(err, "base64: truncated header");
     const uint64_t n = header_word(head.data(), f, 0);
-    if (n > (uint64_t(1) << 40)) return fail(err, "array claims an absurd size");
+    if (n != expect) return fail(err, "array does not have the size its extent and type call for");
     std::vector<unsigned char> all;
     all.reserve((size_t)n + hw + 3);
     p = pos;
@@ -170,14 +177,20 @@ bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f
   size_t p = pos;
   if (!b64_decode(text, &p, end, 3 * hw, &head)) return fail(err, "base64: truncated compression header");
   const uint64_t nb = header_word(head.data(), f, 0), block = header_word(head.data(), f, 1), last = header_word(head.data(), f, 2);
-  if (nb > (uint64_t(1) << 32)) return fail(err, "compression header claims an absurd block count");
+  // every block but the last holds `block` bytes: more blocks than bytes cannot be
+  if (nb > (uint64_t)expect + 1 || nb > (end - pos)) return fail(err, "compression header claims an absurd block count");
   const size_t hbytes = (3 + (size_t)nb) * hw;
   head.clear();
   p = pos;
   if (!b64_decode(text, &p, end, hbytes, &head)) return fail(err, "base64: truncated compression header");
   std::vector<uint64_t> csize((size_t)nb);
   uint64_t ctotal = 0;
-  for (size_t b = 0; b < (size_t)nb; ++b) ctotal += (csize[b] = header_word(head.data(), f, 3 + b));
+  for (size_t b = 0; b < (size_t)nb; ++b) {
+    csize[b] = header_word(head.data(), f, 3 + b);
+    if (csize[b] > end - pos) return fail(err, "base64: a compressed block is larger than the file");
+    ctotal += csize[b];
+  }
+  if (ctotal > end - pos) return fail(err, "base64: the compressed blocks are larger than the file");
   // the header unit is padded to whole groups: the data unit starts at the next group boundary
   size_t q = pos, groups = (hbytes + 2) / 3, seen = 0;
   while (seen < groups * 4 && q < end) {
@@ -187,7 +200,7 @@ bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f
   std::vector<unsigned char> comp;
   comp.reserve((size_t)ctotal + 3);
   if (!b64_decode(text, &q, end, (size_t)ctotal, &comp)) return fail(err, "base64: compressed data is shorter than its header says");
-  return inflate_blocks(comp.data(), comp.size(), csize, block, last, out, err);
+  return inflate_blocks(comp.data(), comp.size(), csize, block, last, expect, out, err);
 }
 
 }  // namespace
@@ -234,6 +247,9 @@ bool ReadImageData(const std::string &path, const std::vector<std::string> &want
   }
   for (int a = 0; a < 3; ++a)
     if (out->dims(a) < 1) return fail(err, path + ": empty extent");
+  for (int a = 0; a < 3; ++a)
+    if (out->dims(a) > (1 << 20)) return fail(err, path + ": extent too large");
+  if ((double)out->dims(0) * out->dims(1) * out->dims(2) > 4e9) return fail(err, path + ": extent too large");
   const size_t n_points = (size_t)out->dims(0) * out->dims(1) * out->dims(2);
 
   // appended data section (raw payloads can contain anything: never search inside it)
@@ -277,7 +293,7 @@ bool ReadImageData(const std::string &path, const std::vector<std::string> &want
     if (!attr(tag, "type", &a.type) || (a.elem_size = type_size(a.type)) == 0)
       return fail(err, path + ": array '" + a.name + "' has an unknown type");
     if (attr(tag, "NumberOfComponents", &s)) a.components = std::atoi(s.c_str());
-    if (a.components < 1) return fail(err, path + ": array '" + a.name + "' has no components");
+    if (a.components < 1 || a.components > 1024) return fail(err, path + ": array '" + a.name + "' has an impossible component count");
     const size_t n_values = n_points * (size_t)a.components;
     const size_t n_bytes = n_values * a.elem_size;
 
@@ -288,8 +304,8 @@ bool ReadImageData(const std::string &path, const std::vector<std::string> &want
       if (off > text.size() - app_data) return fail(err, path + ": offset of '" + a.name + "' is past the end of the file");
       std::string why;
       const bool ok = app_raw ? decode_raw(reinterpret_cast<const unsigned char *>(text.data()) + app_data + off,
-                                           text.size() - app_data - (size_t)off, fmt, &a.bytes, &why)
-                              : decode_b64(text, app_data + (size_t)off, text.size(), fmt, &a.bytes, &why);
+                                           text.size() - app_data - (size_t)off, fmt, n_bytes, &a.bytes, &why)
+                              : decode_b64(text, app_data + (size_t)off, text.size(), fmt, n_bytes, &a.bytes, &why);
       if (!ok) return fail(err, path + ": array '" + a.name + "': " + why);
     } else {
       if (self_closed) return fail(err, path + ": inline array '" + a.name + "' has no content");
@@ -297,8 +313,9 @@ bool ReadImageData(const std::string &path, const std::vector<std::string> &want
       if (close == std::string::npos || close > pd1) return fail(err, path + ": unterminated <DataArray>");
       if (format == "binary") {
         std::string why;
-        if (!decode_b64(text, p, close, fmt, &a.bytes, &why)) return fail(err, path + ": array '" + a.name + "': " + why);
+        if (!decode_b64(text, p, close, fmt, n_bytes, &a.bytes, &why)) return fail(err, path + ": array '" + a.name + "': " + why);
       } else if (format == "ascii") {
+        if (n_values > (close - p)) return fail(err, path + ": array '" + a.name + "' has fewer values than points");
         a.bytes.resize(n_bytes);
         const char *c = text.data() + p;
         const char *const cend = text.data() + close;

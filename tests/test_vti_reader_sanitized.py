@@ -1,0 +1,60 @@
+"""The .vti reader (host/vti_reader.cpp) under AddressSanitizer + UBSan on the CPU: every data mode, then thousands of
+truncated and bit-flipped variants of those files.  A parse error is fine; a sanitizer report fails the test."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from vti_writer import write_vti
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = [("ascii", False, "UInt32", False), ("binary", False, "UInt32", False), ("binary", True, "UInt64", False),
+         ("appended-raw", False, "UInt32", False), ("appended-raw", True, "UInt64", True),
+         ("appended-base64", False, "UInt64", False), ("appended-base64", True, "UInt32", False)]
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    out = tmp_path_factory.mktemp("asan") / "vti_harness"
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           os.path.join(ROOT, "tests", "cpp", "vti_reader_harness.cpp"),
+           os.path.join(ROOT, "cudadepthmapintegration_amd", "csrc", "host", "vti_reader.cpp"), "-lz", "-o", str(out)]
+    subprocess.check_call(cmd)
+    return str(out)
+
+
+def test_vti_reader_survives_mutated_files(harness, tmp_path):
+    rng = np.random.default_rng(11)
+    W, H = 19, 13
+    arrays = {"Depths": rng.uniform(0.5, 9.0, size=(H, W)), "Best Cost Values": rng.random((H, W)),
+              "Color": rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)}
+    files = []
+    for n, (mode, compress, header, big) in enumerate(MODES):
+        p = tmp_path / f"ok{n}.vti"
+        write_vti(str(p), arrays, W, H, mode=mode, compress=compress, header=header, big_endian=big, block=700)
+        files.append(str(p))
+        good = p.read_bytes()
+        for t in range(60):                                   # truncations and byte flips, header area favoured
+            b = bytearray(good)
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                b = b[:int(rng.integers(1, len(b)))]
+            else:
+                for _ in range(int(rng.integers(1, 6))):
+                    pos = int(rng.integers(0, len(b))) if kind == 1 else int(rng.integers(0, min(len(b), 900)))
+                    b[pos] = int(rng.integers(0, 256))
+            q = tmp_path / f"mut{n}_{t}.vti"
+            q.write_bytes(bytes(b))
+            files.append(str(q))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for i in range(0, len(files), 100):
+        r = subprocess.run([harness] + files[i:i + 100], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+    # the unmutated files all parse
+    r = subprocess.run([harness] + files[::61][:len(MODES)], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 0 and f"parsed {len(MODES)} rejected 0" in r.stdout, r.stdout + r.stderr[-2000:]
