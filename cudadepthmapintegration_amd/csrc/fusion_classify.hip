@@ -288,14 +288,15 @@ __device__ __forceinline__ bool slot_to_brick(const TileArgs &a, int slot, int &
 
 constexpr int kWorkLevels = 4;
 
+// one wave per workgroup slot: the lanes run over the views of the slot's wave bricks (coalesced class bytes)
 __global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int wx, int wy, int n_slots,
                                                          uint8_t *__restrict__ level) {
-  const int local = blockIdx.x * blockDim.x + threadIdx.x;  // slot within the slab being fused
-  if (local >= n_slots) return;
-  const int slot = local;
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);  // slot within the slab being fused
+  if (slot >= n_slots) return;
   int bx, by, bz;
-  if (!slot_to_brick(a, local + a.slot_base, bx, by, bz)) {
-    level[slot] = 255;  // padding of the super-brick grid: no workgroup needed
+  if (!slot_to_brick(a, slot + a.slot_base, bx, by, bz)) {
+    if (lane == 0) level[slot] = 255;  // padding of the super-brick grid: no workgroup needed
     return;
   }
   int mixed = 0, total = 0;
@@ -304,17 +305,38 @@ __global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int w
       const int wbx = bx * wx + u, wby = by * wy + v;
       if (wbx >= a.wbricks_x || wby >= a.wbricks_y) continue;
       const uint8_t *row = a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch;
-      for (int m = a.first_map; m < a.first_map + a.n_maps; ++m) mixed += row[m] == BRICK_MIXED ? 1 : 0;
+      for (int m = a.first_map + lane; m < a.first_map + a.n_maps; m += 64) mixed += row[m] == BRICK_MIXED ? 1 : 0;
       total += a.n_maps;
     }
-  level[slot] = mixed * 2 >= total ? 0 : (mixed * 8 >= total ? 1 : (mixed > 0 ? 2 : 3));
+  for (int off = 32; off > 0; off >>= 1) mixed += __shfl_xor(mixed, off, 64);
+  if (lane == 0) level[slot] = mixed * 2 >= total ? 0 : (mixed * 8 >= total ? 1 : (mixed > 0 ? 2 : 3));
+}
+
+// exclusive prefix sum of one int per thread over a block of 1024 threads (16 waves); returns the block total in *sum
+__device__ __forceinline__ int block_exclusive_scan(int value, int *wave_totals /* LDS, 16 ints */, int *sum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = value;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_totals[wave] = incl;
+  __syncthreads();
+  int base = 0, all = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = wave_totals[w];
+    if (w < wave) base += t;
+    all += t;
+  }
+  __syncthreads();  // wave_totals is reused by the next scan
+  *sum = all;
+  return base + incl - value;
 }
 
 // stable partition of the valid slots by level; one workgroup of 1024 threads, each owning a run of slots
 __global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__restrict__ level, int n_slots, int slot_base,
                                                            int *__restrict__ order, int *__restrict__ n_valid) {
-  __shared__ int cnt[kWorkLevels][1024];
-  __shared__ int base[kWorkLevels + 1];
+  __shared__ int wave_totals[16];
   const int t = threadIdx.x;
   const int per = (n_slots + 1023) / 1024;
   const int lo = t * per, hi = min(n_slots, lo + per);
@@ -323,26 +345,14 @@ __global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__rest
     const int l = level[s];
     if (l < kWorkLevels) mine[l] += 1;
   }
-  for (int l = 0; l < kWorkLevels; ++l) cnt[l][t] = mine[l];
-  __syncthreads();
-  if (t < kWorkLevels) {  // exclusive scan of this level's counts (1024 adds: a few microseconds)
-    int run = 0;
-    for (int i = 0; i < 1024; ++i) {
-      const int c = cnt[t][i];
-      cnt[t][i] = run;
-      run += c;
-    }
-    base[t + 1] = run;
-  }
-  __syncthreads();
-  if (t == 0) {
-    base[0] = 0;
-    for (int l = 1; l <= kWorkLevels; ++l) base[l] += base[l - 1];
-    *n_valid = base[kWorkLevels];
-  }
-  __syncthreads();
   int pos[kWorkLevels];
-  for (int l = 0; l < kWorkLevels; ++l) pos[l] = base[l] + cnt[l][t];
+  int level_base = 0;
+  for (int l = 0; l < kWorkLevels; ++l) {
+    int total = 0;
+    pos[l] = level_base + block_exclusive_scan(mine[l], wave_totals, &total);
+    level_base += total;
+  }
+  if (t == 0) *n_valid = level_base;
   for (int s = lo; s < hi; ++s) {
     const int l = level[s];
     if (l < kWorkLevels) order[pos[l]++] = s + slot_base;  // absolute slot
@@ -415,7 +425,7 @@ int64_t coarse_class_bytes(const TileArgs &a, int tk) {
 hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level, int *order, int *n_valid,
                                hipStream_t stream) {
   const int n_slots = a.super_x * a.super_y * a.super_z * 32;
-  hipLaunchKernelGGL(brick_work_kernel, dim3(blocks_of(n_slots)), dim3(256), 0, stream, a, wx, wy, n_slots, level);
+  hipLaunchKernelGGL(brick_work_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, stream, a, wx, wy, n_slots, level);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, stream, level, n_slots, a.slot_base, order, n_valid);
