@@ -18,12 +18,14 @@
 //      axis-parallel line, so every voxel's real-valued u lies between the corner values.  The reference's
 //      computed, rounded pixel differs from that by at most 1/2 + (TileMapRec::err / c.z); the box is dilated
 //      by one pixel and c.z >= 4*err is required.
-//   3. depth over the footprint: min/max pyramid, tiles rounded outward, at the level where the footprint
-//      spans at most 2 x 2 tiles.
+//   3. depth over the footprint: min/max pyramid, tiles rounded outward, at the finest level where the footprint
+//      spans at most 5 x 5 tiles (2 x 2 in the coarse pass).
 //   4. class FREE: fl(czmax - dmin) < -delta implies fl(c.z - d) < -delta for every voxel and pixel (monotone
 //      rounding).  Class BEHIND: fl(czmin - dmax) > delta likewise.
 #include <algorithm>
 #include <cstring>
+
+#include <stdlib.h>
 
 #include "fusion_kernels.h"
 #include "fusion_device.h"
@@ -101,19 +103,19 @@ __global__ __launch_bounds__(256) void pyramid_up_kernel(int64_t n_maps, int lev
   pyr[m * P.total_tiles + P.offset[level] + t] = acc.tile();
 }
 
-// bounds of the depth values in pixels [x0, x1] x [y0, y1] (inside the image)
+// bounds of the depth values in pixels [x0, x1] x [y0, y1] (inside the image): the finest level whose tiles cover the
+// range with at most kQueryTiles x kQueryTiles of them.  Finer tiles hug the footprint more closely (a 2 x 2 cover can
+// reach over 4 to 16 times the footprint's area and pull a silhouette in that no voxel of the box projects onto).
+template <int kQueryTiles>
 __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ pyr, const PyramidDesc &P, int x0, int x1,
                                                  int y0, int y1) {
   const int extent = max(x1 - x0, y1 - y0) + 1;
+  // tiles of 2^L pixels: a range of `extent` pixels touches at most (extent - 1) / 2^L + 2 of them per axis
   int li = 0;
-  while (li + 1 < P.n_levels && (1 << (kPyramidMinLevel + li)) < extent) ++li;
+  while (li + 1 < P.n_levels && ((extent - 1) >> (kPyramidMinLevel + li)) + 2 > kQueryTiles) ++li;
   const int L = kPyramidMinLevel + li;
   TileAcc acc;
-  if ((1 << L) < extent) {  // only possible at the top level: scan it (it is at most 2 x 2 tiles... or 1 x 1)
-    for (int t = 0; t < P.width[li] * P.height[li]; ++t) acc.add_tile(pyr[P.offset[li] + t]);
-    return acc;
-  }
-  const int tx0 = x0 >> L, tx1 = x1 >> L, ty0 = y0 >> L, ty1 = y1 >> L;  // at most 2 x 2 tiles
+  const int tx0 = x0 >> L, tx1 = x1 >> L, ty0 = y0 >> L, ty1 = y1 >> L;  // more than kQueryTiles only at the top level
   for (int ty = ty0; ty <= ty1; ++ty)
     for (int tx = tx0; tx <= tx1; ++tx) acc.add_tile(pyr[P.offset[li] + ty * P.width[li] + tx]);
   return acc;
@@ -122,6 +124,7 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
 // What the reference does to EVERY voxel centre of the box [i0, i1] x [j0, j1] x [k0, k1] (cell indices, inclusive; the
 // box may stick out of the grid: a superset is conservative) for one view, if that can be proven;
 // BRICK_MIXED otherwise.  A class proven for a box holds for every box inside it.
+template <int kQueryTiles>
 __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
                                                 const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
                                                 int j0, int j1, int k0, int k1) {
@@ -184,7 +187,7 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
       if (x1 < 0 || y1 < 0 || x0 >= a.W || y0 >= a.H) {
         cls = BRICK_SKIP;  // every voxel projects outside the map (cu:192-197)
       } else if (x0 >= 0 && y0 >= 0 && x1 < a.W && y1 < a.H) {
-        const TileAcc d = pyramid_query(mr->pyramid, P, x0, x1, y0, y1);
+        const TileAcc d = pyramid_query<kQueryTiles>(mr->pyramid, P, x0, x1, y0, y1);
         if (!(d.flags & TILE_HAS_NAN)) {
           if (!(d.flags & TILE_HAS_VALID)) {
             cls = BRICK_SKIP;  // only "no depth" pixels (cu:202)
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
   const int bz0 = cbz * per_z;
-  const uint8_t cls = classify_box(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
+  const uint8_t cls = classify_box<2>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
                                    bz0 * tk + 31);
   coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] = cls;
   if (cls == BRICK_MIXED) return;  // the fine pass decides brick by brick
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
 // 16-voxel columns 4 x 4 x 2, and the wave's upper half takes the next view), so a wave either has nothing to do or
 // works with all its lanes.  A block is four waves = four (eight) consecutive views of one box: their byte stores
 // land in the same cache lines.
+template <int kQueryTiles>
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                        const uint8_t *__restrict__ coarse) {
@@ -265,7 +269,8 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   const int bx = cbx * 4 + (child & 3), by = cby * 4 + ((child >> 2) & 3), bz = cbz * per_z + (child >> 4);
   if (bx >= a.wbricks_x || by >= a.wbricks_y || bz >= bz_first + bz_count) return;
   classes[(int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m] =
-      classify_box(a, maps + m, a.tile_maps + m, P, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+      classify_box<kQueryTiles>(a, maps + m, a.tile_maps + m, P, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk,
+                                         bz * tk + tk - 1);
 }
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
@@ -412,8 +417,22 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int views_per_block = 4 * (64 / (16 * per_z));
-  hipLaunchKernelGGL(classify_kernel, dim3((unsigned)n_boxes, (unsigned)((a.n_maps + views_per_block - 1) / views_per_block)),
-                     dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+  const dim3 fine_grid((unsigned)n_boxes, (unsigned)((a.n_maps + views_per_block - 1) / views_per_block));
+  // tiles per axis the fine pass may read for its depth bounds: 2 -> 3 -> 5 took the mixed pairs of cfg 3 from 10.1 M to
+  // 8.4 M to 7.6 M and the fusion from 10.8 to 10.0 to 9.8 ms; more gains nothing at 8-pixel tiles, and 4-pixel tiles
+  // cost more in this pass than they save in the next (profiles/r01zm_*)
+  int q = 5;
+  if (const char *env = getenv("DMI_QUERY_TILES")) q = atoi(env);  // tuning experiments
+  if (q <= 2)
+    hipLaunchKernelGGL(classify_kernel<2>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+  else if (q == 3)
+    hipLaunchKernelGGL(classify_kernel<3>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+  else if (q <= 5)
+    hipLaunchKernelGGL(classify_kernel<5>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+  else if (q <= 7)
+    hipLaunchKernelGGL(classify_kernel<7>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+  else
+    hipLaunchKernelGGL(classify_kernel<9>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
   return hipGetLastError();
 }
 
