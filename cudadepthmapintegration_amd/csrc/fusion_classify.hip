@@ -17,7 +17,7 @@
 //   2. pixel footprint: u = h.x/h.z is a projective function; on a box with h.z > 0 it is monotone along every
 //      axis-parallel line, so every voxel's real-valued u lies between the corner values.  The reference's
 //      computed, rounded pixel differs from that by at most 1/2 + (TileMapRec::err / c.z); the box is dilated
-//      by one pixel and c.z >= 4*err is required.
+//      by 1/2 + 2*err/czmin + 2^-20 pixel and c.z >= 4*err is required.
 //   3. depth over the footprint: min/max pyramid, tiles rounded outward, at the finest level where the footprint
 //      spans at most 5 x 5 tiles (2 x 2 in the coarse pass).
 //   4. class FREE: fl(czmax - dmin) < -delta implies fl(c.z - d) < -delta for every voxel and pixel (monotone
@@ -181,9 +181,15 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
       cls = BRICK_SKIP;  // every voxel is behind the camera (cu:177)
     } else if (czmin > 4.0 * err && czmin > 0.0 && umin == umin && umax == umax && vmin == vmin && vmax == vmax &&
                fabs(umin) < 0x1p30 && fabs(umax) < 0x1p30 && fabs(vmin) < 0x1p30 && fabs(vmax) < 0x1p30) {
-      // every voxel's rounded pixel lies in [x0, x1] x [y0, y1]
-      const int x0 = (int)floor(umin - 1.0), x1 = (int)ceil(umax + 1.0);
-      const int y0 = (int)floor(vmin - 1.0), y1 = (int)ceil(vmax + 1.0);
+      // Every voxel's rounded pixel lies in [x0, x1] x [y0, y1]: its real u lies between the real corner values
+      // (projective, monotone along the axes), the corner values above are within err/c.z + 2^-21 of the real ones, the
+      // reference's computed u within err/c.z + 2^-21 of the real one, and rounding moves it by at most
+      // 1/2: an integer px with umin - 1/2 - e <= px <= umax + 1/2 + e, e = 2*err/czmin + 2^-20 (< 0.51).
+      double rmin = __builtin_amdgcn_rcp(czmin);
+      rmin = __builtin_fma(rmin, __builtin_fma(-czmin, rmin, 1.0), rmin);
+      const double e = 2.0 * err * rmin * (1.0 + 0x1p-30) + 0x1p-20;
+      const int x0 = (int)ceil(umin - 0.5 - e), x1 = (int)floor(umax + 0.5 + e);
+      const int y0 = (int)ceil(vmin - 0.5 - e), y1 = (int)floor(vmax + 0.5 + e);
       if (x1 < 0 || y1 < 0 || x0 >= a.W || y0 >= a.H) {
         cls = BRICK_SKIP;  // every voxel projects outside the map (cu:192-197)
       } else if (x0 >= 0 && y0 >= 0 && x1 < a.W && y1 < a.H) {
