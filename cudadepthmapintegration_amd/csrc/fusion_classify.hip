@@ -19,7 +19,7 @@
 //      computed, rounded pixel differs from that by at most 1/2 + (TileMapRec::err / c.z); the box is dilated
 //      by 1/2 + 2*err/czmin + 2^-20 pixel and c.z >= 4*err is required.
 //   3. depth over the footprint: min/max pyramid, tiles rounded outward, at the finest level where the footprint
-//      spans at most 5 x 5 tiles (2 x 2 in the coarse pass).
+//      spans at most 5 x 5 tiles.
 //   4. class FREE: fl(czmax - dmin) < -delta implies fl(c.z - d) < -delta for every voxel and pixel (monotone
 //      rounding).  Class BEHIND: fl(czmin - dmax) > delta likewise.
 #include <algorithm>
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
   const int bz0 = cbz * per_z;
-  const uint8_t cls = classify_box<2>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
+  const uint8_t cls = classify_box<5>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
                                    bz0 * tk + 31);
   coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] = cls;
   if (cls == BRICK_MIXED) return;  // the fine pass decides brick by brick
