@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
-    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms",
+    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram",
 ]
 
 _lib = None
@@ -119,6 +119,7 @@ def load() -> ctypes.CDLL:
     L.dmi_download_point_data_f64.argtypes = [vp, dp]
     L.dmi_point_data_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
     L.dmi_get_brick_class_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.dmi_get_mixed_reason_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -292,6 +293,13 @@ class FusionContext:
         h = (ctypes.c_uint64 * 4)()
         self._check(self._lib.dmi_get_brick_class_histogram(self._h, h))
         return {"mixed": int(h[0]), "free": int(h[1]), "behind": int(h[2]), "skip": int(h[3])}
+
+    def mixed_reason_histogram(self) -> dict:
+        """Why the mixed (brick, view) pairs of the last fuse could not be proven uniform (diagnostic)."""
+        h = (ctypes.c_uint64 * 8)()
+        self._check(self._lib.dmi_get_mixed_reason_histogram(self._h, h))
+        names = ["unspecified", "degenerate", "camera_plane", "image_border", "nan_depth", "sentinel_and_depth", "near_surface"]
+        return {n: int(h[i]) for i, n in enumerate(names)}
 
     def timings(self) -> TimingsC:
         t = TimingsC()

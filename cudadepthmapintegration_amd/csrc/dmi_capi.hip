@@ -1018,6 +1018,23 @@ int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]) {
   return DMI_OK;
 }
 
+int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]) {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_mixed_reason_histogram: null argument");
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  if (!ctx->last_fuse_classes) return DMI_OK;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  const size_t bytes = (size_t)ctx->last_class_bricks * ctx->last_class_pitch;
+  std::vector<uint8_t> host(bytes);
+  DMI_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_classes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t b = 0; b < ctx->last_class_bricks; ++b) {
+    const uint8_t *row = host.data() + (size_t)b * ctx->last_class_pitch + ctx->last_first;
+    for (int32_t m = 0; m < ctx->last_count; ++m)
+      if ((row[m] & 3) == dmi::BRICK_MIXED) out[(row[m] >> 2) & 7] += 1;
+  }
+  return DMI_OK;
+}
+
 int dmi_get_timings(dmi_context *ctx, dmi_timings *out) {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_timings: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));

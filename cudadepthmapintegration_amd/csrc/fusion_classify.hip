@@ -174,9 +174,12 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
     vmin = fmin(vmin, v);
     vmax = fmax(vmax, v);
   }
-  uint8_t cls = BRICK_MIXED;
+  // an unproven pair carries, above the two class bits, WHY it is unproven (MixedReason << 2): a diagnostic the
+  // fusion kernel never looks at (it reads the class as byte & 3)
+  uint8_t cls = BRICK_MIXED | (MIXED_DEGENERATE << 2);
   const double err = tr->err;
   if (!bad) {
+    cls = BRICK_MIXED | (MIXED_CAMERA_PLANE << 2);
     if (czmax < 0.0) {
       cls = BRICK_SKIP;  // every voxel is behind the camera (cu:177)
     } else if (czmin > 4.0 * err && czmin > 0.0 && umin == umin && umax == umax && vmin == vmin && vmax == vmax &&
@@ -190,14 +193,18 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
       const double e = 2.0 * err * rmin * (1.0 + 0x1p-30) + 0x1p-20;
       const int x0 = (int)ceil(umin - 0.5 - e), x1 = (int)floor(umax + 0.5 + e);
       const int y0 = (int)ceil(vmin - 0.5 - e), y1 = (int)floor(vmax + 0.5 + e);
+      cls = BRICK_MIXED | (MIXED_IMAGE_BORDER << 2);
       if (x1 < 0 || y1 < 0 || x0 >= a.W || y0 >= a.H) {
         cls = BRICK_SKIP;  // every voxel projects outside the map (cu:192-197)
       } else if (x0 >= 0 && y0 >= 0 && x1 < a.W && y1 < a.H) {
         const TileAcc d = pyramid_query<kQueryTiles>(mr->pyramid, P, x0, x1, y0, y1);
+        cls = BRICK_MIXED | (MIXED_NAN_DEPTH << 2);
         if (!(d.flags & TILE_HAS_NAN)) {
+          cls = BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2);
           if (!(d.flags & TILE_HAS_VALID)) {
             cls = BRICK_SKIP;  // only "no depth" pixels (cu:202)
           } else if (!(d.flags & TILE_HAS_SENTINEL)) {
+            cls = BRICK_MIXED | (MIXED_NEAR_SURFACE << 2);
             if ((czmax - (double)d.dmin) < -a.delta)
               cls = BRICK_FREE;  // cu:114-115: |diff| > delta and diff < 0 for every voxel
             else if ((czmin - (double)d.dmax) > a.delta)
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   const uint8_t cls = classify_box<5>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
                                    bz0 * tk + 31);
   coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] = cls;
-  if (cls == BRICK_MIXED) return;  // the fine pass decides brick by brick
+  if ((cls & 3) == BRICK_MIXED) return;  // the fine pass decides brick by brick
   for (int dz = 0; dz < per_z; ++dz) {
     const int bz = bz0 + dz;
     if (bz >= bz_first + bz_count) break;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   const int cbx = local % cx_n;
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
-  if (coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] != BRICK_MIXED) return;
+  if ((coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] & 3) != BRICK_MIXED) return;
   const int child = lane % children;
   const int bx = cbx * 4 + (child & 3), by = cby * 4 + ((child >> 2) & 3), bz = cbz * per_z + (child >> 4);
   if (bx >= a.wbricks_x || by >= a.wbricks_y || bz >= bz_first + bz_count) return;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int w
       const int wbx = bx * wx + u, wby = by * wy + v;
       if (wbx >= a.wbricks_x || wby >= a.wbricks_y) continue;
       const uint8_t *row = a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch;
-      for (int m = a.first_map + lane; m < a.first_map + a.n_maps; m += 64) mixed += row[m] == BRICK_MIXED ? 1 : 0;
+      for (int m = a.first_map + lane; m < a.first_map + a.n_maps; m += 64) mixed += (row[m] & 3) == BRICK_MIXED ? 1 : 0;
       total += a.n_maps;
     }
   for (int off = 32; off > 0; off >>= 1) mixed += __shfl_xor(mixed, off, 64);

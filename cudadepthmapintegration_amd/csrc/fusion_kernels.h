@@ -128,6 +128,17 @@ enum BrickClass : uint8_t {
   BRICK_SKIP = 3     // no voxel reaches cu:211 (behind the camera cu:177, outside the map cu:192, no depth cu:202)
 };
 
+// Why a (brick, view) pair could not be proven uniform: stored in bits 2..4 of a BRICK_MIXED class byte (diagnostic)
+enum MixedReason : uint8_t {
+  MIXED_UNSPECIFIED = 0,
+  MIXED_DEGENERATE = 1,          // a non-finite c.z or pixel coordinate at a corner
+  MIXED_CAMERA_PLANE = 2,        // c.z changes sign over the brick or comes too close to 0 for the footprint bound
+  MIXED_IMAGE_BORDER = 3,        // the footprint is partly outside the depth map
+  MIXED_NAN_DEPTH = 4,           // a NaN depth in the footprint's tiles
+  MIXED_SENTINEL_AND_DEPTH = 5,  // both "no depth" pixels and depths in the footprint's tiles
+  MIXED_NEAR_SURFACE = 6         // the depths of the footprint's tiles come within delta of the brick's c.z range
+};
+
 struct FuseConfig {
   int depth_is_f64;
   int grid_is_f64;

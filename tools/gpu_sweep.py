@@ -59,7 +59,7 @@ def main():
             rec = {"workload": args.workload, "scene": sc, "variant": v, "k_mode": int(ctxs[v].info().k_mode),
                    "median_ms": float(np.median(t)), "min_ms": float(t.min()),
                    "gproj_per_s_median": proj / np.median(t) / 1e6, "gen_s": gen_s,
-                   "tiled": int(ctxs[v].info().tiled_kernel), "brick_classes": ctxs[v].brick_class_histogram()}
+                   "tiled": int(ctxs[v].info().tiled_kernel), "brick_classes": ctxs[v].brick_class_histogram(), "mixed_reasons": ctxs[v].mixed_reason_histogram()}
             results.append(rec)
             print(json.dumps(rec), flush=True)
         for c in ctxs.values():
