@@ -50,7 +50,7 @@ struct dmi_context {
 
   void *d_grid = nullptr;
   bool own_grid = false;
-  bool grid_is_zero = false;
+  std::vector<uint8_t> layer_is_zero;  // per cell layer: known to hold +0.0 everywhere (reset, not fused since)
   bool zero_fill_pending = false;  // reset requested, memset deferred: the next fuse overwrites every voxel
   uint32_t *d_voxel_hits = nullptr;
   unsigned long long *d_map_hits = nullptr;
@@ -613,7 +613,7 @@ int dmi_reset_grid(dmi_context *ctx) {
   if (ctx->d_voxel_hits) DMI_HIP(ctx, hipMemsetAsync(ctx->d_voxel_hits, 0, ctx->n_voxels * sizeof(uint32_t), ctx->stream));
   if (ctx->d_map_hits)
     DMI_HIP(ctx, hipMemsetAsync(ctx->d_map_hits, 0, ctx->map_hits_capacity * sizeof(unsigned long long), ctx->stream));
-  ctx->grid_is_zero = true;
+  ctx->layer_is_zero.assign((size_t)ctx->grid.cell_dims[2], 1);
   ctx->points_valid = false;
   return DMI_OK;
 }
@@ -631,7 +631,7 @@ int dmi_upload_grid(dmi_context *ctx, const double *grid) {
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_grid, narrow.data(), ctx->n_voxels * 4, hipMemcpyHostToDevice, ctx->stream));
     DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  ctx->grid_is_zero = false;
+  ctx->layer_is_zero.assign((size_t)ctx->grid.cell_dims[2], 0);
   ctx->points_valid = false;
   return DMI_OK;
 }
@@ -682,7 +682,11 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   a.H = ctx->H;
   a.first_map = first;
   a.n_maps = count;
-  a.init_from_grid = ctx->grid_is_zero ? 0 : 1;
+  // the layers being fused start from the grid's values unless all of them are known to be zero (a slab fuse leaves
+  // the other layers as they were, so zero-ness is tracked per layer)
+  a.init_from_grid = 0;
+  for (int32_t z = z_first; z < z_first + z_count; ++z)
+    if (!ctx->layer_is_zero[(size_t)z]) a.init_from_grid = 1;
   a.kz0 = ctx->opt.z_first;
   a.k_first = z_first;
   a.k_count = z_count;
@@ -853,7 +857,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   ctx->pending.push_back(ev);
   // after a whole-grid fuse every voxel has been written; after a slab fuse the other layers still hold what they
   // held (zeros after a reset): later fuses read the grid, which is correct either way
-  ctx->grid_is_zero = false;
+  for (int32_t z = z_first; z < z_first + z_count; ++z) ctx->layer_is_zero[(size_t)z] = 0;
   ctx->zero_fill_pending = false;
   ctx->points_valid = false;
   if (ctx->pending.size() >= 256) return drain_events(ctx);
