@@ -115,6 +115,36 @@ def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int 
             "value_call": n_vertices * n_views / dt / 1e9, "mean_views_per_vertex": float(count.mean())}
 
 
+def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, chunk_views: int = 32):
+    """PCIe-inclusive rate (never the headline value): depth tables start in pinned host memory, go up chunk by chunk on
+    the context's upload stream while the previous chunk is being fused (dmi_add_views + dmi_fuse_range), and the grid
+    comes back into pinned host memory.  host f64 / grid f64 is the reference's contract (vtkDoubleArray in and out)."""
+    n = views.n
+    np_host = np.float64 if host_dtype == "f64" else np.float32
+    np_grid = np.float64 if grid_dtype == "f64" else np.float32
+    pinned = capi.pinned_empty(views.depth.shape, np_host)
+    pinned[:] = views.depth
+    out = capi.pinned_empty((grid.n_voxels,), np_grid)
+    times = []
+    with capi.FusionContext(grid, ray, grid_dtype=grid_dtype, depth_storage="auto") as c:
+        for rep in range(3):
+            c.clear_views()
+            c.reset_grid()
+            c.synchronize()
+            t0 = time.perf_counter()
+            for v0 in range(0, n, chunk_views):
+                v1 = min(n, v0 + chunk_views)
+                c.add_views(scene.Views(pinned[v0:v1], views.K4[v0:v1], views.RT4[v0:v1]))
+                c.fuse(v0, v1 - v0)
+            c.download_grid(np_grid, out=out)
+            times.append(time.perf_counter() - t0)
+    dt = float(np.median(times[1:]))
+    moved = pinned.nbytes + out.nbytes
+    return {"host_depth": host_dtype, "grid": grid_dtype, "seconds": dt, "value": grid.n_voxels * n / dt / 1e9,
+            "unit": "Gvoxel-projections/s including H2D of every depth table and D2H of the grid",
+            "pcie_bytes": moved, "pcie_GBps_if_alone": moved / dt / 1e9, "chunk_views": chunk_views}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +163,7 @@ def main():
     ap.add_argument("--coloration-vertices", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--secondary", action="store_true", help="also time the other scene variant (N = 1)")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -347,6 +378,9 @@ def main():
         out["secondary"] = secondary
     if cell_to_point:
         out["cell_to_point"] = cell_to_point
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        out["end_to_end"] = [end_to_end_probe(scene, capi, grid, ray, views, "f32", "f32"),
+                             end_to_end_probe(scene, capi, grid, ray, views, "f64", "f64")]
     if rank == 0 and world == 1 and not args.no_coloration:
         out["coloration"] = coloration_probe(scene, capi, args.coloration_vertices, W, H)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

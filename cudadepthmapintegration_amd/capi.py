@@ -143,6 +143,19 @@ def load() -> ctypes.CDLL:
     return L
 
 
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """A numpy array over pinned host memory (dmi_alloc_pinned): hipMemcpyAsync from it is a DMA transfer that overlaps
+    with kernels.  Never freed by this helper's user explicitly: the block lives until the process ends."""
+    L = load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = ctypes.c_void_p()
+    rc = L.dmi_alloc_pinned(n, ctypes.byref(p))
+    if rc != DMI_OK:
+        raise DmiError(rc, "dmi_alloc_pinned failed")
+    buf = (ctypes.c_char * n).from_address(p.value)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 def device_count() -> int:
     return int(load().dmi_device_count())
 
@@ -254,13 +267,16 @@ class FusionContext:
     def synchronize(self):
         self._check(self._lib.dmi_synchronize(self._h))
 
-    def download_grid(self, dtype=np.float64) -> np.ndarray:
+    def download_grid(self, dtype=np.float64, out: np.ndarray | None = None) -> np.ndarray:
+        """The grid as [nz, ny, nx]; `out` (flat, contiguous, e.g. from pinned_empty) receives it when given."""
         nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        if out is None:
+            out = np.empty(self.n_voxels, dtype=dtype)
+        if out.dtype != np.dtype(dtype) or out.size != self.n_voxels or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous array of n_voxels elements of the requested dtype")
         if np.dtype(dtype) == np.float64:
-            out = np.empty(self.n_voxels, dtype=np.float64)
             self._check(self._lib.dmi_download_grid_f64(self._h, _dp(out)))
         else:
-            out = np.empty(self.n_voxels, dtype=np.float32)
             self._check(self._lib.dmi_download_grid_f32(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         return out.reshape(nz, ny, nx)
 

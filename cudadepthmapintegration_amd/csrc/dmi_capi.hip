@@ -47,6 +47,9 @@ struct dmi_context {
 
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // dmi_add_views copies, converts and builds pyramids on a stream of its own and waits for that stream only: a fuse
+  // still running on `stream` overlaps the upload of the next views (FusionDriver::ProcessDepthMap pipelines on this)
+  hipStream_t upload_stream = nullptr;
 
   void *d_grid = nullptr;
   bool own_grid = false;
@@ -215,31 +218,31 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   const size_t chunk = std::min<size_t>(maps_per_chunk, (size_t)n);
   rc = ensure_stage(ctx, chunk * npix, best_cost != nullptr);
   if (rc == DMI_OK) {
-    hipError_t e = hipMemsetAsync(ctx->d_lossy, 0, sizeof(unsigned long long), ctx->stream);
+    hipError_t e = hipMemsetAsync(ctx->d_lossy, 0, sizeof(unsigned long long), ctx->upload_stream);
     for (size_t m0 = 0; e == hipSuccess && m0 < (size_t)n; m0 += chunk) {
       const size_t cnt = std::min(chunk, (size_t)n - m0);
       const char *src = depth32 ? reinterpret_cast<const char *>(depth32) : reinterpret_cast<const char *>(depth64);
       e = hipMemcpyAsync(ctx->d_stage_depth, src + m0 * npix * in_elem, cnt * npix * in_elem, hipMemcpyHostToDevice,
-                         ctx->stream);
+                         ctx->upload_stream);
       if (e == hipSuccess && best_cost)
-        e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->upload_stream);
       void *dst = static_cast<char *>(b.d_depth) + m0 * npix * esz;
       if (e == hipSuccess) {
         if (depth32)
           e = dmi::launch_flip_depth_f32(reinterpret_cast<const float *>(ctx->d_stage_depth), dst, ctx->depth_f64 ? 1 : 0,
-                                         (int64_t)cnt, ctx->W, ctx->H, ctx->stream);
+                                         (int64_t)cnt, ctx->W, ctx->H, ctx->upload_stream);
         else
           e = dmi::launch_convert_depth(ctx->d_stage_depth, best_cost ? ctx->d_stage_cost : nullptr, threshold, dst,
-                                        ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->d_lossy, ctx->stream);
+                                        ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->d_lossy, ctx->upload_stream);
       }
     }
     // depth bounds per 8x8 ... image-sized tile of every table: what the brick classification reads
     if (e == hipSuccess)
       e = dmi::launch_build_pyramids(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H, ctx->pyramid, b.d_pyramid,
-                                     ctx->stream);
+                                     ctx->upload_stream);
     if (e == hipSuccess)
-      e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->upload_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->upload_stream);
     if (e != hipSuccess) rc = fail(ctx, DMI_ERR_DEVICE, std::string("depth upload: ") + hipGetErrorString(e));
   }
   if (rc != DMI_OK) {
@@ -502,6 +505,8 @@ int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dm
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     ctx->own_stream = true;
   }
+  e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(upload)");
   if (o.external_grid) {
     hipPointerAttribute_t attr;
     e = hipPointerGetAttributes(&attr, o.external_grid);
@@ -539,6 +544,10 @@ void dmi_destroy(dmi_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->opt.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->upload_stream) {
+    (void)hipStreamSynchronize(ctx->upload_stream);
+    (void)hipStreamDestroy(ctx->upload_stream);
+  }
   for (Batch &b : ctx->batches) {
     (void)hipFree(b.d_depth);
     (void)hipFree(b.d_pyramid);
@@ -770,15 +779,19 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
         ctx->d_cz_table = nullptr;
         ctx->cz_table_capacity = 0;
       }
-      DMI_HIP(ctx, hipMalloc(&ctx->d_cz_table, need * 8));
-      ctx->cz_table_capacity = need;
-      ctx->device_bytes += need * 8;
+      const size_t grown = need * 2;  // views often arrive in chunks: grow geometrically
+      DMI_HIP(ctx, hipMalloc(&ctx->d_cz_table, grown * 8));
+      ctx->cz_table_capacity = grown;
+      ctx->device_bytes += grown * 8;
     }
     t.cz_table = ctx->d_cz_table;
     // brick classes: one byte per (8 x 8 x column wave brick, resident view)
     t.wbricks_x = (a.nx + 7) / 8;
     t.wbricks_y = (a.ny + 7) / 8;
-    t.class_pitch = (n_views + 15) / 16 * 16;
+    // row pitch of the class tables: a power of two >= 64 views, so that views arriving in chunks (add, fuse, add,
+    // fuse ...) change the layout -- and force a reallocation, which waits for the device -- only at doublings
+    t.class_pitch = 64;
+    while (t.class_pitch < n_views) t.class_pitch *= 2;
     if (!(cfg.variant & dmi::VAR_NO_BRICK_CLASSES)) {
       const size_t fine_bytes = ((size_t)t.wbricks_x * t.wbricks_y * t.bricks_z * (size_t)t.class_pitch + 255) / 256 * 256;
       // the coarse table (one row per box of 32^3 voxels) lives behind the brick table in the same allocation

@@ -292,7 +292,10 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
   if (!all_zero && dmi_upload_grid(ctx, io_scalar) != DMI_OK) return fail("dmi_upload_grid");
 
   // Views go up as a pinned structure-of-arrays ([n][H][W] depth, [n][H][W] best cost, [n][16] K, [n][16] RT),
-  // a chunk of at most ~256 MiB at a time; dmi_add_views copies from it with hipMemcpyAsync.
+  // a chunk of at most ~256 MiB at a time; dmi_add_views copies from it with hipMemcpyAsync on the context's upload
+  // stream and returns when the chunk is resident.  Each chunk is fused as soon as it is up (dmi_fuse_range,
+  // asynchronous on the compute stream), so the fusion of chunk i runs while chunk i+1 is packed and copied; every
+  // voxel still accumulates its views in order (cu:211), the f64 grid makes the chunking invisible in the result.
   const size_t chunk = std::max<size_t>(1, std::min(views.size(), (size_t(256) << 20) / std::max<size_t>(1, npix * 16)));
   double *p_depth = nullptr, *p_cost = nullptr;
   void *pv = nullptr;
@@ -341,6 +344,12 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
     if (rc != DMI_OK) {
       Error = std::string("dmi_add_views: ") + dmi_last_error(ctx);
       ok = false;
+      break;
+    }
+    rc = dmi_fuse_range(ctx, (int32_t)v0, (int32_t)cnt);  // replaces the kernel launches of these views (cu:363)
+    if (rc != DMI_OK) {
+      Error = std::string("dmi_fuse_range: ") + dmi_last_error(ctx);
+      ok = false;
     }
   }
   dmi_free_pinned(p_depth);
@@ -349,8 +358,7 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
     dmi_destroy(ctx);
     return false;
   }
-  if (dmi_fuse(ctx) != DMI_OK) return fail("dmi_fuse");
-  if (dmi_download_grid_f64(ctx, io_scalar) != DMI_OK) return fail("dmi_download_grid_f64");  // cu:368-371
+  if (dmi_download_grid_f64(ctx, io_scalar) != DMI_OK) return fail("dmi_download_grid_f64");  // cu:368-371 (synchronises)
   dmi_timings t;
   if (dmi_get_timings(ctx, &t) == DMI_OK) FuseKernelMs = t.total_fuse_kernel_ms;
   dmi_destroy(ctx);

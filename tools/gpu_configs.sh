@@ -10,7 +10,7 @@ OUT=gpurun_out/configs_$TAG.jsonl
 run() {  # name, extra args...
   local name=$1; shift
   echo "== $name $*" >&2
-  timeout -k 10 600 python bench.py --steps 5 --warmup 2 --no-ablation --no-coloration "$@" 2> gpurun_out/configs_$TAG.$name.err | tail -1 > gpurun_out/configs_$TAG.$name.json
+  timeout -k 10 600 python bench.py --steps 5 --warmup 2 --no-ablation --no-coloration --no-end-to-end "$@" 2> gpurun_out/configs_$TAG.$name.err | tail -1 > gpurun_out/configs_$TAG.$name.json
   local rc=$?
   if [ -s gpurun_out/configs_$TAG.$name.json ]; then
     python - "$name" gpurun_out/configs_$TAG.$name.json >> $OUT <<'PY'
