@@ -33,6 +33,13 @@ def z_slab(nz: int, rank: int, world: int, multiple: int = 1) -> tuple[int, int]
     return min(lo * multiple, nz), min(hi * multiple, nz)
 
 
+def vertex_shard(n_vertices: int, rank: int, world: int) -> tuple[int, int]:
+    """MeshColoration on several GPUs (BASELINE config 5): every rank holds all views (dmi_color_context) and colours
+    the vertices [lo, hi); the three output arrays are concatenated in rank order.  No exchange step: a vertex's mean,
+    median and count depend on that vertex alone (Coloration/MeshColoration.cxx:140-192)."""
+    return view_shard(n_vertices, rank, world)
+
+
 def all_reduce_grid(grid_tensor, group=None):
     """The path's single exchange step: sum the per-rank TSDF grids in place (RCCL ring/direct over xGMI
     on GPUs, gloo in the CPU tests).  Also used for the integer hit counters."""

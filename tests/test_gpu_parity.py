@@ -445,3 +445,40 @@ def test_overlapped_fuse_and_all_reduce_single_rank(tmp_path):
         assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)) and np.abs(plain).max() > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_diagnostics_and_layer_tracking():
+    """dmi_get_mixed_reason_histogram accounts for every mixed pair; a slab fused after a reset starts from zero (no grid
+    read, +0.0 adds skipped) while a slab fused after an upload accumulates onto the uploaded values -- same bits as the
+    oracle either way; download into a caller's (pinned) buffer."""
+    grid = scene.default_grid((64, 64, 64))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(7, 160, 120, seed=9, dense=False)
+    views.depth[3, 30:34, 40:44] = np.nan
+    p = oracle_params_from_scene(grid, rp, views)
+    with np.errstate(all="ignore"):
+        want, _, _ = oracle.fuse(p, views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())
+    out = capi.pinned_empty((grid.n_voxels,), np.float64)
+    with capi.FusionContext(grid, rp) as ctx:
+        ctx.add_views(views)
+        ctx.fuse_slab(32, 32)          # upper half first, then the lower one: both from a fresh grid
+        ctx.fuse_slab(0, 32)
+        got = ctx.download_grid(np.float64, out=out)
+        assert got.base is not None and bits_equal(got, want)
+        hist, why = ctx.brick_class_histogram(), ctx.mixed_reason_histogram()
+        # both slabs have been classified: the table holds all 8 x 8 x 8 bricks of 8 voxels
+        assert sum(hist.values()) == 8 * 8 * 8 * views.n and sum(why.values()) == hist["mixed"]
+        assert why["image_border"] > 0 and why["sentinel_and_depth"] > 0 and why["unspecified"] == 0
+        ctx.fuse()
+        assert ctx.mixed_reason_histogram()["nan_depth"] > 0     # view 3's NaN patch lands in some footprint
+        init = np.random.default_rng(2).normal(size=(64, 64, 64))
+        init[:8] = -0.0
+        ctx.upload_grid(init)
+        ctx.fuse_slab(0, 32)
+        ctx.fuse_slab(32, 32)
+        with np.errstate(all="ignore"):
+            want2, _, _ = oracle.fuse(p, views.depth, views.K4, views.RT4, init_grid=init, n_threads=oracle.max_threads())
+        assert bits_equal(ctx.download_grid(), want2)
+    with pytest.raises(ValueError):
+        with capi.FusionContext(grid, rp) as ctx:
+            ctx.download_grid(np.float64, out=np.zeros(5))

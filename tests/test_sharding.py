@@ -105,3 +105,47 @@ def test_view_shards_plus_all_reduce_match_single_fusion(tmp_path):
     assert np.abs(want).max() > 0.1
     slabs = [tuple(np.load(tmp_path / f"slab_{r}.npy")) for r in range(world)]
     assert slabs[0][0] == 0 and slabs[-1][1] == 20 and slabs[0][1] == slabs[1][0] and slabs[0][1] % 8 == 0
+
+
+def _color_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    views = scene.make_views(6, 48, 36, seed=3)
+    colors = scene.make_colors(6, 48, 36, seed=4)
+    pts = scene.make_mesh_points(501, seed=5)
+    lo, hi = sharding.vertex_shard(len(pts), rank, world)          # every rank: all views, its own vertices
+    mean, median, count = oracle.color_mesh(pts[lo:hi], colors, views.K4, views.RT4)
+    # the only "exchange" is the concatenation of the rank results (a gather to whoever writes the mesh)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, mean, median, count))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "colored.npz"), mean=np.concatenate([g[2] for g in gathered]),
+                 median=np.concatenate([g[3] for g in gathered]), count=np.concatenate([g[4] for g in gathered]),
+                 bounds=np.array([[g[0], g[1]] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vertex_shards_of_the_coloration_pass_concatenate_to_the_whole(tmp_path):
+    """BASELINE config 5's coloration pass on several GPUs: vertex shards, no collective on the data path."""
+    import torch.multiprocessing as mp
+
+    from oracle import oracle
+
+    world = 2
+    mp.spawn(_color_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    views = scene.make_views(6, 48, 36, seed=3)
+    colors = scene.make_colors(6, 48, 36, seed=4)
+    pts = scene.make_mesh_points(501, seed=5)
+    want = oracle.color_mesh(pts, colors, views.K4, views.RT4)
+    got = np.load(tmp_path / "colored.npz")
+    assert got["bounds"].tolist() == [[0, 251], [251, 501]]
+    for name, w in zip(("mean", "median", "count"), want):
+        assert np.array_equal(got[name], w), name
