@@ -49,7 +49,8 @@ class OptionsC(ctypes.Structure):
 class TimingsC(ctypes.Structure):
     _fields_ = [("last_fuse_kernel_ms", ctypes.c_double), ("total_fuse_kernel_ms", ctypes.c_double),
                 ("fuse_launches", ctypes.c_uint64), ("last_upload_ms", ctypes.c_double),
-                ("last_download_ms", ctypes.c_double), ("last_cell_to_point_ms", ctypes.c_double)]
+                ("last_download_ms", ctypes.c_double), ("last_cell_to_point_ms", ctypes.c_double),
+                ("last_fuse_main_kernel_ms", ctypes.c_double), ("total_fuse_main_kernel_ms", ctypes.c_double)]
 
 
 class InfoC(ctypes.Structure):

@@ -174,7 +174,8 @@ hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t 
 // Tiled kernel: fills args.cz_table for maps [first_map, first_map + n_maps) and fuses them.
 // args.full must point to a device copy of the matching FuseArgs (read by the exact fallback).
 hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
-                             uint8_t *order_scratch, uint8_t *coarse_classes, hipStream_t stream);
+                             uint8_t *order_scratch, uint8_t *coarse_classes, hipEvent_t before_main_kernel,
+                             hipStream_t stream);
 
 // depth upload helpers ------------------------------------------------------------------
 // out[row-flipped i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64, n_maps

@@ -96,12 +96,16 @@ typedef struct dmi_options {
 } dmi_options;
 
 typedef struct dmi_timings {
-  double last_fuse_kernel_ms; /* hipEvent time of the fusion kernel of the last dmi_fuse, on its stream */
+  double last_fuse_kernel_ms; /* hipEvent time of all launches of the last dmi_fuse, on its stream */
   double total_fuse_kernel_ms;
   uint64_t fuse_launches;
   double last_upload_ms; /* host wall time of the last dmi_add_views (copy + convert, synchronised) */
   double last_download_ms;
   double last_cell_to_point_ms; /* hipEvent time of the last dmi_cell_to_point kernel */
+  /* of last_fuse_kernel_ms / total_fuse_kernel_ms, the fusion kernel proper (without the cz table, the brick
+   * classification and the workgroup ordering that precede it) */
+  double last_fuse_main_kernel_ms;
+  double total_fuse_main_kernel_ms;
 } dmi_timings;
 
 typedef struct dmi_info {
