@@ -106,13 +106,19 @@ __global__ __launch_bounds__(256) void pyramid_up_kernel(int64_t n_maps, int lev
 // bounds of the depth values in pixels [x0, x1] x [y0, y1] (inside the image): the finest level whose tiles cover the
 // range with at most kQueryTiles x kQueryTiles of them.  Finer tiles hug the footprint more closely (a 2 x 2 cover can
 // reach over 4 to 16 times the footprint's area and pull a silhouette in that no voxel of the box projects onto).
+// index (0 = finest kept) of the finest pyramid level at which `extent` pixels span at most kQueryTiles tiles per axis:
+// tiles of 2^L pixels, a range of `extent` pixels touches at most (extent - 1) / 2^L + 2 of them
+template <int kQueryTiles>
+__device__ __forceinline__ int query_level(const PyramidDesc &P, int extent) {
+  int li = 0;
+  while (li + 1 < P.n_levels && ((extent - 1) >> (kPyramidMinLevel + li)) + 2 > kQueryTiles) ++li;
+  return li;
+}
+
 template <int kQueryTiles>
 __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ pyr, const PyramidDesc &P, int x0, int x1,
                                                  int y0, int y1) {
-  const int extent = max(x1 - x0, y1 - y0) + 1;
-  // tiles of 2^L pixels: a range of `extent` pixels touches at most (extent - 1) / 2^L + 2 of them per axis
-  int li = 0;
-  while (li + 1 < P.n_levels && ((extent - 1) >> (kPyramidMinLevel + li)) + 2 > kQueryTiles) ++li;
+  const int li = query_level<kQueryTiles>(P, max(x1 - x0, y1 - y0) + 1);
   const int L = kPyramidMinLevel + li;
   TileAcc acc;
   const int tx0 = x0 >> L, tx1 = x1 >> L, ty0 = y0 >> L, ty1 = y1 >> L;  // more than kQueryTiles only at the top level
@@ -124,10 +130,21 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
 // What the reference does to EVERY voxel centre of the box [i0, i1] x [j0, j1] x [k0, k1] (cell indices, inclusive; the
 // box may stick out of the grid: a superset is conservative) for one view, if that can be proven;
 // BRICK_MIXED otherwise.  A class proven for a box holds for every box inside it.
-template <int kQueryTiles>
-__device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
-                                                const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
-                                                int j0, int j1, int k0, int k1) {
+// Part 1, everything that needs no depth: either the class is settled (`query` false), or the depth bounds over the
+// pixel rectangle [x0, x1] x [y0, y1] (inside the image) decide it together with [czmin, czmax] (class_from_bounds).
+struct BoxFootprint {
+  uint8_t cls;
+  bool query;
+  int x0, x1, y0, y1;
+  double czmin, czmax;
+};
+
+__device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const MapRec *__restrict__ mr,
+                                                      const TileMapRec *__restrict__ tr, int i0, int i1, int j0, int j1, int k0,
+                                                      int k1) {
+  BoxFootprint fp;
+  fp.query = false;
+  fp.x0 = fp.x1 = fp.y0 = fp.y1 = 0;
   // World coordinates of the box's faces (cu:78-83 + cu:168).  With the axis-aligned grid the tiled kernel requires,
   // wx depends on i only, wy on j, wz on k (fusion_tile.hip), so the eight corners share six values.
   double wxs[2], wys[2], wzs[2];
@@ -197,24 +214,37 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
       if (x1 < 0 || y1 < 0 || x0 >= a.W || y0 >= a.H) {
         cls = BRICK_SKIP;  // every voxel projects outside the map (cu:192-197)
       } else if (x0 >= 0 && y0 >= 0 && x1 < a.W && y1 < a.H) {
-        const TileAcc d = pyramid_query<kQueryTiles>(mr->pyramid, P, x0, x1, y0, y1);
-        cls = BRICK_MIXED | (MIXED_NAN_DEPTH << 2);
-        if (!(d.flags & TILE_HAS_NAN)) {
-          cls = BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2);
-          if (!(d.flags & TILE_HAS_VALID)) {
-            cls = BRICK_SKIP;  // only "no depth" pixels (cu:202)
-          } else if (!(d.flags & TILE_HAS_SENTINEL)) {
-            cls = BRICK_MIXED | (MIXED_NEAR_SURFACE << 2);
-            if ((czmax - (double)d.dmin) < -a.delta)
-              cls = BRICK_FREE;  // cu:114-115: |diff| > delta and diff < 0 for every voxel
-            else if ((czmin - (double)d.dmax) > a.delta)
-              cls = BRICK_BEHIND;  // cu:114-115: diff > delta for every voxel
-          }
-        }
+        fp.query = true;
+        fp.x0 = x0;
+        fp.x1 = x1;
+        fp.y0 = y0;
+        fp.y1 = y1;
       }
     }
   }
-  return cls;
+  fp.cls = cls;
+  fp.czmin = czmin;
+  fp.czmax = czmax;
+  return fp;
+}
+
+// Part 2: the class that depth bounds `d` over (a superset of) the footprint prove for c.z in [czmin, czmax]
+__device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const TileAcc &d, double czmin, double czmax) {
+  if (d.flags & TILE_HAS_NAN) return BRICK_MIXED | (MIXED_NAN_DEPTH << 2);
+  if (!(d.flags & TILE_HAS_VALID)) return BRICK_SKIP;  // only "no depth" pixels (cu:202)
+  if (d.flags & TILE_HAS_SENTINEL) return BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2);
+  if ((czmax - (double)d.dmin) < -a.delta) return BRICK_FREE;    // cu:114-115: |diff| > delta and diff < 0 for every voxel
+  if ((czmin - (double)d.dmax) > a.delta) return BRICK_BEHIND;   // cu:114-115: diff > delta for every voxel
+  return BRICK_MIXED | (MIXED_NEAR_SURFACE << 2);
+}
+
+template <int kQueryTiles>
+__device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
+                                                const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
+                                                int j0, int j1, int k0, int k1) {
+  const BoxFootprint fp = box_footprint(a, mr, tr, i0, i1, j0, j1, k0, k1);
+  if (!fp.query) return fp.cls;
+  return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
 }
 
 // Coarse pass: one thread per (box of 32 x 32 x 32 voxels = 4 x 4 x 32/tk wave bricks, view).  Most of the volume is far
@@ -259,10 +289,16 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
 // 16-voxel columns 4 x 4 x 2, and the wave's upper half takes the next view), so a wave either has nothing to do or
 // works with all its lanes.  A block is four waves = four (eight) consecutive views of one box: their byte stores
 // land in the same cache lines.
+// With one view per wave the footprints of the 64 bricks tile the box's footprint: the wave stages that window of
+// the view's min/max pyramid in LDS once (coalesced rows of tiles) and every lane reduces its own tiles from there,
+// instead of 64 lanes gathering 4 to 25 tiles each from global memory.
+constexpr int kWindow = 16;  // tiles per axis of the staged window
+
 template <int kQueryTiles>
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                        const uint8_t *__restrict__ coarse) {
+  __shared__ DepthTile window[4][kWindow * kWindow];
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
   const int per_z = 32 / tk;
@@ -271,19 +307,65 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   const int children = 16 * per_z;          // 64 or 32
   const int views_per_wave = 64 / children;  // 1 or 2
   const int mm = (blockIdx.y * 4 + wave) * views_per_wave + lane / children;
-  if (mm >= a.n_maps) return;
-  const int m = a.first_map + mm;
   const int local = blockIdx.x;  // box within the slab
   const int cbx = local % cx_n;
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
-  if ((coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] & 3) != BRICK_MIXED) return;
   const int child = lane % children;
   const int bx = cbx * 4 + (child & 3), by = cby * 4 + ((child >> 2) & 3), bz = cbz * per_z + (child >> 4);
-  if (bx >= a.wbricks_x || by >= a.wbricks_y || bz >= bz_first + bz_count) return;
-  classes[(int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m] =
-      classify_box<kQueryTiles>(a, maps + m, a.tile_maps + m, P, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk,
-                                         bz * tk + tk - 1);
+  const int m = a.first_map + min(mm, a.n_maps - 1);
+  const bool mine = mm < a.n_maps && bx < a.wbricks_x && by < a.wbricks_y && bz < bz_first + bz_count &&
+                    (coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] & 3) == BRICK_MIXED;
+  if (__builtin_amdgcn_ballot_w64(mine) == 0) return;  // the whole wave: proven by the coarse pass, or no such view
+  const MapRec *__restrict__ mr = maps + m;
+  BoxFootprint fp;
+  fp.query = false;
+  fp.cls = BRICK_SKIP;
+  if (mine) fp = box_footprint(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+  const bool query = mine && fp.query;
+  uint8_t cls = fp.cls;
+  const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
+  bool from_window = false;
+  if (views_per_wave == 1) {
+    // the finest level any lane asks for, and the window of its tiles that covers those lanes' rectangles
+    int li_w = li;
+    for (int off = 32; off > 0; off >>= 1) li_w = min(li_w, __shfl_xor(li_w, off, 64));
+    if (li_w != 0x7fff) {
+      const int L = kPyramidMinLevel + li_w;
+      const bool at_level = query && li == li_w;
+      int tx0 = at_level ? fp.x0 >> L : 0x7fffffff, ty0 = at_level ? fp.y0 >> L : 0x7fffffff;
+      int tx1 = at_level ? fp.x1 >> L : -1, ty1 = at_level ? fp.y1 >> L : -1;
+      int wx0 = tx0, wy0 = ty0, wx1 = tx1, wy1 = ty1;
+      for (int off = 32; off > 0; off >>= 1) {
+        wx0 = min(wx0, __shfl_xor(wx0, off, 64));
+        wy0 = min(wy0, __shfl_xor(wy0, off, 64));
+        wx1 = max(wx1, __shfl_xor(wx1, off, 64));
+        wy1 = max(wy1, __shfl_xor(wy1, off, 64));
+      }
+      if (wx1 - wx0 < kWindow && wy1 - wy0 < kWindow) {  // wave-uniform
+        const DepthTile *__restrict__ level = mr->pyramid + P.offset[li_w];
+        const int pitch = P.width[li_w];
+        const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+        for (int t = lane; t < ww * wh; t += 64) {
+          const int ty = t / ww, tx = t - ty * ww;
+          window[wave][ty * kWindow + tx] = level[(wy0 + ty) * pitch + wx0 + tx];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (at_level) {
+          TileAcc d;
+          for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) d.add_tile(window[wave][(ty - wy0) * kWindow + (tx - wx0)]);
+          cls = class_from_bounds(a, d, fp.czmin, fp.czmax);
+          from_window = true;
+        }
+      }
+    }
+  }
+  if (query && !from_window)
+    cls = class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
+  if (mine) classes[(int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m] = cls;
 }
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
