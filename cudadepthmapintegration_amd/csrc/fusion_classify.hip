@@ -289,23 +289,24 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
 // 16-voxel columns 4 x 4 x 2, and the wave's upper half takes the next view), so a wave either has nothing to do or
 // works with all its lanes.  A block is four waves = four (eight) consecutive views of one box: their byte stores
 // land in the same cache lines.
-// With one view per wave the footprints of the 64 bricks tile the box's footprint: the wave stages that window of
-// the view's min/max pyramid in LDS once (coalesced rows of tiles) and every lane reduces its own tiles from there,
-// instead of 64 lanes gathering 4 to 25 tiles each from global memory.
+// The footprints of a box's bricks tile the box's footprint: the lanes of a view stage that window of the view's
+// min/max pyramid in LDS once (coalesced rows of tiles) and every lane reduces its own tiles from there, instead of
+// every lane gathering 4 to 25 tiles from global memory.
 constexpr int kWindow = 16;  // tiles per axis of the staged window
 
-template <int kQueryTiles>
+// kChildren: wave bricks per box = lanes per view, 64 (8-voxel columns) or 32 (16-voxel columns)
+template <int kQueryTiles, int kChildren>
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                        const uint8_t *__restrict__ coarse) {
-  __shared__ DepthTile window[4][kWindow * kWindow];
+  constexpr int children = kChildren;
+  constexpr int views_per_wave = 64 / children;  // 1 or 2
+  constexpr int per_z = children / 16;           // wave-brick layers per box = 32 / tk
+  __shared__ DepthTile window[4 * views_per_wave][kWindow * kWindow];  // one per (wave, view of the wave)
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
-  const int per_z = 32 / tk;
   const int cx_n = (a.wbricks_x + 3) / 4, cy_n = (a.wbricks_y + 3) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int children = 16 * per_z;          // 64 or 32
-  const int views_per_wave = 64 / children;  // 1 or 2
   const int mm = (blockIdx.y * 4 + wave) * views_per_wave + lane / children;
   const int local = blockIdx.x;  // box within the slab
   const int cbx = local % cx_n;
@@ -326,29 +327,31 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   uint8_t cls = fp.cls;
   const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
   bool from_window = false;
-  if (views_per_wave == 1) {
-    // the finest level any lane asks for, and the window of its tiles that covers those lanes' rectangles
+  {
+    // per view of the wave (its 64 or 32 lanes): the finest level any lane asks for, and the window of that level's
+    // tiles that covers those lanes' rectangles
+    DepthTile *__restrict__ win = window[wave * views_per_wave + lane / children];
     int li_w = li;
-    for (int off = 32; off > 0; off >>= 1) li_w = min(li_w, __shfl_xor(li_w, off, 64));
+    for (int off = children >> 1; off > 0; off >>= 1) li_w = min(li_w, __shfl_xor(li_w, off, 64));
     if (li_w != 0x7fff) {
       const int L = kPyramidMinLevel + li_w;
       const bool at_level = query && li == li_w;
       int tx0 = at_level ? fp.x0 >> L : 0x7fffffff, ty0 = at_level ? fp.y0 >> L : 0x7fffffff;
       int tx1 = at_level ? fp.x1 >> L : -1, ty1 = at_level ? fp.y1 >> L : -1;
       int wx0 = tx0, wy0 = ty0, wx1 = tx1, wy1 = ty1;
-      for (int off = 32; off > 0; off >>= 1) {
+      for (int off = children >> 1; off > 0; off >>= 1) {
         wx0 = min(wx0, __shfl_xor(wx0, off, 64));
         wy0 = min(wy0, __shfl_xor(wy0, off, 64));
         wx1 = max(wx1, __shfl_xor(wx1, off, 64));
         wy1 = max(wy1, __shfl_xor(wy1, off, 64));
       }
-      if (wx1 - wx0 < kWindow && wy1 - wy0 < kWindow) {  // wave-uniform
+      if (wx1 - wx0 < kWindow && wy1 - wy0 < kWindow) {  // uniform over the view's lanes
         const DepthTile *__restrict__ level = mr->pyramid + P.offset[li_w];
         const int pitch = P.width[li_w];
         const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
-        for (int t = lane; t < ww * wh; t += 64) {
+        for (int t = child; t < ww * wh; t += children) {
           const int ty = t / ww, tx = t - ty * ww;
-          window[wave][ty * kWindow + tx] = level[(wy0 + ty) * pitch + wx0 + tx];
+          win[ty * kWindow + tx] = level[(wy0 + ty) * pitch + wx0 + tx];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
         if (at_level) {
           TileAcc d;
           for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) d.add_tile(window[wave][(ty - wy0) * kWindow + (tx - wx0)]);
+            for (int tx = tx0; tx <= tx1; ++tx) d.add_tile(win[(ty - wy0) * kWindow + (tx - wx0)]);
           cls = class_from_bounds(a, d, fp.czmin, fp.czmax);
           from_window = true;
         }
@@ -518,16 +521,21 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   // cost more in this pass than they save in the next (profiles/r01zm_*)
   int q = 5;
   if (const char *env = getenv("DMI_QUERY_TILES")) q = atoi(env);  // tuning experiments
+  const bool wide = tk == 8;  // 64 bricks per box
+#define DMI_LAUNCH_FINE(Q)                                                                                              \
+  do {                                                                                                                   \
+    if (wide)                                                                                                            \
+      hipLaunchKernelGGL((classify_kernel<Q, 64>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((classify_kernel<Q, 32>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse); \
+  } while (0)
   if (q <= 2)
-    hipLaunchKernelGGL(classify_kernel<2>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+    DMI_LAUNCH_FINE(2);
   else if (q == 3)
-    hipLaunchKernelGGL(classify_kernel<3>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
-  else if (q <= 5)
-    hipLaunchKernelGGL(classify_kernel<5>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
-  else if (q <= 7)
-    hipLaunchKernelGGL(classify_kernel<7>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+    DMI_LAUNCH_FINE(3);
   else
-    hipLaunchKernelGGL(classify_kernel<9>, fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse);
+    DMI_LAUNCH_FINE(5);
+#undef DMI_LAUNCH_FINE
   return hipGetLastError();
 }
 
