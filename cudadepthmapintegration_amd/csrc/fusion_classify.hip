@@ -444,9 +444,24 @@ __global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__rest
   const int per = (n_slots + 1023) / 1024;
   const int lo = t * per, hi = min(n_slots, lo + per);
   int mine[kWorkLevels] = {0, 0, 0, 0};
-  for (int s = lo; s < hi; ++s) {
-    const int l = level[s];
-    if (l < kWorkLevels) mine[l] += 1;
+  if (per % 16 == 0 && hi == lo + per) {  // whole 16-byte groups (n_slots is a multiple of 32): one load per 16 slots
+    const uint4 *v = reinterpret_cast<const uint4 *>(level + lo);
+    for (int g = 0; g < per / 16; ++g) {
+      const uint4 w = v[g];
+      const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int l = (words[q] >> (8 * b)) & 0xff;
+          if (l < kWorkLevels) mine[l] += 1;
+        }
+    }
+  } else {
+    for (int s = lo; s < hi; ++s) {
+      const int l = level[s];
+      if (l < kWorkLevels) mine[l] += 1;
+    }
   }
   int pos[kWorkLevels];
   int level_base = 0;
@@ -456,9 +471,24 @@ __global__ __launch_bounds__(1024) void brick_order_kernel(const uint8_t *__rest
     level_base += total;
   }
   if (t == 0) *n_valid = level_base;
-  for (int s = lo; s < hi; ++s) {
-    const int l = level[s];
-    if (l < kWorkLevels) order[pos[l]++] = s + slot_base;  // absolute slot
+  if (per % 16 == 0 && hi == lo + per) {
+    const uint4 *v = reinterpret_cast<const uint4 *>(level + lo);
+    for (int g = 0; g < per / 16; ++g) {
+      const uint4 w = v[g];
+      const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int l = (words[q] >> (8 * b)) & 0xff;
+          if (l < kWorkLevels) order[pos[l]++] = lo + g * 16 + q * 4 + b + slot_base;  // absolute slot
+        }
+    }
+  } else {
+    for (int s = lo; s < hi; ++s) {
+      const int l = level[s];
+      if (l < kWorkLevels) order[pos[l]++] = s + slot_base;  // absolute slot
+    }
   }
 }
 
