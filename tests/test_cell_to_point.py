@@ -85,3 +85,27 @@ def test_gpu_cell_to_point_after_fuse():
         assert bits_equal(pts, oracle.cell_to_point(cells))
         ctx.fuse()  # accumulate again: the point data must be recomputed
         assert bits_equal(ctx.download_point_data(), oracle.cell_to_point(ctx.download_grid()))
+
+
+def _post_golden(name):
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post", name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_oracles_match_committed_cell_to_point_fixture():
+    g = _post_golden("cell_to_point")
+    assert bits_equal(oracle.cell_to_point(g["cells"]), g["expected_points"])
+    assert bits_equal(oracle_np.cell_to_point_np(g["cells"]), g["expected_points"])
+    # the corner point above the lone -0.0 cell: c = 0; c += 1 * (-0.0) gives +0.0, as VTK's accumulation does
+    assert g["expected_points"][0, 0, 0] == 0 and not np.signbit(g["expected_points"][0, 0, 0])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_committed_cell_to_point_fixture():
+    g = _post_golden("cell_to_point")
+    nz, ny, nx = g["cells"].shape
+    grid = scene.default_grid((nx, ny, nz))
+    with capi.FusionContext(grid, scene.default_ray_potential(grid)) as ctx:
+        ctx.upload_grid(g["cells"])
+        assert bits_equal(ctx.download_point_data(), g["expected_points"])

@@ -128,3 +128,25 @@ def test_gpu_color_context_resident_views_chunks_and_batches(monkeypatch):
             assert np.array_equal(g, w)
         with pytest.raises(capi.DmiError):
             c.add_views(colors[:1, :10], K4[:1], RT4[:1])   # a view of another size (MC.cxx:111 reads view 0's)
+
+
+def _post_golden(name):
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post", name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_oracles_match_committed_coloration_fixture():
+    g = _post_golden("coloration")
+    for fn in (oracle.color_mesh, oracle_np.color_mesh_np):
+        mean, median, count = fn(g["points"], g["colors"], g["K4"], g["RT4"])
+        assert np.array_equal(mean, g["expected_mean"]) and np.array_equal(median, g["expected_median"])
+        assert np.array_equal(count, g["expected_count"])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_committed_coloration_fixture():
+    g = _post_golden("coloration")
+    mean, median, count = capi.color_mesh(g["points"], g["colors"], g["K4"], g["RT4"])
+    assert np.array_equal(mean, g["expected_mean"]) and np.array_equal(median, g["expected_median"])
+    assert np.array_equal(count, g["expected_count"])
