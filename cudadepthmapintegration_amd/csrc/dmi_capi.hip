@@ -738,7 +738,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   // SIMD (more, smaller work items and a finer brick classification: 0.65 vs 0.74 ms at 256^3 x 64 views, 11.2 vs 11.5
   // ms at 512^3 x 256), 1024^3 with 16-voxel columns (15.5 vs 17.7 ms at 1024^3 x 64: the classification of twice as
   // many bricks costs more than it saves); profiles/r01zc_*, r01zd_*, r01zi_*
-  if (cfg.use_tile && !ctx->depth_f64 && !(cfg.variant & (dmi::VAR_TILE_SHAPE_MASK | dmi::VAR_FIXED_TILE_SHAPE))) {
+  if (cfg.use_tile && !(cfg.variant & (dmi::VAR_TILE_SHAPE_MASK | dmi::VAR_FIXED_TILE_SHAPE))) {
     const int64_t bricks16 = (int64_t)((a.nx + 15) / 16) * ((a.ny + 15) / 16) * ((a.nz + 15) / 16);
     if (bricks16 <= 32768) cfg.variant |= 7 << dmi::VAR_TILE_SHAPE_SHIFT;
   }

@@ -436,10 +436,16 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   return hipGetLastError();
 }
 
-// Shape 0 is built for every storage type; the other (tuning) shapes only for f32 depth tables.
+// Shapes 0 and 7 (the two that dmi_fuse picks by grid size) are built for every storage type; the other (tuning)
+// shapes only for f32 depth tables.
+int effective_shape(int variant, bool depth_is_f64) {
+  const int shape = tile_shape_index(variant);
+  return (depth_is_f64 && shape != 7) ? 0 : shape;
+}
+
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  const int shape = std::is_same<DepthT, float>::value ? tile_shape_index(cfg.variant) : 0;
+  const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value);
   if constexpr (std::is_same<DepthT, float>::value) {
     switch (shape) {
       case 1: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 4>(a, cfg, s);  // 80 + 32 = 112 VGPRs: 4 waves
@@ -448,10 +454,10 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 2>(a, cfg, s);
       case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 2>(a, cfg, s);  // 64 + 32 = 96: 5 waves, loads in flight: 2
       case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
-      case 7: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);   // 72 + 16 = 88: 5 waves
       default: break;
     }
   }
+  if (shape == 7) return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);  // 72 + 16 = 88: 5 waves
   return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);  // 96 + 32 = 128 VGPRs: 4 waves per SIMD
 }
 
@@ -460,7 +466,7 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
 int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VAR_TILE_SHAPE_SHIFT; }
 
 TileShape tile_shape(int variant, bool depth_is_f64) {
-  switch (depth_is_f64 ? 0 : tile_shape_index(variant)) {
+  switch (effective_shape(variant, depth_is_f64)) {
     case 3:
     case 4:
     case 7: return TileShape{8, 2, 2};
