@@ -297,15 +297,31 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   }
   t.px = P[0]; t.py = P[1]; t.pz = P[2]; t.p0 = P[3];
   t.qx = Q[0]; t.qy = Q[1]; t.qz = Q[2]; t.q0 = Q[3];
-  const double dz = ctx->grid.grid_matrix[10] * ctx->grid.spacing[2];  // step of wz per voxel along k
-  t.dhx = P[2] * dz;
-  t.dhy = Q[2] * dz;
-  // magnitudes: |w| is largest at a grid corner (each w component is monotone in its own index)
-  double lo[3], hi[3], wm[3];
-  voxel_world(ctx->grid, 0, 0, ctx->opt.z_first, lo);
-  voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1,
-              ctx->opt.z_first + ctx->grid.cell_dims[2] - 1 + kMaxColumn, hi);
-  for (int a = 0; a < 3; ++a) wm[a] = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+  // step of the world position per voxel along k: column 2 of the grid matrix times the spacing (for an axis-aligned
+  // grid only its z component is non-zero)
+  const double *g = ctx->grid.grid_matrix;
+  const double sz = ctx->grid.spacing[2];
+  t.dhx = (P[0] * (g[2] * sz) + P[1] * (g[6] * sz)) + P[2] * (g[10] * sz);
+  t.dhy = (Q[0] * (g[2] * sz) + Q[1] * (g[6] * sz)) + Q[2] * (g[10] * sz);
+  // magnitudes of the world coordinates over the grid (plus one column height)
+  double wm[3];
+  const bool aligned = grid_axis_aligned(ctx->grid);
+  if (aligned) {
+    // |w| is largest at a grid corner (each w component is monotone in its own index)
+    double lo[3], hi[3];
+    voxel_world(ctx->grid, 0, 0, ctx->opt.z_first, lo);
+    voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1,
+                ctx->opt.z_first + ctx->grid.cell_dims[2] - 1 + kMaxColumn, hi);
+    for (int a = 0; a < 3; ++a) wm[a] = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+  } else {
+    // sum of magnitudes: also bounds every intermediate of the evaluation
+    double gm[3];
+    for (int a = 0; a < 3; ++a)
+      gm[a] = std::fabs(ctx->grid.origin[a]) +
+              (ctx->grid.cell_dims[a] + 1.0 + (a == 2 ? ctx->opt.z_first + kMaxColumn : 0)) * std::fabs(ctx->grid.spacing[a]);
+    for (int a = 0; a < 3; ++a)
+      wm[a] = std::fabs(g[4 * a]) * gm[0] + std::fabs(g[4 * a + 1]) * gm[1] + std::fabs(g[4 * a + 2]) * gm[2] + std::fabs(g[4 * a + 3]);
+  }
   double M[3];
   for (int row = 0; row < 3; ++row)
     M[row] = std::fabs(rt[4 * row]) * wm[0] + std::fabs(rt[4 * row + 1]) * wm[1] + std::fabs(rt[4 * row + 2]) * wm[2] +
@@ -313,6 +329,9 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   const double Sx = std::fabs(k[0]) * M[0] + std::fabs(k[1]) * M[1] + std::fabs(k[2]) * M[2];
   const double Sy = std::fabs(k[5]) * M[1] + std::fabs(k[6]) * M[2];
   t.err = std::max(Sx, Sy) * 0x1p-44;  // 512 ulps of the term magnitudes
+  // rotated grid: the computed c.z (9 + 6 rounded operations on terms bounded by M[2]) is within 8 ulp(M[2]) of the
+  // real, exactly affine one; four times that as the margin of the brick classification
+  t.cz_err = aligned ? 0.0 : M[2] * 0x1p-47;
   t.depth = r.depth;
   return t;
 }
@@ -320,7 +339,7 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
 // Preconditions of the tiled kernel (fusion_tile.hip header); otherwise the general kernel runs.
 bool tile_eligible(const dmi_context *ctx) {
   if (ctx->opt.kernel_variant & dmi::VAR_FORCE_GENERAL) return false;
-  if (!ctx->finite_bounded || !grid_axis_aligned(ctx->grid)) return false;
+  if (!ctx->finite_bounded) return false;  // any grid matrix: axis-aligned or rotated (TileArgs::rotated)
   if (ctx->k_mode < (int)dmi::K_PINHOLE_SKEW) return false;
   if (!(ctx->ray.thickness >= 0) || !(ctx->ray.delta >= 0)) return false;
   if ((int64_t)ctx->W * ctx->H * (int64_t)(ctx->depth_f64 ? 8 : 4) >= (int64_t(1) << 31)) return false;
@@ -746,7 +765,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   TileArgs t;
   std::memset(&t, 0, sizeof(t));
   if (cfg.use_tile) {
-    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64);
+    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64, !grid_axis_aligned(ctx->grid));
     t.nx = a.nx; t.ny = a.ny; t.nz = a.nz; t.W = a.W; t.H = a.H;
     t.first_map = first; t.n_maps = count; t.init_from_grid = a.init_from_grid;
     t.kpad = (a.nz + sh.tk - 1) / sh.tk * sh.tk;
@@ -778,7 +797,9 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     t.tile_maps = ctx->d_tile_maps;
     t.grid = a.grid; t.voxel_hits = a.voxel_hits; t.map_hits = a.map_hits;
     // r22*wz(k) table, one row of kpad doubles per resident view
-    const size_t need = (size_t)n_views * (size_t)t.kpad;
+    t.rotated = grid_axis_aligned(ctx->grid) ? 0 : 1;
+    t.maps = ctx->d_maps;
+    const size_t need = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;  // rotated: [kpad][4]
     if (ctx->cz_table_capacity < need) {
       if (ctx->d_cz_table) {
         DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));

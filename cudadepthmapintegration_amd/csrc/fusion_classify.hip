@@ -139,12 +139,45 @@ struct BoxFootprint {
   double czmin, czmax;
 };
 
+template <bool ROT>
 __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const MapRec *__restrict__ mr,
                                                       const TileMapRec *__restrict__ tr, int i0, int i1, int j0, int j1, int k0,
                                                       int k1) {
   BoxFootprint fp;
   fp.query = false;
   fp.x0 = fp.x1 = fp.y0 = fp.y1 = 0;
+  double czmin = __builtin_inf(), czmax = -__builtin_inf();
+  double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
+  bool bad = false;
+  const double r23 = mr->rt[11];
+  if constexpr (ROT) {
+    // Rotated grid: every corner in full.  c.z exactly as the fusion kernel computes it (cu:168 then cu:172 row 2);
+    // the real c.z is affine in (i, j, k), so its extremes over the box are at corners, and computed values -- at
+    // corners and inside -- are within TileMapRec::cz_err of the real ones: the range is widened by twice that below.
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = (c & 1) ? i1 : i0, j = (c & 2) ? j1 : j0, k = (c & 4) ? k1 : k0;
+      const double gx = a.ox + (i + 0.5) * a.sx;  // cu:80-82
+      const double gy = a.oy + (j + 0.5) * a.sy;
+      const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
+      const double wx = row4(a.g + 0, gx, gy, gz), wy = row4(a.g + 4, gx, gy, gz), wz = row4(a.g + 8, gx, gy, gz);
+      const double cz = row4(mr->rt + 8, wx, wy, wz);
+      const double hx = __builtin_fma(tr->px, wx, __builtin_fma(tr->py, wy, __builtin_fma(tr->pz, wz, tr->p0)));
+      const double hy = __builtin_fma(tr->qx, wx, __builtin_fma(tr->qy, wy, __builtin_fma(tr->qz, wz, tr->q0)));
+      double r = __builtin_amdgcn_rcp(cz);
+      r = __builtin_fma(r, __builtin_fma(-cz, r, 1.0), r);
+      const double u = hx * r, v = hy * r;
+      bad = bad || !(cz == cz);
+      czmin = fmin(czmin, cz);
+      czmax = fmax(czmax, cz);
+      umin = fmin(umin, u);
+      umax = fmax(umax, u);
+      vmin = fmin(vmin, v);
+      vmax = fmax(vmax, v);
+    }
+    czmin -= 2.0 * tr->cz_err;
+    czmax += 2.0 * tr->cz_err;
+  } else {
   // World coordinates of the box's faces (cu:78-83 + cu:168).  With the axis-aligned grid the tiled kernel requires,
   // wx depends on i only, wy on j, wz on k (fusion_tile.hip), so the eight corners share six values.
   double wxs[2], wys[2], wzs[2];
@@ -160,7 +193,7 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   // c.z at the corners in the reference's order ((r20*wx + r21*wy) + r22*wz) + r23 (cu:92, cu:172): exactly the values
   // the fusion kernel computes there.  h.x, h.y only bound the footprint: the affine form of the fusion kernel
   // (rows of K*[R|T], error <= TileMapRec::err) is enough, see DESIGN.md 4b.2.
-  const double r20 = mr->rt[8], r21 = mr->rt[9], r22 = mr->rt[10], r23 = mr->rt[11];
+  const double r20 = mr->rt[8], r21 = mr->rt[9], r22 = mr->rt[10];
   const double zx[2] = {r20 * wxs[0], r20 * wxs[1]}, zy[2] = {r21 * wys[0], r21 * wys[1]}, zz[2] = {r22 * wzs[0], r22 * wzs[1]};
   const double ux[2] = {tr->px * wxs[0], tr->px * wxs[1]};
   const double uy[2] = {__builtin_fma(tr->py, wys[0], tr->p0), __builtin_fma(tr->py, wys[1], tr->p0)};
@@ -168,9 +201,6 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   const double vx[2] = {tr->qx * wxs[0], tr->qx * wxs[1]};
   const double vy[2] = {__builtin_fma(tr->qy, wys[0], tr->q0), __builtin_fma(tr->qy, wys[1], tr->q0)};
   const double vz[2] = {tr->qz * wzs[0], tr->qz * wzs[1]};
-  double czmin = __builtin_inf(), czmax = -__builtin_inf();
-  double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
-  bool bad = false;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int cx = c & 1, cy = (c >> 1) & 1, ck = c >> 2;
@@ -191,6 +221,7 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
     vmin = fmin(vmin, v);
     vmax = fmax(vmax, v);
   }
+  }  // axis-aligned grid
   // an unproven pair carries, above the two class bits, WHY it is unproven (MixedReason << 2): a diagnostic the
   // fusion kernel never looks at (it reads the class as byte & 3)
   uint8_t cls = BRICK_MIXED | (MIXED_DEGENERATE << 2);
@@ -238,11 +269,11 @@ __device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const Ti
   return BRICK_MIXED | (MIXED_NEAR_SURFACE << 2);
 }
 
-template <int kQueryTiles>
+template <int kQueryTiles, bool ROT>
 __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
                                                 const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
                                                 int j0, int j1, int k0, int k1) {
-  const BoxFootprint fp = box_footprint(a, mr, tr, i0, i1, j0, j1, k0, k1);
+  const BoxFootprint fp = box_footprint<ROT>(a, mr, tr, i0, i1, j0, j1, k0, k1);
   if (!fp.query) return fp.cls;
   return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
 }
@@ -251,6 +282,7 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
 // from every surface a view saw: there the whole box is proven at once and its bricks inherit the class; the bricks of
 // unproven boxes are left to the fine pass.  threadIdx.x runs over 64 consecutive views, so the box's own table row
 // and every child row receive 64 consecutive bytes per store.  Boxes are numbered over the whole grid.
+template <bool ROT>
 __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                               const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                               uint8_t *__restrict__ coarse) {
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
   const int bz0 = cbz * per_z;
-  const uint8_t cls = classify_box<5>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
+  const uint8_t cls = classify_box<5, ROT>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
                                    bz0 * tk + 31);
   coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] = cls;
   if ((cls & 3) == BRICK_MIXED) return;  // the fine pass decides brick by brick
@@ -295,7 +327,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
 constexpr int kWindow = 16;  // tiles per axis of the staged window
 
 // kChildren: wave bricks per box = lanes per view, 64 (8-voxel columns) or 32 (16-voxel columns)
-template <int kQueryTiles, int kChildren>
+template <int kQueryTiles, int kChildren, bool ROT>
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                        const uint8_t *__restrict__ coarse) {
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   BoxFootprint fp;
   fp.query = false;
   fp.cls = BRICK_SKIP;
-  if (mine) fp = box_footprint(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+  if (mine) fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
   const bool query = mine && fp.query;
   uint8_t cls = fp.cls;
   const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
@@ -540,8 +572,11 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   if (n_bricks > (int64_t)0x7fffffff || (a.n_maps + 3) / 4 > 65535) return hipErrorInvalidConfiguration;
   const int per_z = 32 / tk;
   const int64_t n_boxes = (int64_t)((a.wbricks_x + 3) / 4) * ((a.wbricks_y + 3) / 4) * ((bz_count + per_z - 1) / per_z);
-  hipLaunchKernelGGL(classify_coarse_kernel, dim3((unsigned)((n_boxes + 3) / 4), (unsigned)((a.n_maps + 63) / 64)), dim3(64, 4),
-                     0, stream, a, maps_dev, P, tk, classes, coarse);
+  const dim3 coarse_grid((unsigned)((n_boxes + 3) / 4), (unsigned)((a.n_maps + 63) / 64));
+  if (a.rotated)
+    hipLaunchKernelGGL(classify_coarse_kernel<true>, coarse_grid, dim3(64, 4), 0, stream, a, maps_dev, P, tk, classes, coarse);
+  else
+    hipLaunchKernelGGL(classify_coarse_kernel<false>, coarse_grid, dim3(64, 4), 0, stream, a, maps_dev, P, tk, classes, coarse);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int views_per_block = 4 * (64 / (16 * per_z));
@@ -552,12 +587,18 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   int q = 5;
   if (const char *env = getenv("DMI_QUERY_TILES")) q = atoi(env);  // tuning experiments
   const bool wide = tk == 8;  // 64 bricks per box
-#define DMI_LAUNCH_FINE(Q)                                                                                              \
-  do {                                                                                                                   \
-    if (wide)                                                                                                            \
-      hipLaunchKernelGGL((classify_kernel<Q, 64>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse); \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((classify_kernel<Q, 32>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse); \
+#define DMI_LAUNCH_FINE_R(Q, C, R) \
+  hipLaunchKernelGGL((classify_kernel<Q, C, R>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse)
+#define DMI_LAUNCH_FINE(Q)                      \
+  do {                                          \
+    if (wide && a.rotated)                      \
+      DMI_LAUNCH_FINE_R(Q, 64, true);           \
+    else if (wide)                              \
+      DMI_LAUNCH_FINE_R(Q, 64, false);          \
+    else if (a.rotated)                         \
+      DMI_LAUNCH_FINE_R(Q, 32, true);           \
+    else                                        \
+      DMI_LAUNCH_FINE_R(Q, 32, false);          \
   } while (0)
   if (q <= 2)
     DMI_LAUNCH_FINE(2);
@@ -565,6 +606,7 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
     DMI_LAUNCH_FINE(3);
   else
     DMI_LAUNCH_FINE(5);
+#undef DMI_LAUNCH_FINE_R
 #undef DMI_LAUNCH_FINE
   return hipGetLastError();
 }

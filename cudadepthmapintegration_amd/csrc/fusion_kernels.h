@@ -53,7 +53,8 @@ struct alignas(16) TileMapRec {
   double dhx, dhy;         // increments of hx, hy per voxel step along k
   double err;              // bound on |hx_ref - hx_fast| and |hy_ref - hy_fast| (absolute)
   const void *depth;       // same table as MapRec::depth
-  uint64_t pad;
+  double cz_err;           // rotated grids: bound on |computed c.z - real c.z| (0 for axis-aligned grids, where the
+                           // computed c.z is monotone in every index and needs no margin)
 };
 static_assert(sizeof(TileMapRec) == 128, "TileMapRec layout");
 
@@ -117,6 +118,11 @@ struct TileArgs {
   // 0x0101010101010101 when adding +0.0 cannot change any running sum (the grid starts at +0.0 and there are no hit
   // counters): BRICK_BEHIND is then treated as BRICK_SKIP; 0 otherwise
   unsigned long long behind_mask;
+  // Rotated grid (the 3x3 part of the grid matrix is not diagonal): w depends on all of (i, j, k), so c.z cannot
+  // be split into a per-lane part and a per-(view, k) table; cz_table then holds [kpad][4] = the k-dependent products
+  // (g02, g12, g22) * gz(k) of cu:168, and the kernel forms w and c.z per voxel in the reference's order
+  int32_t rotated, pad4;
+  const MapRec *maps;                    // RT row 2 in full for the rotated path
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
@@ -166,7 +172,7 @@ enum VariantBits : int {
 struct TileShape {
   int tk, wx, wy;  // column height; waves per workgroup along x and y (a wave is 8 x 8 lanes)
 };
-TileShape tile_shape(int variant, bool depth_is_f64);
+TileShape tile_shape(int variant, bool depth_is_f64, bool rotated);
 
 // Enqueues the general fusion kernel on `stream`.  Returns hipSuccess or the launch error.
 hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t stream);

@@ -146,12 +146,17 @@ __device__ __forceinline__ bool tile_exact(const FuseArgs *__restrict__ fa, int 
 // occupancy (<= 96: five waves per SIMD, <= 128: four).
 constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw == 6 ? 80 : minw == 5 ? 96 : 128; }
 
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT>
+// ROT: the grid is rotated (3x3 part of the grid matrix not diagonal): w depends on all of (i, j, k); each voxel forms
+// w = ((g_r0*gx + g_r1*gy) + g_r2*gz) + g_r3 from a per-lane part and the per-k products of the wk table, then
+// c.z = ((r20*wx + r21*wy) + r22*wz) + r23, every operation the reference's (cu:90-92, cu:168, cu:172): 12 VALU
+// operations per voxel-projection instead of 2.  Everything else is shared with the axis-aligned path.
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
   constexpr int BASE = acc_base(MINW);
   constexpr int kGroup = GROUP;
   typedef double czvec __attribute__((ext_vector_type(GROUP)));
+  typedef double czvec4 __attribute__((ext_vector_type(4)));
   // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD), and
   // an XCD runs about 32 of these workgroups at a time.  So consecutive blocks OF ONE XCD enumerate one
   // super-brick of 4 x 4 x 2 bricks: the workgroups an XCD runs together are neighbours in space and their
@@ -195,9 +200,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const double gx = a.ox + (i + 0.5) * a.sx;
   const double gy = a.oy + (j + 0.5) * a.sy;
   const double gz0 = a.oz + ((k0 + a.kz0) + 0.5) * a.sz;
-  const double wx = row4(a.g + 0, gx, gy, gz0);
-  const double wy = row4(a.g + 4, gx, gy, gz0);
-  const double wz0 = row4(a.g + 8, gx, gy, gz0);
+  // axis-aligned: the lane's world x, y and the column's first z.  Rotated: the (i, j)-dependent part of each world
+  // coordinate, fl(fl(g_r0*gx) + fl(g_r1*gy)) -- the first sum of cu:90-92, which does not depend on k.
+  const double wx = ROT ? a.g[0] * gx + a.g[1] * gy : row4(a.g + 0, gx, gy, gz0);
+  const double wy = ROT ? a.g[4] * gx + a.g[5] * gy : row4(a.g + 4, gx, gy, gz0);
+  const double wz0 = ROT ? a.g[8] * gx + a.g[9] * gy : row4(a.g + 8, gx, gy, gz0);
 
   GridT *__restrict__ grid = static_cast<GridT *>(a.grid);
   const int64_t plane = (int64_t)a.ny * a.nx;
@@ -272,25 +279,37 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // exact: the part of c.z shared by the whole column, (r20*wx + r21*wy)  (cu:92).  Lanes outside
     // the grid get -inf: their c.z is -inf, i.e. "behind the camera" (cu:177), at no cost per voxel.
     // Voxels above the grid (k >= nz) get the same through a -inf entry of the cz table.
-    const double sz_in = cload(&rec->rz0) * wx + cload(&rec->rz1) * wy;
-    const double sz = lane_ok ? sz_in : -__builtin_inf();
-    const double rz3 = cload(&rec->rz3);
-    // pixel selection only: h.x, h.y at the column's first voxel, then one add per step
-    double hx = __builtin_fma(cload(&rec->px), wx,
-                              __builtin_fma(cload(&rec->py), wy, __builtin_fma(cload(&rec->pz), wz0, cload(&rec->p0))));
-    double hy = __builtin_fma(cload(&rec->qx), wx,
-                              __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
+    double sz, rz3, hx, hy;
+    double r20 = 0, r21 = 0, r22 = 0;  // ROT only
+    if constexpr (ROT) {
+      r20 = cload(&rec->rz0);
+      r21 = cload(&rec->rz1);
+      r22 = cload(&a.maps[m].rt[10]);
+      sz = lane_ok ? cload(&rec->rz3) : -__builtin_inf();  // r23 per lane: -inf puts lanes outside the grid behind the camera
+      rz3 = 0;
+      hx = hy = 0;  // set at the column's first voxel below
+    } else {
+      const double sz_in = cload(&rec->rz0) * wx + cload(&rec->rz1) * wy;
+      sz = lane_ok ? sz_in : -__builtin_inf();
+      rz3 = cload(&rec->rz3);
+      // pixel selection only: h.x, h.y at the column's first voxel, then one add per step
+      hx = __builtin_fma(cload(&rec->px), wx,
+                         __builtin_fma(cload(&rec->py), wy, __builtin_fma(cload(&rec->pz), wz0, cload(&rec->p0))));
+      hy = __builtin_fma(cload(&rec->qx), wx,
+                         __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
+    }
     const double dhx = cload(&rec->dhx), dhy = cload(&rec->dhy), err = cload(&rec->err);
 
     uint32_t undecided = 0;  // per lane: bit kk set = redo voxel kk of this map exactly
     uint32_t map_hits = 0;   // wave-uniform
 
     // r22*wz(k) for one group of the column per scalar load, fetched one group ahead of its use
-    czvec ct_cur = cload(reinterpret_cast<const czvec *>(ct));
+    czvec ct_cur = {};
+    if constexpr (!ROT) ct_cur = cload(reinterpret_cast<const czvec *>(ct));
 #pragma unroll
     for (int g0 = 0; g0 < TK; g0 += kGroup) {
       czvec ct_next = ct_cur;
-      if (g0 + kGroup < TK) ct_next = cload(reinterpret_cast<const czvec *>(ct + g0 + kGroup));
+      if (!ROT && g0 + kGroup < TK) ct_next = cload(reinterpret_cast<const czvec *>(ct + g0 + kGroup));
       double czg[kGroup];
       typename DL::raw_t dg[kGroup];
       mask_t ing[kGroup];
@@ -298,11 +317,30 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #pragma unroll
       for (int q = 0; q < kGroup; ++q) {
         const int kk = g0 + q;
-        if (kk > 0) {
-          hx += dhx;
-          hy += dhy;
+        double cz;
+        if constexpr (ROT) {
+          ing[q] = 0;
+          if (kk >= kcount) continue;  // wave-uniform: a voxel above the grid (the table has no -inf trick here)
+          // the k-dependent products g_r2*gz(k) of cu:168 (wk table, scalar load), then w and c.z in the reference's order
+          const czvec4 b = cload(reinterpret_cast<const czvec4 *>(a.cz_table + (int64_t)(k0 + kk) * 4));
+          const double wxk = (wx + b[0]) + a.g[3], wyk = (wy + b[1]) + a.g[7], wzk = (wz0 + b[2]) + a.g[11];
+          cz = ((r20 * wxk + r21 * wyk) + r22 * wzk) + sz;
+          if (kk == 0) {
+            hx = __builtin_fma(cload(&rec->px), wxk,
+                               __builtin_fma(cload(&rec->py), wyk, __builtin_fma(cload(&rec->pz), wzk, cload(&rec->p0))));
+            hy = __builtin_fma(cload(&rec->qx), wxk,
+                               __builtin_fma(cload(&rec->qy), wyk, __builtin_fma(cload(&rec->qz), wzk, cload(&rec->q0))));
+          } else {
+            hx += dhx;
+            hy += dhy;
+          }
+        } else {
+          if (kk > 0) {
+            hx += dhx;
+            hy += dhy;
+          }
+          cz = (sz + ct_cur[q]) + rz3;  // exact c.z (cu:92, cu:172); h.z == c.z for a pinhole K
         }
-        const double cz = (sz + ct_cur[q]) + rz3;  // exact c.z (cu:92, cu:172); h.z == c.z for a pinhole K
         czg[q] = cz;
         // reciprocal: hardware seed + one Newton step; e0 is the seed's residual, checked below
         const double r0 = __builtin_amdgcn_rcp(cz);
@@ -423,29 +461,44 @@ __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const M
   table[(int64_t)m * a.kpad + k] = k < a.nz ? maps[m].rt[10] * wz : -__builtin_inf();
 }
 
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP>
+// rotated grids: table[k][0..2] = (g02, g12, g22) * gz(k), the k-dependent products of cu:168 (exact fp64 multiplies)
+__global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double *__restrict__ table) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.kpad) return;
+  const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;  // cu:82
+  table[4 * k + 0] = a.g[2] * gz;
+  table[4 * k + 1] = a.g[6] * gz;
+  table[4 * k + 2] = a.g[10] * gz;
+  table[4 * k + 3] = 0.0;
+}
+
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   // super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
   const int per_round = 8 * a.xcd_run_wg;
   const unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + per_round - 1) / per_round * per_round);
   const dim3 block(64 * WX * WY);
   if (cfg.count_hits)
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT>), dim3(blocks), block, 0, s, a);
   else
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT>), dim3(blocks), block, 0, s, a);
   return hipGetLastError();
 }
 
 // Shapes 0 and 7 (the two that dmi_fuse picks by grid size) are built for every storage type; the other (tuning)
 // shapes only for f32 depth tables.
-int effective_shape(int variant, bool depth_is_f64) {
+int effective_shape(int variant, bool depth_is_f64, bool rotated) {
   const int shape = tile_shape_index(variant);
-  return (depth_is_f64 && shape != 7) ? 0 : shape;
+  return ((depth_is_f64 || rotated) && shape != 7) ? 0 : shape;
 }
 
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value);
+  const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0);
+  if (a.rotated) {  // rotated grid: the two default shapes
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4, true>(a, cfg, s);
+    return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4, true>(a, cfg, s);
+  }
   if constexpr (std::is_same<DepthT, float>::value) {
     switch (shape) {
       case 1: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 4>(a, cfg, s);  // 80 + 32 = 112 VGPRs: 4 waves
@@ -465,8 +518,8 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
 
 int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VAR_TILE_SHAPE_SHIFT; }
 
-TileShape tile_shape(int variant, bool depth_is_f64) {
-  switch (effective_shape(variant, depth_is_f64)) {
+TileShape tile_shape(int variant, bool depth_is_f64, bool rotated) {
+  switch (effective_shape(variant, depth_is_f64, rotated)) {
     case 3:
     case 4:
     case 7: return TileShape{8, 2, 2};
@@ -478,12 +531,15 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
                              uint8_t *order_scratch, uint8_t *coarse_classes, hipEvent_t before_main_kernel,
                              hipStream_t stream) {
   if (a.n_maps <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
-                     const_cast<double *>(a.cz_table));
+  if (a.rotated)
+    hipLaunchKernelGGL(wk_table_kernel, dim3((a.kpad + 255) / 256), dim3(256), 0, stream, a, const_cast<double *>(a.cz_table));
+  else
+    hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
+                       const_cast<double *>(a.cz_table));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.classes) {
-    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0);
+    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, stream);
     if (e != hipSuccess) return e;
     if (a.order) {

@@ -24,9 +24,13 @@ def _random_case(seed):
     if kind == 1:                                   # scaled / flipped / translated axes: still axis-aligned
         gm[:3, :3] = np.diag(rng.choice([-1.5, -1.0, 0.5, 1.0, 2.0], size=3))
         gm[:3, 3] = rng.uniform(-0.5, 0.5, size=3)
-    elif kind == 2:                                 # rotated grid: general kernel
-        a = rng.uniform(-1, 1)
+    elif kind == 2:                                 # rotated grid (about z, or any orthonormal axes): the tiled
+        a = rng.uniform(-1, 1)                      # kernel's rotated path
         gm[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+        if rng.integers(0, 2):
+            q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            gm[:3, :3] = q
+            gm[:3, 3] = rng.uniform(-0.2, 0.2, size=3)
     grid = scene.GridDesc(dims, origin, spacing, gm)
     n = int(rng.integers(1, 9))
     W, H = int(rng.integers(8, 90)), int(rng.integers(6, 70))

@@ -217,9 +217,9 @@ def test_near_half_pixel_stress_fast_path_equals_exact():
 
 
 def test_tiled_kernel_is_selected_only_when_its_preconditions_hold():
-    """Axis-aligned grid + pinhole K -> tiled kernel; rotated grid or general K -> general kernel."""
+    """Pinhole K (axis-aligned or rotated grid) -> tiled kernel; general K -> general kernel."""
     from conftest import load_golden
-    expect = {"generic_sphere_32": 1, "noncubic_70x33x17": 1, "anisotropic_rotated": 0, "general_k_f64_depth": 0}
+    expect = {"generic_sphere_32": 1, "noncubic_70x33x17": 1, "anisotropic_rotated": 1, "general_k_f64_depth": 0}
     for name, want in expect.items():
         grid, rp, views, thr = _golden_inputs(load_golden(name))
         with capi.FusionContext(grid, rp) as ctx:
@@ -232,7 +232,7 @@ def test_tiled_kernel_is_selected_only_when_its_preconditions_hold():
 
 @pytest.mark.parametrize("shape", TILE_SHAPES)
 @pytest.mark.parametrize("case", ["scaled_translated_grid", "cameras_inside", "skewed_k", "thin_grid", "f64_depth",
-                                  "negative_axes"])
+                                  "negative_axes", "rotated_grid", "rotated_cameras_inside"])
 def test_tiled_kernel_cases_against_oracle(shape, case):
     """Inputs that exercise the tiled kernel's preconditions and its fallbacks, checked bit for bit."""
     rng = np.random.default_rng(11)
@@ -244,6 +244,14 @@ def test_tiled_kernel_cases_against_oracle(shape, case):
         gm[:3, 3] = [0.125, -0.25, 0.0625]
     elif case == "negative_axes":
         gm = np.diag([-1.0, 1.0, -1.0, 1.0])
+    elif case in ("rotated_grid", "rotated_cameras_inside"):
+        # orthonormal axes that are not the coordinate axes (main.cxx:345-359 takes any orthogonal gridVecX/Y/Z):
+        # the tiled kernel's rotated path, w and c.z formed per voxel
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        gm[:3, :3] = q
+        gm[:3, 3] = [0.05, -0.1, 0.02]
+        if case == "rotated_cameras_inside":
+            radius = 0.45
     elif case == "cameras_inside":
         radius = 0.45      # cameras inside the grid: voxels behind them take the c.z < 0 exit (cu:177)
     elif case == "thin_grid":
