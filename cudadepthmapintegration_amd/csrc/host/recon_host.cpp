@@ -286,9 +286,20 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
     return false;
   };
   // cu:323-327: the accumulator starts from io_scalar
-  bool all_zero = true;
+  // +0.0 everywhere (all bits zero)?  The filter knows (RequestData has just filled the array, filt.cxx:133); other
+  // callers' arrays are scanned, eight bytes at a time.
+  bool all_zero = InitialGridIsZero;
+  InitialGridIsZero = false;
   const int64_t nvox = NumberOfCells();
-  for (int64_t i = 0; i < nvox && all_zero; ++i) all_zero = io_scalar[i] == 0.0 && !std::signbit(io_scalar[i]);
+  if (!all_zero) {
+    uint64_t any = 0;
+    for (int64_t i = 0; i < nvox; ++i) {
+      uint64_t bits;
+      std::memcpy(&bits, io_scalar + i, 8);
+      any |= bits;
+    }
+    all_zero = any == 0;
+  }
   if (!all_zero && dmi_upload_grid(ctx, io_scalar) != DMI_OK) return fail("dmi_upload_grid");
 
   // Views go up as a pinned structure-of-arrays ([n][H][W] depth, [n][H][W] best cost, [n][16] K, [n][16] RT),
@@ -501,6 +512,7 @@ int ReconstructionFilter::Compute(int gridDims[3], double gridOrig[3], double gr
   driver.SetKernelVariant(KernelVariant);
   driver.CudaInitialize(GridMatrix, gridDims, gridOrig, gridSpacing, RayPotentialThickness, RayPotentialRho,
                         RayPotentialEta, RayPotentialDelta, depthMapGrid);  // filt.cxx:171-173
+  driver.SetInitialGridIsZero(true);  // RequestData zero-filled outScalar just before (filt.cxx:133)
   const bool result = driver.ProcessDepthMap(views, ThresholdBestCost, outScalar->data());  // filt.cxx:175-176
   FuseKernelMs = driver.LastFuseKernelMs();
   if (!result) {

@@ -108,6 +108,8 @@ class FusionDriver {
 
   void SetDevice(int device) { Device = device; }
   void SetKernelVariant(int v) { KernelVariant = v; }
+  // the next ProcessDepthMap's io_scalar is known to hold +0.0 everywhere: skips the scan and the upload (cu:323-327)
+  void SetInitialGridIsZero(bool yes) { InitialGridIsZero = yes; }
   const std::string &LastError() const { return Error; }
   double LastFuseKernelMs() const { return FuseKernelMs; }
   int64_t NumberOfCells() const;
@@ -117,6 +119,7 @@ class FusionDriver {
   dmi_ray_potential Ray;
   int DepthDims[2];
   bool Initialized = false;
+  bool InitialGridIsZero = false;
   int Device = 0;
   int KernelVariant = 0;
   double FuseKernelMs = 0.0;
