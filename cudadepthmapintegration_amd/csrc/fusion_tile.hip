@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       czvec ct_next = ct_cur;
       if (!ROT && g0 + kGroup < TK) ct_next = cload(reinterpret_cast<const czvec *>(ct + g0 + kGroup));
       double czg[kGroup];
-      typename DL::raw_t dg[kGroup];
+      typename DL::raw_t dg[kGroup] = {};  // defined on every path: no loop-carried undefined values to shuffle around
       mask_t ing[kGroup];
       // ---- phase A: project the group's voxels and issue their depth loads
 #pragma unroll
