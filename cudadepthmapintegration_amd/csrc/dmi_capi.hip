@@ -83,6 +83,8 @@ struct dmi_context {
   int64_t last_class_bricks = 0;  // wave bricks of the last fuse
   int32_t last_class_pitch = 0, last_first = 0, last_count = 0;
   dmi::PyramidDesc pyramid{};    // geometry of every view's depth min/max pyramid
+  uint8_t *d_zero_row = nullptr;  // one row of BRICK_MIXED bytes: the class table of a fuse without classes
+  size_t zero_row_capacity = 0;
   uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch], then the coarse table [boxes][class_pitch]
   size_t coarse_offset = 0;      // byte offset of the coarse table within d_classes (last fuse)
   size_t classes_capacity = 0;   // bytes
@@ -578,6 +580,7 @@ void dmi_destroy(dmi_context *ctx) {
     (void)hipFree(b.d_pyramid);
   }
   if (ctx->d_classes) (void)hipFree(ctx->d_classes);
+  if (ctx->d_zero_row) (void)hipFree(ctx->d_zero_row);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
   if (ctx->d_order_level) (void)hipFree(ctx->d_order_level);
   for (EventPair &p : ctx->pending) {
@@ -821,7 +824,22 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     // fuse ...) change the layout -- and force a reallocation, which waits for the device -- only at doublings
     t.class_pitch = 64;
     while (t.class_pitch < n_views) t.class_pitch *= 2;
-    if (!(cfg.variant & dmi::VAR_NO_BRICK_CLASSES)) {
+    if (cfg.variant & dmi::VAR_NO_BRICK_CLASSES) {
+      // classes off: every brick reads the same all-BRICK_MIXED row (pitch 0), so the kernel needs no "have classes?"
+      // test in its view loop
+      if (ctx->zero_row_capacity < (size_t)t.class_pitch) {
+        if (ctx->d_zero_row) {
+          DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          (void)hipFree(ctx->d_zero_row);
+          ctx->d_zero_row = nullptr;
+        }
+        DMI_HIP(ctx, hipMalloc(&ctx->d_zero_row, (size_t)t.class_pitch));
+        DMI_HIP(ctx, hipMemsetAsync(ctx->d_zero_row, dmi::BRICK_MIXED, (size_t)t.class_pitch, ctx->stream));
+        ctx->zero_row_capacity = (size_t)t.class_pitch;
+      }
+      t.classes = ctx->d_zero_row;
+      t.class_pitch = 0;
+    } else {
       const size_t fine_bytes = ((size_t)t.wbricks_x * t.wbricks_y * t.bricks_z * (size_t)t.class_pitch + 255) / 256 * 256;
       // the coarse table (one row per box of 32^3 voxels) lives behind the brick table in the same allocation
       const size_t cbytes = fine_bytes + (size_t)dmi::coarse_class_bytes(t, sh.tk);
@@ -892,7 +910,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     return fail(ctx, DMI_ERR_DEVICE, std::string("fusion kernel launch: ") + hipGetErrorString(e));
   }
   ctx->last_fuse_tiled = cfg.use_tile != 0;
-  ctx->last_fuse_classes = cfg.use_tile != 0 && t.classes != nullptr;
+  ctx->last_fuse_classes = cfg.use_tile != 0 && !(cfg.variant & dmi::VAR_NO_BRICK_CLASSES);
   ctx->last_class_bricks = (int64_t)t.wbricks_x * t.wbricks_y * t.bricks_z;
   ctx->last_class_pitch = t.class_pitch;
   ctx->last_first = first;

@@ -229,15 +229,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int m_end = a.first_map + a.n_maps;
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
-  const unsigned long long *crow =
-      a.classes ? reinterpret_cast<const unsigned long long *>(
-                      a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch)
-                : nullptr;
+  // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
+  const unsigned long long *crow = reinterpret_cast<const unsigned long long *>(
+      a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch);
 
-  unsigned long long cword = 0ull, cnext = 0ull;  // all BRICK_MIXED when classes are off
-  if (crow) cnext = cload(crow + (a.first_map >> 3));
+  unsigned long long cword = 0ull;
+  unsigned long long cnext = cload(crow + (a.first_map >> 3));
   for (int m = a.first_map; m < m_end; ++m) {
-    if (crow && ((m & 7) == 0 || m == a.first_map)) {
+    if ((m & 7) == 0 || m == a.first_map) {
       // fetched one block ahead: its latency hides behind the previous eight maps.  behind_mask turns BEHIND (2) into
       // SKIP (3) when x + 0.0 == x for every running sum: sums that start at +0.0 never become -0.0
       cword = cnext | ((cnext >> 1) & a.behind_mask);
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // all TK slots, also in a brick that sticks out of the top of the grid (kcount < TK): the slots above the grid
         // are never stored, and treating them alike keeps per-slot predicates out of the loop
 #pragma unroll
-        for (int q = 0; q < TK; q += 8) acc_add8_s<BASE, TK>(q, m_lane_ok, v);
+        for (int q = 0; q < TK; q += 8) acc_add8_all<BASE, TK>(q, v);  // every lane: those outside the grid store nothing
         if (COUNT) {
 #pragma unroll
           for (int q = 0; q < TK; ++q) nh[q] += lane_ok ? 1u : 0u;
@@ -538,7 +537,7 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
                        const_cast<double *>(a.cz_table));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (a.classes) {
+  if (!(cfg.variant & VAR_NO_BRICK_CLASSES)) {
     const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, stream);
     if (e != hipSuccess) return e;
