@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--no-ablation", action="store_true")
     ap.add_argument("--slabs", type=int, default=4,
                     help="N > 1: z-slabs per fusion; the all-reduce of a slab overlaps the fusion of the next (1 = no overlap)")
+    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="N > 1: all_reduce = the contract (every rank gets the whole grid, overlapped slab by slab); "
+                         "reduce_scatter = every rank gets the sum of its own 1/N of the grid (half the traffic, no overlap)")
     ap.add_argument("--no-coloration", action="store_true")
     ap.add_argument("--coloration-vertices", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -226,6 +229,9 @@ def main():
         ctx.reset_grid()
         if dist is None:
             ctx.fuse()
+        elif args.exchange == "reduce_scatter":
+            ctx.fuse()
+            sharding.reduce_scatter_grid(grid_t, rank, world)
         elif args.slabs <= 1:
             ctx.fuse()
             sharding.all_reduce_grid(grid_t)  # the single RCCL all-reduce of the TSDF grid over xGMI
@@ -351,8 +357,10 @@ def main():
             "tiled_kernel": int(info.tiled_kernel),
             "kernel_variant": args.variant,
             "maps_total": total_maps,
-            "parallelism": (f"depth-map shards x{world}, RCCL all-reduce of the grid in {args.slabs} z-slabs overlapped with "
-                            f"the fusion" if world > 1 else "single GPU"),
+            "parallelism": ((f"depth-map shards x{world}, RCCL reduce-scatter of the grid (each rank keeps 1/{world})"
+                             if args.exchange == "reduce_scatter" else
+                             f"depth-map shards x{world}, RCCL all-reduce of the grid in {args.slabs} z-slabs overlapped with "
+                             f"the fusion") if world > 1 else "single GPU"),
             "host_upload_s": round(upload_s, 3),
         },
         "roofline": {

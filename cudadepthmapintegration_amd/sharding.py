@@ -49,6 +49,23 @@ def all_reduce_grid(grid_tensor, group=None):
     return grid_tensor
 
 
+def reduce_scatter_grid(grid_tensor, rank: int, world: int, group=None):
+    """The cheaper exchange when only the host consumes the grid: every rank ends up with the sum of
+    its own 1/world slice (contiguous in z) and downloads just that -- half the traffic of the all-reduce.  Returns
+    (slice tensor, first element, element count).  The element count must divide evenly (pad the grid otherwise).
+    RCCL only (gloo has no reduce-scatter); bench.py --exchange reduce_scatter."""
+    import torch
+    import torch.distributed as dist
+
+    n = grid_tensor.numel()
+    if n % world != 0:
+        raise ValueError("reduce_scatter_grid: the grid size must be a multiple of the world size")
+    per = n // world
+    out = torch.empty(per, dtype=grid_tensor.dtype, device=grid_tensor.device)
+    dist.reduce_scatter_tensor(out, grid_tensor, op=dist.ReduceOp.SUM, group=group)
+    return out, rank * per, per
+
+
 def sharded_tolerance(world: int, abs_partial_sum):
     """Bound on |all-reduced f32 grid - single-GPU f64 grid| per voxel: each rank rounds its partial to f32
     (2^-24 relative), the reduction adds world-1 f32 roundings of partial sums, fp64 reordering is

@@ -451,6 +451,10 @@ def test_overlapped_fuse_and_all_reduce_single_rank(tmp_path):
             torch.cuda.synchronize()
             plain = grid_t.cpu().numpy()
         assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)) and np.abs(plain).max() > 0
+        # the cheaper exchange (every rank keeps its own 1/N): with one rank the slice is the whole grid
+        part, first, count = sharding.reduce_scatter_grid(grid_t, 0, 1)
+        torch.cuda.synchronize()
+        assert first == 0 and count == grid.n_voxels and torch.equal(part, grid_t)
     finally:
         dist.destroy_process_group()
 
