@@ -495,22 +495,24 @@ template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0);
   if (a.rotated) {  // rotated grid: the two default shapes
-    if (shape == 7) return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4, true>(a, cfg, s);
-    return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4, true>(a, cfg, s);
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 2, 2, 6, 8, true>(a, cfg, s);
+    return launch_shape<DepthT, GridT, 16, 2, 2, 5, 8, true>(a, cfg, s);
   }
   if constexpr (std::is_same<DepthT, float>::value) {
     switch (shape) {
       case 1: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 4>(a, cfg, s);  // 80 + 32 = 112 VGPRs: 4 waves
       case 2: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 4>(a, cfg, s);  // 64 + 32 = 96: 5 waves, tight compiler budget
       case 3: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 4>(a, cfg, s);   // 80 + 16 = 96: 5 waves
-      case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 2>(a, cfg, s);
-      case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 2>(a, cfg, s);  // 64 + 32 = 96: 5 waves, loads in flight: 2
+      case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 8>(a, cfg, s);   // 72 + 16 = 88: 5 waves, one load group
+      case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);  // 96 + 32 = 128: 4 waves, 4 loads in flight
       case 6: return launch_shape<DepthT, GridT, 16, 2, 2, 6, 2>(a, cfg, s);
       default: break;
     }
   }
-  if (shape == 7) return launch_shape<DepthT, GridT, 8, 2, 2, 7, 4>(a, cfg, s);  // 72 + 16 = 88: 5 waves
-  return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);  // 96 + 32 = 128 VGPRs: 4 waves per SIMD
+  // 80 + 16 = 96 VGPRs: 5 waves; the whole column is one load group (8 gathers in flight before the first is consumed)
+  if (shape == 7) return launch_shape<DepthT, GridT, 8, 2, 2, 6, 8>(a, cfg, s);
+  // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight)
+  return launch_shape<DepthT, GridT, 16, 2, 2, 5, 8>(a, cfg, s);
 }
 
 }  // namespace
