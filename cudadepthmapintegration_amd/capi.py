@@ -26,7 +26,7 @@ VARIANT_KEEP_BEHIND_ADDS = 1024  # tiled kernel: perform +0.0 adds even when the
 VARIANT_FIXED_TILE_SHAPE = 4096  # tile-shape bits 0 mean shape 0 (tk16_w5) whatever the grid size; without it grids
                                  # below 512^3 pick tk8_w7 on their own
 VARIANT_SPATIAL_ORDER = 512  # tiled kernel: workgroups in spatial order instead of heaviest bricks first
-VARIANT_TILE_SHAPE = {"tk16_w5_g8": 0, "tk8_w6_g8_2x2": 32, "tk16_w8": 64, "tk8_w6": 96, "tk8_w7_g8": 128, "tk16_w5_g4": 160,
+VARIANT_TILE_SHAPE = {"tk16_w5_g8_1x1": 0, "tk8_w6_g8_2x2": 32, "tk16_w5_g8_2x2": 64, "tk8_w6": 96, "tk8_w7_g8": 128, "tk16_w5_g4": 160,
                       "tk16_w6_g2": 192, "tk8_w6_g8_1x1": 224}  # tiled kernel: column height / compiler register budget / load group
 
 

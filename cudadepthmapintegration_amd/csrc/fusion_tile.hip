@@ -496,12 +496,12 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0);
   if (a.rotated) {  // rotated grid: the two default shapes
     if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
-    return launch_shape<DepthT, GridT, 16, 2, 2, 5, 8, true>(a, cfg, s);
+    return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true>(a, cfg, s);
   }
   if constexpr (std::is_same<DepthT, float>::value) {
     switch (shape) {
       case 1: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 8>(a, cfg, s);   // 8-voxel columns, four waves per workgroup
-      case 2: return launch_shape<DepthT, GridT, 16, 2, 2, 8, 4>(a, cfg, s);  // 64 + 32 = 96: 5 waves, tight compiler budget
+      case 2: return launch_shape<DepthT, GridT, 16, 2, 2, 5, 8>(a, cfg, s);  // 16-voxel columns, four waves per workgroup
       case 3: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 4>(a, cfg, s);   // 80 + 16 = 96: 5 waves
       case 4: return launch_shape<DepthT, GridT, 8, 2, 2, 7, 8>(a, cfg, s);   // 72 + 16 = 88: 5 waves, one load group
       case 5: return launch_shape<DepthT, GridT, 16, 2, 2, 5, 4>(a, cfg, s);  // 96 + 32 = 128: 4 waves, 4 loads in flight
@@ -512,8 +512,8 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   // 80 + 16 = 96 VGPRs: 5 waves; the whole column is one load group (8 gathers in flight before the first is consumed);
   // one wave per workgroup: an 8 x 8 x 8 brick is the unit of scheduling and of the heaviest-first order
   if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
-  // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight)
-  return launch_shape<DepthT, GridT, 16, 2, 2, 5, 8>(a, cfg, s);
+  // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight); one wave per workgroup
+  return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
 }
 
 }  // namespace
@@ -522,6 +522,7 @@ int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VA
 
 TileShape tile_shape(int variant, bool depth_is_f64, bool rotated) {
   switch (effective_shape(variant, depth_is_f64, rotated)) {
+    case 0: return TileShape{16, 1, 1};
     case 7: return TileShape{8, 1, 1};
     case 1:
     case 3:
