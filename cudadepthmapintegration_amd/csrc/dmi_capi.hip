@@ -872,7 +872,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
             ctx->order_capacity = 0;
           }
           DMI_HIP(ctx, hipMalloc(&ctx->d_order, (n_slots + 1) * sizeof(int32_t)));
-          DMI_HIP(ctx, hipMalloc(&ctx->d_order_level, n_slots));
+          DMI_HIP(ctx, hipMalloc(&ctx->d_order_level, dmi::order_scratch_bytes(n_slots)));
           ctx->order_capacity = n_slots;
           ctx->device_bytes += n_slots * 5 + 4;
         }

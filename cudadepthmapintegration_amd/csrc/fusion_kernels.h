@@ -205,6 +205,8 @@ hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, 
 int64_t coarse_class_bytes(const TileArgs &args, int tk);
 // order[p] = slot (super_brick * 32 + brick) of the p-th workgroup, bricks with the most BRICK_MIXED pairs first;
 // level: scratch of super_x*super_y*super_z*32 bytes; wx, wy: waves per workgroup
+// bytes of the `level` scratch of launch_order_bricks for n_slots workgroup slots (levels + per-chunk counts)
+size_t order_scratch_bytes(size_t n_slots);
 hipError_t launch_order_bricks(const TileArgs &args, int wx, int wy, uint8_t *level, int *order, int *n_valid,
                                hipStream_t stream);
 
