@@ -73,17 +73,28 @@ def sharded_tolerance(world: int, abs_partial_sum):
     return (2 * world) * 2.0 ** -24 * abs_partial_sum + 1e-30
 
 
-def slab_ranges(nz: int, n_slabs: int, align: int = 32) -> list[tuple[int, int]]:
+def slab_ranges(nz: int, n_slabs: int, align: int = 32, taper: bool = True) -> list[tuple[int, int]]:
     """nz cell layers split into at most n_slabs contiguous (z_first, z_count) ranges whose inner boundaries are
-    multiples of `align` (dmi.h: DMI_SLAB_ALIGNMENT)."""
+    multiples of `align` (dmi.h: DMI_SLAB_ALIGNMENT).  With `taper` the last slab is about half as thick as the
+    others: its all-reduce is the one piece of the exchange that no fusion hides (fuse_and_all_reduce), so it should
+    be the smallest message; the earlier slabs take up the difference."""
     units = -(-int(nz) // align)
     n = max(1, min(int(n_slabs), units))
-    out = []
-    for s in range(n):
-        lo, hi = view_shard(units, s, n)
-        z0, z1 = min(lo * align, nz), min(hi * align, nz)
+    sizes = []
+    if taper and n >= 2 and units >= 2 * n:
+        last = max(1, units // (2 * n))
+        rest, extra = divmod(units - last, n - 1)
+        sizes = [rest + (1 if s < extra else 0) for s in range(n - 1)] + [last]
+    else:
+        for s in range(n):
+            lo, hi = view_shard(units, s, n)
+            sizes.append(hi - lo)
+    out, lo = [], 0
+    for sz in sizes:
+        z0, z1 = min(lo * align, nz), min((lo + sz) * align, nz)
         if z1 > z0:
             out.append((z0, z1 - z0))
+        lo += sz
     return out
 
 
