@@ -34,6 +34,12 @@ namespace dmi {
 
 namespace {
 
+// read-only data at a wave-uniform address, through the constant address space: a scalar load into SGPRs
+template <typename T>
+__device__ __forceinline__ T cload(const T *p) {
+  return *reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ float float_below(double d) {  // largest float <= d
   float f = (float)d;
   if ((double)f > d) f = nextafterf(f, -__builtin_inff());
@@ -354,7 +360,24 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   BoxFootprint fp;
   fp.query = false;
   fp.cls = BRICK_SKIP;
-  if (mine) fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+  MapRec mr_u;      // one view per wave: the camera records arrive through scalar loads, once, instead of ~35 vector
+  TileMapRec tr_u;  // loads of the same address per lane
+  if constexpr (views_per_wave == 1) {
+    const int mu = __builtin_amdgcn_readfirstlane(m);
+    const MapRec *src = maps + mu;
+    const TileMapRec *tsrc = a.tile_maps + mu;
+#pragma unroll
+    for (int q = 8; q < 12; ++q) mr_u.rt[q] = cload(&src->rt[q]);
+    mr_u.pyramid = cload(&src->pyramid);
+    tr_u.px = cload(&tsrc->px); tr_u.py = cload(&tsrc->py); tr_u.pz = cload(&tsrc->pz); tr_u.p0 = cload(&tsrc->p0);
+    tr_u.qx = cload(&tsrc->qx); tr_u.qy = cload(&tsrc->qy); tr_u.qz = cload(&tsrc->qz); tr_u.q0 = cload(&tsrc->q0);
+    tr_u.err = cload(&tsrc->err);
+    tr_u.cz_err = cload(&tsrc->cz_err);
+    mr = &mr_u;
+    if (mine) fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+  } else {
+    if (mine) fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+  }
   const bool query = mine && fp.query;
   uint8_t cls = fp.cls;
   const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
