@@ -138,6 +138,83 @@ __global__ __launch_bounds__(256) void median_kernel(const uchar4 *__restrict__ 
   for (int c = 0; c < 3; ++c) median[3 * id + c] = cnt > 0 ? (uint8_t)((prefix[c][0] + prefix[c][1]) >> 1) : 0;
 }
 
+// The same medians with two passes over the scratch column instead of eight: per lane, 16-bin histograms of the upper
+// nibble of each channel (pass 1), then of the lower nibble among the entries whose upper nibble holds the wanted
+// rank (pass 2), kept in LDS -- every lane owns a column of counters, two 16-bit counters to a word (so at most
+// 65 535 views; more take the bit-by-bit kernel above).  The pass is bound by the reads of the scratch table
+// (n_views x 4 bytes per vertex per pass), so a quarter of the passes is what counts.
+constexpr int kHistWords = 8;   // 16 bins, two to a 32-bit word
+__global__ __launch_bounds__(256) void median_hist_kernel(const uchar4 *__restrict__ scratch, int64_t nv, int n,
+                                                          const int32_t *__restrict__ count, uint8_t *__restrict__ median) {
+  __shared__ uint32_t hist[6 * kHistWords * 256];  // [table][word][lane]: 48 KB
+  const int lane = threadIdx.x;
+  const int64_t id = (int64_t)blockIdx.x * 256 + lane;
+  const int cnt = id < nv ? count[id] : 0;
+  // rank (0-based) of the upper and of the lower middle element (the same element for an odd count)
+  const int want[2] = {cnt / 2, (cnt & 1) == 0 ? cnt / 2 - 1 : cnt / 2};
+  int hi[3][2] = {{0, 0}, {0, 0}, {0, 0}}, rest[3][2] = {{0, 0}, {0, 0}, {0, 0}}, lo[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  auto bin = [&](int table, int b) -> int {
+    return (int)((hist[(table * kHistWords + (b & 7)) * 256 + lane] >> (16 * (b >> 3))) & 0xffffu);
+  };
+  auto bump = [&](int table, int b) {
+    __hip_atomic_fetch_add(&hist[(table * kHistWords + (b & 7)) * 256 + lane], 1u << (16 * (b >> 3)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // only this lane touches its columns: no barrier anywhere
+  for (int q = 0; q < 3 * kHistWords; ++q) hist[q * 256 + lane] = 0;
+  if (cnt > 0) {
+    for (int m = 0; m < n; ++m) {
+      const uchar4 e = scratch[(int64_t)m * nv + id];
+      if (e.w != 0) {
+        bump(0, e.x >> 4);
+        bump(1, e.y >> 4);
+        bump(2, e.z >> 4);
+      }
+    }
+    for (int c = 0; c < 3; ++c)
+      for (int t = 0; t < 2; ++t) {
+        int k = want[t], b = 0;
+        for (; b < 15; ++b) {
+          const int here = bin(c, b);
+          if (k < here) break;
+          k -= here;
+        }
+        hi[c][t] = b;
+        rest[c][t] = k;
+      }
+  }
+  for (int q = 0; q < 6 * kHistWords; ++q) hist[q * 256 + lane] = 0;
+  if (cnt > 0) {
+    for (int m = 0; m < n; ++m) {
+      const uchar4 e = scratch[(int64_t)m * nv + id];
+      if (e.w != 0) {
+        const int val[3] = {e.x, e.y, e.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int up = val[c] >> 4, low = val[c] & 15;
+          if (up == hi[c][0]) bump(2 * c, low);
+          if (up == hi[c][1]) bump(2 * c + 1, low);
+        }
+      }
+    }
+    for (int c = 0; c < 3; ++c)
+      for (int t = 0; t < 2; ++t) {
+        int k = rest[c][t], b = 0;
+        for (; b < 15; ++b) {
+          const int here = bin(2 * c + t, b);
+          if (k < here) break;
+          k -= here;
+        }
+        lo[c][t] = b;
+      }
+  }
+  if (id < nv) {
+    // (a + b) / 2 in double, then static_cast<unsigned char> (MC.cxx:185): the integer (a + b) >> 1; a == b for odd counts
+    for (int c = 0; c < 3; ++c)
+      median[3 * id + c] = cnt > 0 ? (uint8_t)((((hi[c][0] << 4) | lo[c][0]) + ((hi[c][1] << 4) | lo[c][1])) >> 1) : 0;
+  }
+}
+
 thread_local std::string g_color_error;
 
 struct ColorBatch {
@@ -355,8 +432,12 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     hipLaunchKernelGGL(project_color_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, c->d_views, (int)n_views,
                        c->W, c->H, c->d_scratch, c->d_mean, c->d_count);
     DMI_COLOR_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, c->d_count,
-                       c->d_median);
+    if (n_views <= 65535 && !getenv("DMI_COLOR_BITWISE_MEDIAN"))
+      hipLaunchKernelGGL(median_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, c->d_count,
+                         c->d_median);
+    else
+      hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, c->d_count,
+                         c->d_median);
     DMI_COLOR_HIP(c, hipGetLastError());
     DMI_COLOR_HIP(c, hipEventRecord(c->ev1, c->stream));
     DMI_COLOR_HIP(c, hipMemcpyAsync(mean + 3 * v0, c->d_mean, (size_t)nv * 3, hipMemcpyDeviceToHost, c->stream));
