@@ -5,9 +5,10 @@
 // (brick, map) pair the reference does THE SAME thing to every voxel of the brick (cu:158-212):
 //   * every voxel returns early (behind the camera cu:177, outside the map cu:192-197, no depth cu:202), or
 //   * every voxel accumulates the same constant: -eta*rho (|diff| > delta, diff < 0) or 0 (diff > delta), cu:114-115.
-// This file PROVES that, conservatively, from the eight corner voxels of the brick (computed with the
-// reference's exact expression) and a min/max pyramid of the depth table, and writes one class byte per
-// (brick, map).  The tiled kernel then replaces 16 projections by 16 adds (or nothing).  A pair that cannot
+// This file PROVES that, conservatively, from the eight corner voxels of a box (c.z there exactly as the fusion
+// kernel computes it) and a min/max pyramid of the depth table -- first for boxes of 32^3 voxels, then brick by
+// brick inside the boxes that stay unproven -- and writes one class byte per (brick, map).  The tiled kernel then
+// replaces the brick's projections by as many adds (or nothing).  A pair that cannot
 // be proven is BRICK_MIXED and takes the full per-voxel path, so results stay bit-identical.
 //
 // Proof obligations (DESIGN.md "Brick classes"):
