@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: Gvoxel-projections/s of the TSDF depth-map fusion path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|NxM@WxH]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|NxM@WxH] [--scaling weak|strong]
 
-A step = one pass of the hot path over one batch of synthetic input: zero the grid, fuse every
-HBM-resident depth map of this rank into it (ONE kernel launch), and for N > 1 all-reduce the
-f32 grid over RCCL (the path's only exchange step).  Depth maps are resident before the timed
+A step = one pass of the hot path over one batch of synthetic input: zero the grid, fuse every HBM-resident depth map
+of this rank into it and, for N > 1, sum the f32 grids of the ranks over RCCL (the path's only exchange step; issued
+by the library itself, dmi_multi_fuse, slab by slab behind the fusion).  Depth maps are resident before the timed
 region.  N = 1 workload = BASELINE.json configs[2]: 512^3 voxels x 256 depth maps of 1280x720.
-For N > 1 every rank fuses its own shard of 256 maps (weak scaling: 256*N maps in total).
 
-Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+N > 1: one process per GPU.  Launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) the script joins as a rank; launched plainly (`python bench.py --gpus 2`) it starts the N rank
+processes itself BEFORE anything touches a GPU and relays rank 0's line.  torch.distributed (gloo, CPU) carries only
+the rendezvous: the RCCL unique id, the barriers and the max over ranks; every GPU operation is the C ABI's.
+  weak scaling (top level by default): every rank fuses `maps` views of its own -> N x maps views in total
+  strong scaling ("strong" objects):   the fixed problems of BASELINE.json -- cfg3's 256 views and cfg4's 1024 VGA
+                                       views -- split over the N ranks; the same views whatever N is, and rank 0
+                                       checks the N-rank grid of cfg3 against its own single-GPU fusion of all views
+
+Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
   roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s
   roofline_valu the binding roof of the per-voxel path: fp64 VALU issue (DESIGN.md "Roofline"), measured on
-                the same workload with brick classes switched off (every projection computed), plus how many
-                (brick, view) pairs the default path proved uniform
+                the same workload with brick classes switched off (every projection computed)
   ablation      the same fusion without brick classes / with workgroups in spatial order
   cpu_baseline  the CPU oracle (restated reference arithmetic) timed on this host's cores on a
                 bounded sample of the same workload (N = 1 only)
@@ -23,6 +30,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,6 +52,8 @@ WORKLOADS = {
     "cfg2": ((256, 256, 256), 64, 640, 480),
     "cfg3": ((512, 512, 512), 256, 1280, 720),
     "cfg3vga": ((512, 512, 512), 256, 640, 480),
+    "cfg4": ((512, 512, 512), 1024, 640, 480),
+    "cfg5share": ((1024, 1024, 1024), 64, 1920, 1080),
 }
 
 
@@ -72,36 +83,41 @@ def cpu_baseline(grid, ray, views, target_seconds: float = 15.0):
     p = oracle.make_params(grid.cell_dims, grid.origin, grid.spacing, grid.grid_matrix, ray.thickness, ray.rho,
                            ray.eta, ray.delta, views.width, views.height)
 
-    def run(m):
+    def run(m, threads):
         depth = np.ascontiguousarray(views.depth[:m], dtype=np.float64)
         t0 = time.perf_counter()
-        oracle.fuse(p, depth, views.K4[:m], views.RT4[:m], count_hits=False, n_threads=cores)
+        oracle.fuse(p, depth, views.K4[:m], views.RT4[:m], count_hits=False, n_threads=threads)
         return time.perf_counter() - t0
 
-    probe = run(1)
-    m = int(max(1, min(views.n, round(target_seconds / max(probe, 1e-3)))))
-    dt = run(m)
+    probe = run(2, cores)
+    m = int(max(2, min(views.n, round(2 * target_seconds / max(probe, 1e-3)))))
+    dt = run(m, cores)
     single = None
+    efficiency = None
     if n_vox <= 2e8:  # one thread, one map over the full grid: a few seconds
-        depth1 = np.ascontiguousarray(views.depth[:1], dtype=np.float64)
-        t0 = time.perf_counter()
-        oracle.fuse(p, depth1, views.K4[:1], views.RT4[:1], count_hits=False, n_threads=1)
-        single = {"value": n_vox / (time.perf_counter() - t0) / 1e9, "cores": 1, "sample": "the first depth map over the full grid"}
+        dt1 = run(1, 1)
+        single = {"value": n_vox / dt1 / 1e9, "cores": 1, "sample": "the first depth map over the full grid"}
+        efficiency = (n_vox * m / dt / 1e9) / (cores * single["value"])
     return {
         "single_thread": single,
         "value": n_vox * m / dt / 1e9,
         "unit": "Gvoxel-projections/s",
         "cores": cores,
         "kind": "port",
+        "scaling_efficiency": efficiency,
         "sample": f"{grid.cell_dims[0]}x{grid.cell_dims[1]}x{grid.cell_dims[2]} voxels x first {m} of {views.n} depth "
-                  f"maps, oracle/tsdf_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over z on {cores} threads, {dt:.1f} s",
+                  f"maps, oracle/tsdf_oracle.c (gcc -O2 -ffp-contract=off), one OpenMP region, z-layers dealt dynamically "
+                  f"to {cores} threads, every layer fused through all maps by the thread that first touches it, {dt:.1f} s; "
+                  f"scaling_efficiency = this rate / ({cores} x the single-thread rate)",
     }
 
 
 def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int = 64):
     """Secondary measurement: the MeshColoration pass on the GPU with the colour planes
     resident (dmi_color_context), on synthetic vertices x views of the bench's image size.  `value` counts the
-    kernels only (hipEvents); `seconds` is the whole dmi_color_process call, vertex upload and result download included."""
+    kernels only (hipEvents); `seconds` is the whole dmi_color_process call, vertex upload and result download included.
+    Two vertex orders: random points (every lane gathers from a different place in every plane) and the same points
+    sorted along a space-filling curve, as the vertices of a real mesh are (neighbours in neighbouring lanes)."""
     views = scene.make_views(n_views, 8, 8, seed=77)          # cameras only; the depth tables are not used
     # per-pixel content is irrelevant to the timing: one byte pattern, tiled over all views (fast to generate)
     colors = np.empty((n_views, H, W, 3), dtype=np.uint8)
@@ -110,22 +126,39 @@ def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int 
     K4[:, 0, 0] = K4[:, 1, 1] = 0.9 * W
     K4[:, 0, 2], K4[:, 1, 2] = W / 2.0, H / 2.0
     pts = scene.make_mesh_points(n_vertices, seed=78)
+    ordered = pts[scene.morton_order(pts)]
+    out = {}
     with capi.ColorContext() as c:
         c.add_views(colors, K4, views.RT4)
         c.process(pts[:1000])   # warm-up
-        t0 = time.perf_counter()
-        mean, median, count = c.process(pts)
-        dt = time.perf_counter() - t0
-        kms = c.kernel_ms()
-    return {"value": n_vertices * n_views / (kms * 1e-3) / 1e9, "unit": "Gvertex-projections/s (kernels, views resident)",
-            "vertices": n_vertices, "views": n_views, "image": f"{W}x{H}", "kernel_ms": kms, "seconds": dt,
-            "value_call": n_vertices * n_views / dt / 1e9, "mean_views_per_vertex": float(count.mean())}
+        for name, p in (("random_vertices", pts), ("mesh_ordered_vertices", ordered)):
+            t0 = time.perf_counter()
+            mean, median, count = c.process(p)
+            dt = time.perf_counter() - t0
+            kms = c.kernel_ms()
+            hits = int(count.sum(dtype=np.int64))
+            # algorithmic traffic: every vertex read once (24 B), one RGBA texel gathered per (vertex, view) hit (4 B),
+            # the three outputs written once (3 + 3 + 4 B)
+            b_alg = float(n_vertices * 24 + hits * 4 + n_vertices * 10)
+            out[name] = {"value": n_vertices * n_views / (kms * 1e-3) / 1e9, "kernel_ms": kms, "seconds": dt,
+                         "value_call": n_vertices * n_views / dt / 1e9, "mean_views_per_vertex": float(count.mean()),
+                         "roofline": {"bound": "hbm", "algorithmic_bytes": b_alg, "achieved": b_alg / (kms * 1e-3) / 1e9,
+                                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+    out.update({"unit": "Gvertex-projections/s (kernels, views resident)", "vertices": n_vertices, "views": n_views,
+                "image": f"{W}x{H}",
+                "note": "algorithmic_bytes = 24 B per vertex + 4 B per (vertex, view) pair inside an image + 10 B of "
+                        "outputs per vertex; the gathers are scattered 4-byte reads, so the HBM fraction is low by nature"})
+    # keep the round-1 top-level keys (random vertices) for continuity
+    out["value"] = out["random_vertices"]["value"]
+    out["kernel_ms"] = out["random_vertices"]["kernel_ms"]
+    return out
 
 
-def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, chunk_views: int = 32):
+def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, pcie, chunk_views: int = 32):
     """PCIe-inclusive rate (never the headline value): depth tables start in pinned host memory, go up chunk by chunk on
     the context's upload stream while the previous chunk is being fused (dmi_add_views + dmi_fuse_range), and the grid
-    comes back into pinned host memory.  host f64 / grid f64 is the reference's contract (vtkDoubleArray in and out)."""
+    comes back into pinned host memory.  host f64 / grid f64 is the reference's contract (vtkDoubleArray in and out).
+    pcie_floor_s = the same bytes at the copy rates dmi_pcie_probe measured on this box, nothing else counted."""
     n = views.n
     np_host = np.float64 if host_dtype == "f64" else np.float32
     np_grid = np.float64 if grid_dtype == "f64" else np.float32
@@ -147,9 +180,36 @@ def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, chun
             times.append(time.perf_counter() - t0)
     dt = float(np.median(times[1:]))
     moved = pinned.nbytes + out.nbytes
+    floor = pinned.nbytes / (pcie[0] * 1e9) + out.nbytes / (pcie[1] * 1e9)
     return {"host_depth": host_dtype, "grid": grid_dtype, "seconds": dt, "value": grid.n_voxels * n / dt / 1e9,
             "unit": "Gvoxel-projections/s including H2D of every depth table and D2H of the grid",
-            "pcie_bytes": moved, "pcie_GBps_if_alone": moved / dt / 1e9, "chunk_views": chunk_views}
+            "pcie_bytes": moved, "pcie_GBps_if_alone": moved / dt / 1e9, "chunk_views": chunk_views,
+            "pcie_floor_s": floor, "seconds_over_floor": dt / floor}
+
+
+# ---- launching -------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters, before this
+    process has made any GPU call -- it never makes one) and relay rank 0's output."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DMI_BENCH_LAUNCHED_BY="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -162,6 +222,8 @@ def main():
                     help="dense: background behind the sphere, ~every in-frustum voxel accumulates")
     ap.add_argument("--grid-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: which measurement is the top-level line (the other one is reported beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ablation", action="store_true")
     ap.add_argument("--slabs", type=int, default=4,
@@ -169,6 +231,12 @@ def main():
     ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: all_reduce = the contract (every rank gets the whole grid, overlapped slab by slab); "
                          "reduce_scatter = every rank gets the sum of its own 1/N of the grid (half the traffic, no overlap)")
+    ap.add_argument("--partition", default="views", choices=["views", "z_slabs"],
+                    help="N > 1: views = the north star's depth-map shards + exchange; z_slabs = every rank fuses all views into "
+                         "its own cell layers, no collective")
+    ap.add_argument("--one-process", action="store_true",
+                    help="N > 1: one process drives all N devices (dmi_multi_create / ncclCommInitAll) instead of one process per GPU")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling objects")
     ap.add_argument("--no-coloration", action="store_true")
     ap.add_argument("--coloration-vertices", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -176,108 +244,115 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
-    import torch
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None and not args.one_process:
+        sys.exit(self_launch(args.gpus))
+    world = 1 if args.one_process else int(env_world or "1")
+    rank = 0 if args.one_process else int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.one_process else int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.one_process and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
 
-    from cudadepthmapintegration_amd import capi, scene, sharding
+    import torch  # before the HIP library: one HIP runtime per process (capi.load explains)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
+    from cudadepthmapintegration_amd import capi, scene
+
+    n_dev = capi.device_count()
+    if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the fusion path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    n_ranks = args.gpus  # ranks of the fusion = GPUs, however they are spread over processes
+    if (args.one_process and n_dev < args.gpus) or local_rank >= n_dev:
+        raise SystemExit(f"bench.py: {args.gpus} GPUs asked for, {n_dev} visible")
+    have_torch_gpu = torch.cuda.is_available()
+    if have_torch_gpu:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend="gloo")  # rendezvous only: unique id, barriers, max over ranks (all on the CPU)
+
+    def device_sync():
+        if have_torch_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     cells, maps_per_gpu, W, H = parse_workload(args.workload)
     grid = scene.default_grid(cells)
     ray = scene.default_ray_potential(grid)
     n_vox = grid.n_voxels
+    grid_bytes = 4 if args.grid_dtype == "f32" else 8
+    np_grid = np.float32 if args.grid_dtype == "f32" else np.float64
 
+    if n_ranks > 1:
+        out = multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, world, rank, local_rank, n_ranks)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
+
+    # ---------------------------------------------------------------- N = 1 -----------------------------------
     def make(scene_kind: str):
-        return scene.make_views(maps_per_gpu, W, H, seed=1000 + rank, dense=(scene_kind == "dense"),
-                                layout="sphere", dtype=np.float32)
+        return scene.make_views(maps_per_gpu, W, H, seed=1000, dense=(scene_kind == "dense"), layout="sphere", dtype=np.float32)
 
     views = make(args.scene)
-
-    torch_dtype = torch.float32 if args.grid_dtype == "f32" else torch.float64
-    grid_t = torch.zeros(n_vox, dtype=torch_dtype, device="cuda")
-    # an explicit (non-default) torch stream: the fusion kernel, the grid memset and the RCCL
-    # all-reduce are all ordered on it, and its handle is non-NULL for the C ABI
-    tstream = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
     ctx = capi.FusionContext(grid, ray, device=local_rank, grid_dtype=args.grid_dtype, depth_storage="auto",
-                             kernel_variant=args.variant, stream=stream, external_grid=grid_t.data_ptr())
+                             kernel_variant=args.variant)
     t_up = time.perf_counter()
     ctx.add_views(views)
     upload_s = time.perf_counter() - t_up
     info = ctx.info()
     depth_bytes = 8 if info.depth_storage_in_use == capi.DMI_DEPTH_F64 else 4
-    grid_bytes = 4 if args.grid_dtype == "f32" else 8
-
-    comm_stream = torch.cuda.Stream() if dist is not None else None
 
     def step():
         ctx.reset_grid()
-        if dist is None:
-            ctx.fuse()
-        elif args.exchange == "reduce_scatter":
-            ctx.fuse()
-            sharding.reduce_scatter_grid(grid_t, rank, world)
-        elif args.slabs <= 1:
-            ctx.fuse()
-            sharding.all_reduce_grid(grid_t)  # the single RCCL all-reduce of the TSDF grid over xGMI
-        else:
-            # the same exchange, slab by slab: the all-reduce of slab i overlaps the fusion of slab i + 1
-            sharding.fuse_and_all_reduce(ctx, grid_t, grid.cell_dims, args.slabs, tstream, comm_stream)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        ctx.fuse()
 
     def timed(steps: int, warmup: int):
         for _ in range(warmup):
             step()
+        ctx.synchronize()
+        device_sync()
         barrier()
         k0 = ctx.timings()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        ctx.synchronize()
+        device_sync()
         barrier()
         dt = time.perf_counter() - t0
         k1 = ctx.timings()
-        kern_ms = (k1.total_fuse_kernel_ms - k0.total_fuse_kernel_ms) / max(1, steps)  # per step (a step may fuse in slabs)
+        kern_ms = (k1.total_fuse_kernel_ms - k0.total_fuse_kernel_ms) / max(1, steps)
         timed.main_ms = (k1.total_fuse_main_kernel_ms - k0.total_fuse_main_kernel_ms) / max(1, steps)
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, kern_ms
+        return max_over_ranks(dt), kern_ms
 
     dt, kern_ms = timed(args.steps, args.warmup)
     main_ms = timed.main_ms  # the fusion kernel proper (what rocprofv3 lists as fuse_tile_kernel / fuse_kernel)
     ms_per_step = dt / args.steps * 1e3
-    total_maps = maps_per_gpu * world
-    value = n_vox * total_maps * args.steps / dt / 1e9
+    value = n_vox * maps_per_gpu * args.steps / dt / 1e9
 
-    # ablations on the same resident views (N = 1): brick classes off = every voxel-projection computed
+    # ablations on the same resident views: brick classes off = every voxel-projection computed
     ablation = None
     hist = ctx.brick_class_histogram()
-    if world == 1 and not args.no_ablation:
+    if not args.no_ablation:
         ablation = {}
+        default_grid = ctx.download_grid(np_grid).copy()
         for name, var in (("no_brick_classes", capi.VARIANT_NO_BRICK_CLASSES), ("spatial_order", capi.VARIANT_SPATIAL_ORDER)):
-            g2 = torch.zeros(n_vox, dtype=torch_dtype, device="cuda")
             c2 = capi.FusionContext(grid, ray, device=local_rank, grid_dtype=args.grid_dtype, depth_storage="auto",
-                                    kernel_variant=args.variant | var, stream=stream, external_grid=g2.data_ptr())
+                                    kernel_variant=args.variant | var)
             c2.add_views(views)
             for i in range(3):
                 c2.reset_grid()
@@ -288,28 +363,29 @@ def main():
             ms = (c2.timings().total_fuse_kernel_ms - k0) / 2
             ablation[name] = {"kernel_ms": ms, "value": n_vox * maps_per_gpu / ms / 1e6}
             if name == "no_brick_classes":
-                same = bool(torch.equal(g2, grid_t))
-                ablation[name]["grid_bit_identical_to_default"] = same
+                other = c2.download_grid(np_grid)
+                ablation[name]["grid_bit_identical_to_default"] = bool(
+                    np.array_equal(other.view(np.uint32 if grid_bytes == 4 else np.uint64),
+                                   default_grid.view(np.uint32 if grid_bytes == 4 else np.uint64)))
+                del other
             c2.close()
-            del g2
+        del default_grid
 
     # the step right after the path: cell data -> point data of the fused grid, HBM-bound
-    cell_to_point = None
-    if world == 1:
-        ts = []
-        for _ in range(4):
-            ctx.cell_to_point()
-            ctx.synchronize()
-            ts.append(ctx.timings().last_cell_to_point_ms)
-        c2p_ms = float(np.median(ts[1:]))
-        n_pts = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
-        c2p_bytes = float((4 if args.grid_dtype == "f32" else 8) * n_vox + 8 * n_pts)
-        cell_to_point = {"kernel": "dmi::cell_to_point_kernel", "kernel_ms": c2p_ms, "bound": "hbm",
-                         "algorithmic_bytes": c2p_bytes, "achieved": c2p_bytes / (c2p_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c2p_bytes / (c2p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    ts = []
+    for _ in range(4):
+        ctx.cell_to_point()
+        ctx.synchronize()
+        ts.append(ctx.timings().last_cell_to_point_ms)
+    c2p_ms = float(np.median(ts[1:]))
+    n_pts = (cells[0] + 1) * (cells[1] + 1) * (cells[2] + 1)
+    c2p_bytes = float(grid_bytes * n_vox + 8 * n_pts)
+    cell_to_point = {"kernel": "dmi::cell_to_point_kernel", "kernel_ms": c2p_ms, "bound": "hbm",
+                     "algorithmic_bytes": c2p_bytes, "achieved": c2p_bytes / (c2p_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c2p_bytes / (c2p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     secondary = None
-    if args.secondary and world == 1:
+    if args.secondary:
         other = "sparse" if args.scene == "dense" else "dense"
         v2 = make(other)
         ctx.clear_views()
@@ -339,12 +415,12 @@ def main():
         "metric": "Gvoxel-projections/s",
         "value": value,
         "unit": "Gvoxel-projections/s",
-        "n_gpus": world,
+        "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -356,11 +432,9 @@ def main():
             "k_mode": int(info.k_mode),
             "tiled_kernel": int(info.tiled_kernel),
             "kernel_variant": args.variant,
-            "maps_total": total_maps,
-            "parallelism": ((f"depth-map shards x{world}, RCCL reduce-scatter of the grid (each rank keeps 1/{world})"
-                             if args.exchange == "reduce_scatter" else
-                             f"depth-map shards x{world}, RCCL all-reduce of the grid in {args.slabs} z-slabs overlapped with "
-                             f"the fusion") if world > 1 else "single GPU"),
+            "maps_total": maps_per_gpu,
+            "parallelism": "single GPU",
+            "rccl_ranks": 0,
             "host_upload_s": round(upload_s, 3),
         },
         "roofline": {
@@ -395,21 +469,165 @@ def main():
         out["ablation"] = ablation
     if secondary:
         out["secondary"] = secondary
-    if cell_to_point:
-        out["cell_to_point"] = cell_to_point
-    if rank == 0 and world == 1 and not args.no_end_to_end:
-        out["end_to_end"] = [end_to_end_probe(scene, capi, grid, ray, views, "f32", "f32"),
-                             end_to_end_probe(scene, capi, grid, ray, views, "f64", "f64")]
-    if rank == 0 and world == 1 and not args.no_coloration:
+    out["cell_to_point"] = cell_to_point
+    if not args.no_end_to_end:
+        pcie = capi.pcie_probe(local_rank)
+        out["pcie_GBps"] = {"h2d": pcie[0], "d2h": pcie[1]}
+        out["end_to_end"] = [end_to_end_probe(scene, capi, grid, ray, views, "f32", "f32", pcie),
+                             end_to_end_probe(scene, capi, grid, ray, views, "f64", "f64", pcie),
+                             end_to_end_probe(scene, capi, grid, ray, views, "f64", "f32", pcie)]
+    if not args.no_coloration:
         out["coloration"] = coloration_probe(scene, capi, args.coloration_vertices, W, H)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(grid, ray, views, args.cpu_seconds)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+
+
+# ---- N > 1 -------------------------------------------------------------------------------------------------------
+def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, world, rank, local_rank, n_ranks):
+    """Every measurement of the N-GPU run; returns rank 0's JSON object.  `world` processes drive `n_ranks` GPUs: one
+    each (the usual launch), or one process all of them (--one-process)."""
+    cells, maps_per_gpu, W, H = parse_workload(args.workload)
+    grid = scene.default_grid(cells)
+    ray = scene.default_ray_potential(grid)
+    n_vox = grid.n_voxels
+    np_grid = np.float32 if args.grid_dtype == "f32" else np.float64
+    dense = args.scene == "dense"
+
+    unique_id = None
+    if not args.one_process and args.partition == "views":
+        box = [capi.multi_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        unique_id = box[0]
+
+    def create(g):
+        kw = dict(grid_dtype=args.grid_dtype, depth_storage="auto", kernel_variant=args.variant, partition=args.partition,
+                  exchange=args.exchange, n_slabs=args.slabs)
+        if args.one_process:
+            return capi.MultiContext(g, ray, devices=list(range(n_ranks)), **kw)
+        return capi.MultiContext(g, ray, rank=rank, world=world, unique_id=unique_id, device=local_rank, **kw)
+
+    my_ranks = list(range(n_ranks)) if args.one_process else [rank]
+
+    def upload(m, n_total, w, h, seed, shard_views: bool):
+        """Views of an n_total-camera scene onto this process's ranks: each rank its share (views partition of a fixed
+        problem), or every rank everything (z-slabs)."""
+        for li, r in enumerate(my_ranks):
+            lo, hi = capi.multi_view_shard(n_total, r, n_ranks) if shard_views else (0, n_total)
+            for c0 in range(lo, hi, 64):   # bounded host memory: 64 views at a time
+                c1 = min(hi, c0 + 64)
+                v = scene.make_views(n_total, w, h, seed=seed, dense=dense, layout="sphere", dtype=np.float32, view_range=(c0, c1))
+                m.add_views(v, local_index=li)
+
+    def timed(m, steps, warmup):
+        for _ in range(warmup):
+            m.fuse()
+        m.synchronize()
+        device_sync()
+        barrier()
+        k0 = m.local_timings(0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.fuse()
+        m.synchronize()
+        device_sync()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        t = m.timings()
+        k1 = m.local_timings(0)
+        timed.main_ms = (k1.total_fuse_main_kernel_ms - k0.total_fuse_main_kernel_ms) / max(1, steps)
+        return dt, t.last_step_ms, t.last_fuse_kernel_ms
+
+    def measure(name, cells_, n_total, w, h, seed, steps, warmup, check: bool):
+        g = scene.default_grid(cells_)
+        m = create(g)
+        upload(m, n_total, w, h, seed, shard_views=(args.partition == "views"))
+        dt, step_ms, fuse_ms = timed(m, steps, warmup)
+        info = m.info()
+        li = m.local_info(0)
+        views_rank0 = int(li.n_views)
+        depth_b = 8 if li.depth_storage_in_use == capi.DMI_DEPTH_F64 else 4
+        b_alg = algorithmic_bytes(int(li.n_voxels), views_rank0, w, h, 4 if args.grid_dtype == "f32" else 8, depth_b)
+        main_ms = timed.main_ms
+        rec = {"workload": name, "maps_total": n_total, "ms_per_step": dt / steps * 1e3,
+               "value": g.n_voxels * n_total * steps / dt / 1e9, "rank0_step_ms": step_ms, "rank0_fuse_kernel_ms": fuse_ms,
+               "rank0_exchange_exposed_ms": max(0.0, step_ms - fuse_ms), "rccl_ranks": int(info.rccl_ranks),
+               "views_on_this_process": int(info.n_views_local),
+               "roofline": {"bound": "hbm", "achieved": b_alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else None,
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": b_alg / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if main_ms > 0 else None, "traffic": None,
+                            "kernel": "dmi::fuse_tile_kernel" if li.tiled_kernel else "dmi::fuse_kernel", "kernel_ms": main_ms,
+                            "algorithmic_bytes_per_launch": b_alg,
+                            "note": "rank 0's fusion kernel (all slabs of one step) over the algorithmic bytes of its own "
+                                    "views and grid; the path is bound by fp64 VALU issue, not HBM (DESIGN.md)"}}
+        if check and rank == 0 and args.partition == "views" and args.exchange == "all_reduce":
+            # the N-rank grid against this GPU's own fusion of ALL views (same views whatever N is)
+            got, _ = m.download_grid(np_grid)
+            got = got.copy()
+            with capi.FusionContext(g, ray, device=local_rank, grid_dtype=args.grid_dtype) as one:
+                for c0 in range(0, n_total, 64):
+                    c1 = min(n_total, c0 + 64)
+                    one.add_views(scene.make_views(n_total, w, h, seed=seed, dense=dense, layout="sphere", dtype=np.float32,
+                                                   view_range=(c0, c1)))
+                one.fuse()
+                want = one.download_grid(np_grid)
+            diff = float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))))
+            # |delta| <= 2 G 2^-24 sum|partials| per voxel (sharding.sharded_tolerance); sum|partials| <= views x rho
+            tol = 2 * n_ranks * 2.0 ** -24 * n_total * abs(ray.rho)
+            rec["check_vs_single_gpu"] = {"max_abs_diff": diff, "tolerance": tol, "within_tolerance": bool(diff <= tol),
+                                          "max_abs_value": float(np.max(np.abs(want)))}
+        m.close()
+        return rec, info
+
+    # weak: every rank `maps_per_gpu` views of its own = the shares of one (N x maps)-camera scene
+    weak, info = measure(f"{args.workload} x {n_ranks} (weak: {maps_per_gpu} views per GPU)", cells, maps_per_gpu * n_ranks, W, H,
+                         1000, args.steps, args.warmup, check=False)
+    strong = []
+    if not args.no_strong:
+        # the fixed problems: the same `maps_per_gpu` views as the 1-GPU run, and BASELINE.json's cfg4
+        rec, _ = measure(f"{args.workload} (strong: {maps_per_gpu} views in all)", cells, maps_per_gpu, W, H, 1000,
+                         args.steps, args.warmup, check=True)
+        strong.append(rec)
+        if args.workload == "cfg3":
+            c4, n4, w4, h4 = WORKLOADS["cfg4"]
+            rec, _ = measure("cfg4 (strong: 512^3 x 1024 views of 640x480 in all)", c4, n4, w4, h4, 1004, args.steps,
+                             args.warmup, check=False)
+            strong.append(rec)
+    top = weak if (args.scaling == "weak" or not strong) else strong[0]
+    exchange_txt = {"all_reduce": f"one RCCL all-reduce of the {args.grid_dtype} grid in {info.n_slabs} z-slabs overlapped with the fusion",
+                    "reduce_scatter": f"RCCL reduce-scatter of the grid (each rank keeps 1/{n_ranks})"}[args.exchange]
+    out = {
+        "metric": "Gvoxel-projections/s",
+        "value": top["value"],
+        "unit": "Gvoxel-projections/s",
+        "n_gpus": n_ranks,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": top["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "weak" if top is weak else "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{cells[0]}x{cells[1]}x{cells[2]} voxels, depth maps {W}x{H}, {top['maps_total']} in all "
+                        f"({args.workload}, {args.scene} sphere scene)",
+            "grid_dtype": args.grid_dtype,
+            "kernel_variant": args.variant,
+            "maps_total": top["maps_total"],
+            "parallelism": (f"depth-map shards x{n_ranks}, {exchange_txt}" if args.partition == "views"
+                            else f"z-slabs x{n_ranks}: every rank fuses all views into its own cell layers, no collective"),
+            "processes": world,
+            "rccl_ranks": int(info.rccl_ranks),
+            "rccl_version": int(info.rccl_version),
+            "launched_by": os.environ.get("DMI_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "bench.py --one-process"),
+        },
+        "roofline": top["roofline"],
+        "weak": weak,
+        "strong": strong,
+    }
+    return out
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libdmi_hip.so")
 
-SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "host/recon_host.cpp", "host/vti_reader.cpp", "host/dmi_host_capi.cpp"]
+SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "dmi_multi.hip", "host/recon_host.cpp", "host/vti_reader.cpp", "host/dmi_host_capi.cpp"]
 HEADERS = ["fusion_kernels.h", "fusion_device.h", "fusion_tile_acc.inc", os.path.join("host", "recon_host.h"),
            os.path.join("host", "vti_reader.h"),
            os.path.join("..", "..", "include", "dmi.h"), os.path.join("..", "..", "include", "dmi_host.h")]
@@ -30,6 +30,12 @@ COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-ma
 # -disable-promote-alloca-to-vector: without it hipcc turns the tiled kernel's register accumulators into one
 # 32-register tuple that it spills and reloads whole (3000+ spill instructions at 4 waves per SIMD).
 HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector"]
+# DMI_TUNING=1 in the environment of the BUILD compiles the experiment switches of tools/ in (getenv-driven launch
+# geometry, dropped depth loads ...).  The default library contains none of them.
+if os.environ.get("DMI_TUNING"):  # a separate library and object directory: never mistaken for the shipped one
+    COMMON_FLAGS = COMMON_FLAGS + ["-DDMI_TUNING"]
+    OBJ_DIR = os.path.join(ROOT, "build", "obj_tuning")
+    LIB_PATH = os.path.join(CSRC, "libdmi_hip_tuning.so")
 
 
 def hipcc_path() -> str:
@@ -63,12 +69,89 @@ def needs_build() -> bool:
     return _stale(LIB_PATH, deps)
 
 
+ACC_BASES = {8: 64, 7: 72, 6: 80, 5: 96}  # __launch_bounds__ MINW -> first accumulator VGPR (fusion_tile.hip acc_base)
+
+
+def audit_accumulator_registers(asm_text: str) -> tuple[int, list[str]]:
+    """The tiled kernel keeps its running sums in v[BASE .. BASE+2*TK), registers the compiler is told nothing about
+    beyond clobber lists (fusion_tile_acc.inc).  That is only sound if no COMPILER-generated instruction of any
+    fuse_tile_kernel instantiation names a VGPR at or above BASE, and if the kernel descriptor allocates all of them.
+    Returns (instantiations checked, violations)."""
+    import re
+
+    bad: list[str] = []
+    checked = 0
+    for body in re.split(r"\n(?=_ZN3dmi\S*fuse_tile_kernel\S*:)", asm_text):
+        m = re.match(r"(_ZN3dmi\S*fuse_tile_kernelI\w+):", body)
+        if not m:
+            continue
+        name = m.group(1)
+        tpl = re.search(r"fuse_tile_kernelI\w\wLi(\d+)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])", name)
+        tk, minw = int(tpl.group(1)), int(tpl.group(4))
+        base = ACC_BASES.get(minw, 128)
+        code = body[: body.find("s_endpgm")]
+        in_asm = False
+        for line in code.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+                continue
+            if "#ASMEND" in line:
+                in_asm = False
+                continue
+            if in_asm or not re.match(r"\s+(v_|global_|buffer_|ds_|scratch_|flat_)", line):
+                continue
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", line)]
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
+                regs += [int(a), int(b)]
+            if any(r >= base for r in regs):
+                bad.append(f"{name}: compiler instruction touches the accumulator file (base v{base}): {line.strip()}")
+        # the descriptor must allocate the accumulators: .amdhsa_next_free_vgpr of this kernel >= BASE + 2*TK
+        d = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\b.*?\.amdhsa_next_free_vgpr (\d+)", asm_text, re.S)
+        if not d:
+            bad.append(f"{name}: no kernel descriptor found")
+        elif int(d.group(1)) < base + 2 * tk:
+            bad.append(f"{name}: descriptor allocates {d.group(1)} VGPRs, the accumulators need {base + 2 * tk}")
+        checked += 1
+    if checked == 0:
+        bad.append("no fuse_tile_kernel instantiation found in the assembly")
+    return checked, bad
+
+
+def run_accumulator_audit(verbose: bool = False) -> int:
+    """Compile fusion_tile.hip to gfx950 assembly with the build's flags and audit it; raises on any violation.
+    Runs inside build() whenever fusion_tile.hip is recompiled, and as a non-GPU test."""
+    import json
+    import tempfile
+
+    hipcc = hipcc_path()
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "fusion_tile.s")
+        cmd = [hipcc] + COMMON_FLAGS + HIP_FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, "fusion_tile.hip"), "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(out) as fh:
+            text = fh.read()
+    checked, bad = audit_accumulator_registers(text)
+    if bad:
+        raise RuntimeError("accumulator-register audit of fusion_tile.hip FAILED (a toolchain change broke the hidden "
+                           "register file; results would be silently wrong):\n  " + "\n  ".join(bad[:20]))
+    version = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, "acc_audit.json"), "w") as fh:
+        json.dump({"instantiations": checked, "violations": 0, "hipcc": version[:2]}, fh)
+    if verbose:
+        print(f"accumulator audit: {checked} fuse_tile_kernel instantiations clean ({version[0] if version else 'hipcc'})", flush=True)
+    return checked
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = _headers()
+    audit_marker = os.path.join(OBJ_DIR, "acc_audit.json")
 
     def compile_one(src: str):
         path = os.path.join(CSRC, src)
@@ -81,9 +164,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
+    def audit_if_needed(_):
+        # same staleness rule as the object: a recompiled tiled kernel is a re-audited one
+        if force or _stale(audit_marker, [os.path.join(CSRC, "fusion_tile.hip")] + headers):
+            run_accumulator_audit(verbose)
+
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(compile_one, _sources()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-lz", "-o", LIB_PATH]  # zlib: compressed .vti arrays (host/vti_reader.cpp)
+        jobs = [ex.submit(compile_one, s) for s in _sources()] + [ex.submit(audit_if_needed, None)]
+        for j in jobs:
+            j.result()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-lz", "-ldl", "-pthread", "-o", LIB_PATH]  # zlib: compressed .vti arrays (host/vti_reader.cpp)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -60,15 +61,42 @@ class InfoC(ctypes.Structure):
                 ("tiled_kernel", ctypes.c_int32), ("device_bytes", ctypes.c_uint64)]
 
 
+class MultiOptionsC(ctypes.Structure):
+    _fields_ = [("grid_dtype", ctypes.c_int32), ("depth_storage", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
+                ("partition", ctypes.c_int32), ("exchange", ctypes.c_int32), ("n_slabs", ctypes.c_int32)]
+
+
+class MultiInfoC(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int32), ("n_local", ctypes.c_int32), ("first_rank", ctypes.c_int32),
+                ("rccl_ranks", ctypes.c_int32), ("rccl_version", ctypes.c_int32), ("partition", ctypes.c_int32),
+                ("exchange", ctypes.c_int32), ("n_slabs", ctypes.c_int32), ("n_voxels", ctypes.c_int64),
+                ("n_views_total", ctypes.c_int64), ("n_views_local", ctypes.c_int64)]
+
+
+class MultiTimingsC(ctypes.Structure):
+    _fields_ = [("last_step_ms", ctypes.c_double), ("last_fuse_kernel_ms", ctypes.c_double),
+                ("total_step_ms", ctypes.c_double), ("steps", ctypes.c_uint64)]
+
+
+DMI_PARTITION_VIEWS, DMI_PARTITION_Z_SLABS = 0, 1
+DMI_EXCHANGE_ALL_REDUCE, DMI_EXCHANGE_REDUCE_SCATTER = 0, 1
+DMI_UNIQUE_ID_BYTES = 128
+
 # every symbol include/dmi.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
     "dmi_default_options", "dmi_create", "dmi_destroy", "dmi_last_error", "dmi_add_views", "dmi_add_views_f32",
     "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_fuse_slab", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
-    "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_abi_version", "dmi_device_count",
+    "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
     "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram",
+    "dmi_color_set_scratch_budget",
+    "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_create",
+    "dmi_multi_get_unique_id", "dmi_multi_create_rank", "dmi_multi_destroy", "dmi_multi_last_error", "dmi_multi_add_views",
+    "dmi_multi_add_views_f32", "dmi_multi_add_local_views", "dmi_multi_add_local_views_f32", "dmi_multi_clear_views", "dmi_multi_fuse", "dmi_multi_synchronize",
+    "dmi_multi_download_grid_f32", "dmi_multi_download_grid_f64", "dmi_multi_get_info", "dmi_multi_get_timings",
+    "dmi_multi_local_context",
 ]
 
 _lib = None
@@ -89,6 +117,14 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if "torch" not in sys.modules:
+        # torch ships its own libamdhip64 / librccl (same SONAMEs as ROCm's).  Whichever is loaded first serves the whole
+        # process; if ROCm's came first, a later `import torch` finds no GPU.  So when torch exists it goes first and this
+        # library, bench.py and torch.distributed all share one HIP runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension is required, there is no CPU fallback")
@@ -125,6 +161,7 @@ def load() -> ctypes.CDLL:
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.dmi_free_pinned.argtypes = [vp]
+    L.dmi_pcie_probe.argtypes = [i32, ctypes.c_size_t, dp, dp]
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.dmi_color_mesh.argtypes = [dp, ctypes.c_int64, u8p, dp, dp, i32, i32, i32, i32, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
     L.dmi_color_create.argtypes = [i32, ctypes.POINTER(vp)]
@@ -134,8 +171,36 @@ def load() -> ctypes.CDLL:
     L.dmi_color_clear_views.argtypes = [vp]
     L.dmi_color_process.argtypes = [vp, dp, ctypes.c_int64, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
     L.dmi_color_get_kernel_ms.argtypes = [vp, dp]
+    L.dmi_color_set_scratch_budget.argtypes = [vp, ctypes.c_uint64]
     L.dmi_color_last_error.argtypes = []
     L.dmi_color_last_error.restype = ctypes.c_char_p
+    i64, i64p, i32p = ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
+    L.dmi_multi_default_options.argtypes = [ctypes.POINTER(MultiOptionsC)]
+    L.dmi_multi_default_options.restype = None
+    L.dmi_multi_view_shard.argtypes = [i64, i32, i32, i64p, i64p]
+    L.dmi_multi_z_slab.argtypes = [i32, i32, i32, i32p, i32p]
+    L.dmi_multi_slab_ranges.argtypes = [i32, i32, i32p, i32p, i32]
+    L.dmi_multi_create.argtypes = [ctypes.POINTER(GridDescC), ctypes.POINTER(RayPotentialC), ctypes.POINTER(MultiOptionsC),
+                                   i32p, i32, ctypes.POINTER(vp)]
+    L.dmi_multi_get_unique_id.argtypes = [u8p]
+    L.dmi_multi_create_rank.argtypes = [ctypes.POINTER(GridDescC), ctypes.POINTER(RayPotentialC), ctypes.POINTER(MultiOptionsC),
+                                        i32, i32, i32, u8p, ctypes.POINTER(vp)]
+    L.dmi_multi_destroy.argtypes = [vp]
+    L.dmi_multi_destroy.restype = None
+    L.dmi_multi_last_error.argtypes = [vp]
+    L.dmi_multi_last_error.restype = ctypes.c_char_p
+    L.dmi_multi_add_views.argtypes = [vp, dp, dp, dbl, dp, dp, i32, i32, i32]
+    L.dmi_multi_add_views_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float), dp, dp, i32, i32, i32]
+    L.dmi_multi_add_local_views.argtypes = [vp, i32, dp, dp, dbl, dp, dp, i32, i32, i32]
+    L.dmi_multi_add_local_views_f32.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), dp, dp, i32, i32, i32]
+    L.dmi_multi_clear_views.argtypes = [vp]
+    L.dmi_multi_fuse.argtypes = [vp]
+    L.dmi_multi_synchronize.argtypes = [vp]
+    L.dmi_multi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i64p, i64p]
+    L.dmi_multi_download_grid_f64.argtypes = [vp, dp, i64p, i64p]
+    L.dmi_multi_get_info.argtypes = [vp, ctypes.POINTER(MultiInfoC)]
+    L.dmi_multi_get_timings.argtypes = [vp, ctypes.POINTER(MultiTimingsC)]
+    L.dmi_multi_local_context.argtypes = [vp, i32, ctypes.POINTER(vp)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:
@@ -157,6 +222,16 @@ def pinned_empty(shape, dtype) -> np.ndarray:
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
+def pcie_probe(device: int = 0, n_bytes: int = 256 << 20) -> tuple[float, float]:
+    """(host-to-device, device-to-host) GB/s of one pinned hipMemcpyAsync each way (dmi_pcie_probe)."""
+    L = load()
+    a, b = ctypes.c_double(), ctypes.c_double()
+    rc = L.dmi_pcie_probe(int(device), int(n_bytes), ctypes.byref(a), ctypes.byref(b))
+    if rc != DMI_OK:
+        raise DmiError(rc, L.dmi_last_error(None).decode())
+    return float(a.value), float(b.value)
+
+
 def device_count() -> int:
     return int(load().dmi_device_count())
 
@@ -173,14 +248,7 @@ class FusionContext:
                  stream: int | None = None, external_grid: int | None = None, z_first: int = 0):
         self._lib = load()
         self._h = ctypes.c_void_p()
-        g = GridDescC()
-        for i in range(3):
-            g.cell_dims[i] = int(grid.cell_dims[i])
-            g.origin[i] = float(grid.origin[i])
-            g.spacing[i] = float(grid.spacing[i])
-        gm = np.ascontiguousarray(grid.grid_matrix, dtype=np.float64).reshape(16)
-        for i in range(16):
-            g.grid_matrix[i] = gm[i]
+        g = _grid_c(grid)
         r = RayPotentialC(float(ray.thickness), float(ray.rho), float(ray.eta), float(ray.delta))
         o = OptionsC()
         self._lib.dmi_default_options(ctypes.byref(o))
@@ -329,6 +397,191 @@ class FusionContext:
         return i
 
 
+def _grid_c(grid: GridDesc) -> GridDescC:
+    g = GridDescC()
+    for i in range(3):
+        g.cell_dims[i] = int(grid.cell_dims[i])
+        g.origin[i] = float(grid.origin[i])
+        g.spacing[i] = float(grid.spacing[i])
+    gm = np.ascontiguousarray(grid.grid_matrix, dtype=np.float64).reshape(16)
+    for i in range(16):
+        g.grid_matrix[i] = gm[i]
+    return g
+
+
+def multi_view_shard(n: int, rank: int, world: int) -> tuple[int, int]:
+    """[lo, hi) of n items for `rank` of `world` (dmi_multi_view_shard; needs no GPU)."""
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    if load().dmi_multi_view_shard(int(n), int(rank), int(world), ctypes.byref(a), ctypes.byref(b)) != DMI_OK:
+        raise ValueError("rank/world out of range")
+    return int(a.value), int(a.value + b.value)
+
+
+def multi_z_slab(nz: int, rank: int, world: int) -> tuple[int, int]:
+    """Cell layers [z0, z1) of `rank` under DMI_PARTITION_Z_SLABS (dmi_multi_z_slab; needs no GPU)."""
+    a, b = ctypes.c_int32(), ctypes.c_int32()
+    if load().dmi_multi_z_slab(int(nz), int(rank), int(world), ctypes.byref(a), ctypes.byref(b)) != DMI_OK:
+        raise ValueError("rank/world out of range")
+    return int(a.value), int(a.value + b.value)
+
+
+def multi_slab_ranges(nz: int, n_slabs: int) -> list[tuple[int, int]]:
+    """(z_first, z_count) of the z-slabs of the overlapped exchange (dmi_multi_slab_ranges; needs no GPU)."""
+    a, b = (ctypes.c_int32 * 64)(), (ctypes.c_int32 * 64)()
+    n = load().dmi_multi_slab_ranges(int(nz), int(n_slabs), a, b, 64)
+    return [(int(a[i]), int(b[i])) for i in range(n)]
+
+
+def multi_unique_id() -> bytes:
+    """The 128-byte id rank 0 creates and the launcher hands to every rank (dmi_multi_get_unique_id)."""
+    L = load()
+    buf = (ctypes.c_uint8 * DMI_UNIQUE_ID_BYTES)()
+    rc = L.dmi_multi_get_unique_id(buf)
+    if rc != DMI_OK:
+        raise DmiError(rc, L.dmi_multi_last_error(None).decode())
+    return bytes(buf)
+
+
+class MultiContext:
+    """One fusion over several GPUs (dmi_multi_create / dmi_multi_create_rank ... dmi_multi_destroy).
+
+    devices=[...]                      all ranks in this process
+    rank=, world=, unique_id=, device= one rank per process (unique_id from multi_unique_id() on rank 0)"""
+
+    def __init__(self, grid: GridDesc, ray: RayPotential, *, devices=None, rank: int | None = None, world: int | None = None,
+                 unique_id: bytes | None = None, device: int = 0, grid_dtype: str = "f32", depth_storage: str = "auto",
+                 kernel_variant: int = 0, partition: str = "views", exchange: str = "all_reduce", n_slabs: int = 0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        o = MultiOptionsC()
+        self._lib.dmi_multi_default_options(ctypes.byref(o))
+        o.grid_dtype = {"f32": DMI_F32, "f64": DMI_F64}[grid_dtype]
+        o.depth_storage = {"auto": DMI_DEPTH_AUTO, "f32": DMI_DEPTH_F32, "f64": DMI_DEPTH_F64}[depth_storage]
+        o.kernel_variant = int(kernel_variant)
+        o.partition = {"views": DMI_PARTITION_VIEWS, "z_slabs": DMI_PARTITION_Z_SLABS}[partition]
+        o.exchange = {"all_reduce": DMI_EXCHANGE_ALL_REDUCE, "reduce_scatter": DMI_EXCHANGE_REDUCE_SCATTER}[exchange]
+        o.n_slabs = int(n_slabs)
+        g = _grid_c(grid)
+        r = RayPotentialC(float(ray.thickness), float(ray.rho), float(ray.eta), float(ray.delta))
+        self.grid = grid
+        self.grid_dtype = grid_dtype
+        self.n_voxels = grid.n_voxels
+        if devices is not None:
+            d = (ctypes.c_int32 * len(devices))(*[int(x) for x in devices])
+            rc = self._lib.dmi_multi_create(ctypes.byref(g), ctypes.byref(r), ctypes.byref(o), d, len(devices), ctypes.byref(self._h))
+        else:
+            if rank is None or world is None:
+                raise ValueError("MultiContext needs devices=[...] or rank= and world=")
+            idbuf = None
+            if unique_id is not None:
+                if len(unique_id) != DMI_UNIQUE_ID_BYTES:
+                    raise ValueError("unique_id must be 128 bytes")
+                idbuf = (ctypes.c_uint8 * DMI_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+            rc = self._lib.dmi_multi_create_rank(ctypes.byref(g), ctypes.byref(r), ctypes.byref(o), int(device), int(rank),
+                                                 int(world), idbuf, ctypes.byref(self._h))
+        if rc != DMI_OK:
+            self._h = ctypes.c_void_p()
+            raise DmiError(rc, self._lib.dmi_multi_last_error(None).decode())
+
+    def _check(self, rc: int):
+        if rc != DMI_OK:
+            raise DmiError(rc, self._lib.dmi_multi_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dmi_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_views(self, views: Views, threshold: float | None = None, local_index: int | None = None):
+        """local_index None: the SAME batch on every rank; each rank takes its share (views partition) or all of it
+        (z-slabs).  local_index i: views of local rank i alone (the caller has partitioned, dmi_multi_add_local_views)."""
+        n, H, W = views.depth.shape
+        K4 = np.ascontiguousarray(views.K4, dtype=np.float64).reshape(n, 16)
+        RT4 = np.ascontiguousarray(views.RT4, dtype=np.float64).reshape(n, 16)
+        L = self._lib
+        if views.depth.dtype == np.float32:
+            d = np.ascontiguousarray(views.depth)
+            dptr = d.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            if local_index is None:
+                self._check(L.dmi_multi_add_views_f32(self._h, dptr, _dp(K4), _dp(RT4), n, W, H))
+            else:
+                self._check(L.dmi_multi_add_local_views_f32(self._h, int(local_index), dptr, _dp(K4), _dp(RT4), n, W, H))
+            return
+        d = np.ascontiguousarray(views.depth, dtype=np.float64)
+        bc = None
+        if views.best_cost is not None and threshold is not None:
+            bc = np.ascontiguousarray(views.best_cost, dtype=np.float64)
+        thr = float(threshold) if threshold is not None else 0.0
+        if local_index is None:
+            self._check(L.dmi_multi_add_views(self._h, _dp(d), _dp(bc) if bc is not None else None, thr, _dp(K4), _dp(RT4), n, W, H))
+        else:
+            self._check(L.dmi_multi_add_local_views(self._h, int(local_index), _dp(d), _dp(bc) if bc is not None else None, thr,
+                                                    _dp(K4), _dp(RT4), n, W, H))
+
+    def clear_views(self):
+        self._check(self._lib.dmi_multi_clear_views(self._h))
+
+    def fuse(self):
+        self._check(self._lib.dmi_multi_fuse(self._h))
+
+    def synchronize(self):
+        self._check(self._lib.dmi_multi_synchronize(self._h))
+
+    def download_grid(self, dtype=np.float32, out: np.ndarray | None = None):
+        """(grid as [nz, ny, nx], (first, count)): the element range of the flat grid this process's ranks own."""
+        nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        if out is None:
+            out = np.zeros(self.n_voxels, dtype=dtype)
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        if np.dtype(dtype) == np.float64:
+            self._check(self._lib.dmi_multi_download_grid_f64(self._h, _dp(out), ctypes.byref(a), ctypes.byref(b)))
+        else:
+            self._check(self._lib.dmi_multi_download_grid_f32(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                              ctypes.byref(a), ctypes.byref(b)))
+        return out.reshape(nz, ny, nx), (int(a.value), int(b.value))
+
+    def info(self) -> MultiInfoC:
+        i = MultiInfoC()
+        self._check(self._lib.dmi_multi_get_info(self._h, ctypes.byref(i)))
+        return i
+
+    def timings(self) -> MultiTimingsC:
+        t = MultiTimingsC()
+        self._check(self._lib.dmi_multi_get_timings(self._h, ctypes.byref(t)))
+        return t
+
+    def local_timings(self, local_index: int = 0) -> TimingsC:
+        """dmi_timings of one local rank's single-GPU context."""
+        h = ctypes.c_void_p()
+        self._check(self._lib.dmi_multi_local_context(self._h, int(local_index), ctypes.byref(h)))
+        t = TimingsC()
+        if h:
+            rc = self._lib.dmi_get_timings(h, ctypes.byref(t))
+            if rc != DMI_OK:
+                raise DmiError(rc, self._lib.dmi_last_error(h).decode())
+        return t
+
+    def local_info(self, local_index: int = 0) -> InfoC:
+        h = ctypes.c_void_p()
+        self._check(self._lib.dmi_multi_local_context(self._h, int(local_index), ctypes.byref(h)))
+        i = InfoC()
+        if h:
+            self._lib.dmi_get_info(h, ctypes.byref(i))
+        return i
+
+
 def color_mesh(points, colors, K4, RT4, device: int = 0):
     """MeshColoration::ProcessColoration on the GPU (include/dmi.h: dmi_color_mesh).
     points [nv,3] f64; colors [n,H,W,3] u8 in vtk row order; returns (mean u8[nv,3], median u8[nv,3], count i32[nv])."""
@@ -404,6 +657,10 @@ class ColorContext:
                                                 count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
         return mean, median, count
 
+    def set_scratch_budget(self, n_bytes: int):
+        """Bound the device scratch of one vertex chunk (more, smaller chunks; same result)."""
+        self._check(self._lib.dmi_color_set_scratch_budget(self._h, int(n_bytes)))
+
     def kernel_ms(self) -> float:
         v = ctypes.c_double(0)
         self._check(self._lib.dmi_color_get_kernel_ms(self._h, ctypes.byref(v)))
@@ -429,7 +686,7 @@ HOST_ABI_SYMBOLS = [
     "dmi_filter_set_ray_potential_eta", "dmi_filter_set_ray_potential_delta", "dmi_filter_set_threshold_best_cost",
     "dmi_filter_set_file_path_krtd", "dmi_filter_set_file_path_vti", "dmi_filter_set_grid_matrix",
     "dmi_filter_set_input_data", "dmi_filter_add_view", "dmi_filter_clear_views", "dmi_filter_set_device",
-    "dmi_filter_set_kernel_variant", "dmi_filter_update", "dmi_filter_get_execution_time",
+    "dmi_filter_set_kernel_variant", "dmi_filter_set_devices", "dmi_filter_set_partition", "dmi_filter_update", "dmi_filter_get_execution_time",
     "dmi_filter_get_fuse_kernel_ms", "dmi_filter_get_number_of_cells", "dmi_filter_get_output",
     "dmi_filter_last_error", "dmi_read_krtd_file", "dmi_extract_all_file_path", "dmi_k3_to_k4",
     "dmi_apply_depth_threshold", "dmi_read_depth_map", "dmi_read_depth_map_color", "dmi_mesh_coloration_from_lists",
@@ -463,6 +720,8 @@ def load_host() -> ctypes.CDLL:
     L.dmi_filter_clear_views.restype, L.dmi_filter_clear_views.argtypes = None, [vp]
     L.dmi_filter_set_device.restype, L.dmi_filter_set_device.argtypes = None, [vp, i32]
     L.dmi_filter_set_kernel_variant.restype, L.dmi_filter_set_kernel_variant.argtypes = None, [vp, i32]
+    L.dmi_filter_set_devices.restype, L.dmi_filter_set_devices.argtypes = None, [vp, ip, i32]
+    L.dmi_filter_set_partition.restype, L.dmi_filter_set_partition.argtypes = None, [vp, i32]
     L.dmi_filter_update.restype, L.dmi_filter_update.argtypes = ctypes.c_int, [vp]
     L.dmi_filter_get_execution_time.restype, L.dmi_filter_get_execution_time.argtypes = dbl, [vp]
     L.dmi_filter_get_fuse_kernel_ms.restype, L.dmi_filter_get_fuse_kernel_ms.argtypes = dbl, [vp]
@@ -549,6 +808,14 @@ class ReconstructionFilter:
     def ClearViews(self): self._lib.dmi_filter_clear_views(self._h)
     def SetDevice(self, d): self._lib.dmi_filter_set_device(self._h, int(d))
     def SetKernelVariant(self, v): self._lib.dmi_filter_set_kernel_variant(self._h, int(v))
+
+    def SetDevices(self, devices):
+        d = (ctypes.c_int32 * len(devices))(*[int(x) for x in devices])
+        self._lib.dmi_filter_set_devices(self._h, d, len(devices))
+
+    def SetPartition(self, partition: str):
+        self._lib.dmi_filter_set_partition(self._h, {"views": DMI_PARTITION_VIEWS, "z_slabs": DMI_PARTITION_Z_SLABS}[partition])
+
     def Update(self) -> int: return int(self._lib.dmi_filter_update(self._h))
     def GetExecutionTime(self) -> float: return float(self._lib.dmi_filter_get_execution_time(self._h))
     def GetFuseKernelMs(self) -> float: return float(self._lib.dmi_filter_get_fuse_kernel_ms(self._h))

@@ -243,6 +243,7 @@ struct dmi_color_context {
   size_t stage_capacity = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_kernel_ms = 0.0;
+  size_t scratch_budget = size_t(1) << 30;  // bytes of [view][vertex] scratch per chunk (dmi_color_set_scratch_budget)
   std::string err;
 };
 
@@ -252,6 +253,26 @@ int cfail(dmi_color_context *c, int code, const std::string &msg) {
   g_color_error = msg;
   if (c) c->err = msg;
   return code;
+}
+
+// no C++ exception may cross the C ABI
+template <typename Body>
+int guarded(dmi_color_context *c, const char *entry, Body &&body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    try {
+      return cfail(c, DMI_ERR_OUT_OF_MEMORY, std::string(entry) + ": host allocation failed");
+    } catch (...) {
+      return DMI_ERR_OUT_OF_MEMORY;
+    }
+  } catch (...) {
+    try {
+      return cfail(c, DMI_ERR_STATE, std::string(entry) + ": unexpected C++ exception");
+    } catch (...) {
+      return DMI_ERR_STATE;
+    }
+  }
 }
 
 #define DMI_COLOR_HIP(c, call)                                                                               \
@@ -264,8 +285,6 @@ int cfail(dmi_color_context *c, int code, const std::string &msg) {
     }                                                                                                        \
   } while (0)
 
-constexpr size_t kScratchBudget = size_t(1) << 30;  // bytes of [view][vertex] scratch per chunk
-
 }  // namespace
 
 extern "C" {
@@ -273,6 +292,7 @@ extern "C" {
 const char *dmi_color_last_error(void) { return g_color_error.c_str(); }
 
 int dmi_color_create(int32_t device, dmi_color_context **out) {
+  return guarded(nullptr, "dmi_color_create", [&]() -> int {
   if (!out) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_create: null argument");
   *out = nullptr;
   int ndev = 0;
@@ -296,6 +316,7 @@ int dmi_color_create(int32_t device, dmi_color_context **out) {
   }
   *out = c;
   return DMI_OK;
+  });
 }
 
 void dmi_color_destroy(dmi_color_context *c) {
@@ -314,6 +335,7 @@ void dmi_color_destroy(dmi_color_context *c) {
 
 int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const double *K4, const double *RT4, int32_t n,
                         int32_t width, int32_t height) {
+  return guarded(c, "dmi_color_add_views", [&]() -> int {
   if (!c) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_add_views: null context");
   if (!colors || !K4 || !RT4) return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_add_views: null argument");
   if (n < 1 || width < 1 || height < 1 || width > 32768 || height > 32768)
@@ -369,9 +391,11 @@ int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const doubl
   }
   c->views_dirty = true;
   return DMI_OK;
+  });
 }
 
 int dmi_color_clear_views(dmi_color_context *c) {
+  return guarded(c, "dmi_color_clear_views", [&]() -> int {
   if (!c) return DMI_ERR_INVALID_ARGUMENT;
   DMI_COLOR_HIP(c, hipSetDevice(c->device));
   DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
@@ -381,10 +405,12 @@ int dmi_color_clear_views(dmi_color_context *c) {
   c->views_dirty = true;
   c->W = c->H = 0;
   return DMI_OK;
+  });
 }
 
 int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_points, uint8_t *mean, uint8_t *median,
                       int32_t *count) {
+  return guarded(c, "dmi_color_process", [&]() -> int {
   if (!c) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_process: null context");
   if (n_points < 0 || (n_points > 0 && (!points || !mean || !median || !count)))
     return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_process: null argument");
@@ -407,8 +433,7 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     c->views_dirty = false;
   }
   // vertices per chunk: the scratch table [view][vertex] stays within its budget
-  size_t budget = kScratchBudget;
-  if (const char *e = getenv("DMI_COLOR_SCRATCH_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);  // tests: force chunking
+  const size_t budget = c->scratch_budget;
   size_t chunk = std::max<size_t>(256, budget / (n_views * sizeof(uchar4)) / 256 * 256);
   chunk = std::min<size_t>(chunk, ((size_t)n_points + 255) / 256 * 256);
   if (c->chunk_capacity < chunk || c->scratch_capacity < chunk * n_views) {
@@ -432,7 +457,11 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     hipLaunchKernelGGL(project_color_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, c->d_views, (int)n_views,
                        c->W, c->H, c->d_scratch, c->d_mean, c->d_count);
     DMI_COLOR_HIP(c, hipGetLastError());
-    if (n_views <= 65535 && !getenv("DMI_COLOR_BITWISE_MEDIAN"))
+    bool histogram_medians = n_views <= 65535;
+#ifdef DMI_TUNING
+    if (getenv("DMI_COLOR_BITWISE_MEDIAN")) histogram_medians = false;  // A/B of the two median kernels
+#endif
+    if (histogram_medians)
       hipLaunchKernelGGL(median_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, c->d_count,
                          c->d_median);
     else
@@ -449,17 +478,30 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     c->last_kernel_ms += ms;
   }
   return DMI_OK;
+  });
+}
+
+int dmi_color_set_scratch_budget(dmi_color_context *c, uint64_t bytes) {
+  return guarded(c, "dmi_color_set_scratch_budget", [&]() -> int {
+  if (!c) return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_set_scratch_budget: null context");
+  if (bytes < 1024) return cfail(c, DMI_ERR_INVALID_ARGUMENT, "dmi_color_set_scratch_budget: at least 1024 bytes");
+  c->scratch_budget = (size_t)bytes;
+  return DMI_OK;
+  });
 }
 
 int dmi_color_get_kernel_ms(dmi_color_context *c, double *out) {
+  return guarded(c, "dmi_color_get_kernel_ms", [&]() -> int {
   if (!c || !out) return DMI_ERR_INVALID_ARGUMENT;
   *out = c->last_kernel_ms;
   return DMI_OK;
+  });
 }
 
 int dmi_color_mesh(const double *points, int64_t n_points, const uint8_t *colors, const double *K4, const double *RT4,
                    int32_t n_views, int32_t width, int32_t height, int32_t device, uint8_t *mean, uint8_t *median,
                    int32_t *count) {
+  return guarded(nullptr, "dmi_color_mesh", [&]() -> int {
   if (!points || !colors || !K4 || !RT4 || !mean || !median || !count)
     return cfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_color_mesh: null argument");
   if (n_points < 0 || n_views < 1 || width < 1 || height < 1)  // MC.cxx:102-106
@@ -472,6 +514,7 @@ int dmi_color_mesh(const double *points, int64_t n_points, const uint8_t *colors
   if (rc == DMI_OK) rc = dmi_color_process(c, points, n_points, mean, median, count);
   dmi_color_destroy(c);  // g_color_error keeps the message
   return rc;
+  });
 }
 
 }  // extern "C"

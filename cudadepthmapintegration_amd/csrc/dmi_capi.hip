@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -97,6 +98,7 @@ struct dmi_context {
   hipEvent_t c2p_start = nullptr, c2p_stop = nullptr;
   bool c2p_pending = false;
 
+  void *d_convert = nullptr;  // staging of the grid up/downloads whose host type is not the grid's (kConvertChunk elements)
   double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
   size_t stage_capacity = 0;  // elements per staging buffer
   unsigned long long *d_lossy = nullptr;
@@ -110,8 +112,34 @@ struct dmi_context {
 namespace {
 
 int fail(dmi_context *ctx, int code, const std::string &msg) {
-  if (ctx) ctx->err = msg;
+  if (ctx)
+    ctx->err = msg;
+  else
+    g_create_error = msg;
   return code;
+}
+
+// No C++ exception may cross the C ABI (the caller may be C, or C++ built with another runtime): every entry point
+// that can allocate on the host runs its body through this.
+template <typename Body>
+int guarded(dmi_context *ctx, const char *entry, Body &&body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    try {
+      return fail(ctx, DMI_ERR_OUT_OF_MEMORY, std::string(entry) + ": host allocation failed");
+    } catch (...) {
+      return DMI_ERR_OUT_OF_MEMORY;
+    }
+  } catch (const std::exception &e) {
+    try {
+      return fail(ctx, DMI_ERR_STATE, std::string(entry) + ": " + e.what());
+    } catch (...) {
+      return DMI_ERR_STATE;
+    }
+  } catch (...) {
+    return DMI_ERR_STATE;
+  }
 }
 
 #define DMI_HIP(ctx, call)                                                                              \
@@ -408,6 +436,51 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
   return DMI_OK;
 }
 
+// Host <-> device grid transfers in a type that is not the grid's: the conversion runs on the device, chunk by chunk
+// through a 32 Mi-element staging buffer, so the host side is one hipMemcpyAsync per chunk (DMA speed when the caller's
+// buffer is pinned, dmi_alloc_pinned) instead of a pageable full-size temporary and a scalar loop over every voxel.
+constexpr int64_t kConvertChunk = int64_t(32) << 20;  // elements: 256 MiB as f64
+
+int ensure_convert_stage(dmi_context *ctx) {
+  if (ctx->d_convert) return DMI_OK;
+  const int64_t elems = std::min<int64_t>(kConvertChunk, ctx->n_voxels);
+  DMI_HIP(ctx, hipMalloc(&ctx->d_convert, (size_t)elems * 8));
+  ctx->device_bytes += (uint64_t)elems * 8;
+  return DMI_OK;
+}
+
+// host (HostT) -> device grid of the other type
+template <typename HostT>
+int upload_converted(dmi_context *ctx, const HostT *src) {
+  int rc = ensure_convert_stage(ctx);
+  if (rc != DMI_OK) return rc;
+  const size_t gsz = grid_elem(ctx);
+  for (int64_t i0 = 0; i0 < ctx->n_voxels; i0 += kConvertChunk) {
+    const int64_t n = std::min<int64_t>(kConvertChunk, ctx->n_voxels - i0);
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_convert, src + i0, (size_t)n * sizeof(HostT), hipMemcpyHostToDevice, ctx->stream));
+    DMI_HIP(ctx, dmi::launch_convert_grid(ctx->d_convert, sizeof(HostT) == 8 ? 1 : 0, static_cast<char *>(ctx->d_grid) + (size_t)i0 * gsz, n,
+                                          ctx->stream));
+  }
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DMI_OK;
+}
+
+// device grid -> host (HostT) of the other type
+template <typename HostT>
+int download_converted(dmi_context *ctx, HostT *dst) {
+  int rc = ensure_convert_stage(ctx);
+  if (rc != DMI_OK) return rc;
+  const size_t gsz = grid_elem(ctx);
+  for (int64_t i0 = 0; i0 < ctx->n_voxels; i0 += kConvertChunk) {
+    const int64_t n = std::min<int64_t>(kConvertChunk, ctx->n_voxels - i0);
+    DMI_HIP(ctx, dmi::launch_convert_grid(static_cast<const char *>(ctx->d_grid) + (size_t)i0 * gsz, gsz == 8 ? 1 : 0, ctx->d_convert, n,
+                                          ctx->stream));
+    DMI_HIP(ctx, hipMemcpyAsync(dst + i0, ctx->d_convert, (size_t)n * sizeof(HostT), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DMI_OK;
+}
+
 int flush_zero_fill(dmi_context *ctx) {
   if (ctx->zero_fill_pending) {
     DMI_HIP(ctx, hipMemsetAsync(ctx->d_grid, 0, ctx->n_voxels * grid_elem(ctx), ctx->stream));
@@ -482,6 +555,7 @@ void dmi_default_options(dmi_options *opt) {
 const char *dmi_last_error(const dmi_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dmi_options *opt, dmi_context **out) {
+  return guarded(nullptr, "dmi_create", [&]() -> int {
   auto bad = [](const char *m) {
     g_create_error = m;
     return (int)DMI_ERR_INVALID_ARGUMENT;
@@ -565,6 +639,7 @@ int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dm
   }
   *out = ctx;
   return DMI_OK;
+  });
 }
 
 void dmi_destroy(dmi_context *ctx) {
@@ -602,6 +677,7 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_fuse_args) (void)hipFree(ctx->d_fuse_args);
   if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
   if (ctx->d_stage_cost) (void)hipFree(ctx->d_stage_cost);
+  if (ctx->d_convert) (void)hipFree(ctx->d_convert);
   if (ctx->d_lossy) (void)hipFree(ctx->d_lossy);
   if (ctx->d_points) (void)hipFree(ctx->d_points);
   if (ctx->c2p_start) (void)hipEventDestroy(ctx->c2p_start);
@@ -612,15 +688,20 @@ void dmi_destroy(dmi_context *ctx) {
 
 int dmi_add_views(dmi_context *ctx, const double *depth, const double *best_cost, double threshold, const double *K4,
                   const double *RT4, int32_t n, int32_t width, int32_t height) {
+  return guarded(ctx, "dmi_add_views", [&]() -> int {
   return add_views_impl(ctx, depth, nullptr, best_cost, threshold, K4, RT4, n, width, height);
+  });
 }
 
 int dmi_add_views_f32(dmi_context *ctx, const float *depth, const double *K4, const double *RT4, int32_t n,
                       int32_t width, int32_t height) {
+  return guarded(ctx, "dmi_add_views_f32", [&]() -> int {
   return add_views_impl(ctx, nullptr, depth, nullptr, 0.0, K4, RT4, n, width, height);
+  });
 }
 
 int dmi_clear_views(dmi_context *ctx) {
+  return guarded(ctx, "dmi_clear_views", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -637,9 +718,11 @@ int dmi_clear_views(dmi_context *ctx) {
   ctx->maps_dirty = true;
   ctx->W = ctx->H = 0;
   return DMI_OK;
+  });
 }
 
 int dmi_reset_grid(dmi_context *ctx) {
+  return guarded(ctx, "dmi_reset_grid", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   // The fusion kernel writes every voxel and skips the read when the grid is known to be zero, so
@@ -655,9 +738,11 @@ int dmi_reset_grid(dmi_context *ctx) {
   ctx->layer_is_zero.assign((size_t)ctx->grid.cell_dims[2], 1);
   ctx->points_valid = false;
   return DMI_OK;
+  });
 }
 
 int dmi_upload_grid(dmi_context *ctx, const double *grid) {
+  return guarded(ctx, "dmi_upload_grid", [&]() -> int {
   if (!ctx || !grid) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_upload_grid: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   ctx->zero_fill_pending = false;
@@ -665,14 +750,13 @@ int dmi_upload_grid(dmi_context *ctx, const double *grid) {
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_grid, grid, ctx->n_voxels * 8, hipMemcpyHostToDevice, ctx->stream));
     DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
-    std::vector<float> narrow((size_t)ctx->n_voxels);
-    for (int64_t i = 0; i < ctx->n_voxels; ++i) narrow[(size_t)i] = (float)grid[i];
-    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_grid, narrow.data(), ctx->n_voxels * 4, hipMemcpyHostToDevice, ctx->stream));
-    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc_ = upload_converted<double>(ctx, grid);  // narrowed on the device
+    if (rc_ != DMI_OK) return rc_;
   }
   ctx->layer_is_zero.assign((size_t)ctx->grid.cell_dims[2], 0);
   ctx->points_valid = false;
   return DMI_OK;
+  });
 }
 
 namespace {
@@ -680,11 +764,14 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
 }
 
 int dmi_fuse_range(dmi_context *ctx, int32_t first, int32_t count) {
+  return guarded(ctx, "dmi_fuse_range", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   return fuse_impl(ctx, first, count, 0, ctx->grid.cell_dims[2]);
+  });
 }
 
 int dmi_fuse_slab(dmi_context *ctx, int32_t z_first, int32_t z_count) {
+  return guarded(ctx, "dmi_fuse_slab", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   const int32_t nz = ctx->grid.cell_dims[2];
   if (z_first < 0 || z_count < 0 || z_first > nz || z_count > nz - z_first)
@@ -693,6 +780,7 @@ int dmi_fuse_slab(dmi_context *ctx, int32_t z_first, int32_t z_count) {
     return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_slab: slab boundaries must be multiples of DMI_SLAB_ALIGNMENT (32) cells");
   if (z_count == 0) return DMI_OK;
   return fuse_impl(ctx, 0, (int32_t)ctx->h_maps.size(), z_first, z_count);
+  });
 }
 
 namespace {
@@ -791,8 +879,10 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
       return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: grid too large for one launch");
     t.depth_bytes = (int32_t)((int64_t)a.W * a.H * (ctx->depth_f64 ? 8 : 4));
     t.kz0 = a.kz0;
-    // timing experiment only (results are wrong): a zero-length buffer makes the range check drop every depth load
+#ifdef DMI_TUNING  // tools/ builds only (DMI_TUNING=1 python -m cudadepthmapintegration_amd.build): never in the shipped library
+    // timing experiment (results are wrong): a zero-length buffer makes the range check drop every depth load
     if (std::getenv("DMI_DEBUG_NO_DEPTH_LOADS")) t.depth_bytes = 0;
+#endif
     t.ox = a.ox; t.oy = a.oy; t.oz = a.oz; t.sx = a.sx; t.sy = a.sy; t.sz = a.sz;
     std::memcpy(t.g, a.g, sizeof(t.g));
     t.thick = a.thick; t.delta = a.delta; t.rho_pos = a.rho_pos; t.rho_neg = a.rho_neg;
@@ -884,7 +974,13 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     // +0.0 adds are no-ops unless a sum can be -0.0 (only an uploaded grid can bring one) or hits are counted
     if (!a.init_from_grid && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS))
       t.behind_mask = 0x0101010101010101ull;
-    if (const char *e = std::getenv("DMI_XCD_RUN_WG")) t.xcd_run_wg = std::max(1, std::atoi(e));  // tuning experiments
+#ifdef DMI_TUNING
+    if (const char *e = std::getenv("DMI_XCD_RUN_WG")) {  // launch-geometry experiments
+      t.xcd_run_wg = std::max(1, std::atoi(e));
+      if (((int64_t)t.super_x * t.super_y * t.super_z * 32 + 8 * (int64_t)t.xcd_run_wg) > (int64_t)0x7fffffff)
+        return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: DMI_XCD_RUN_WG makes the launch too large");
+    }
+#endif
     if (!ctx->d_fuse_args) DMI_HIP(ctx, hipMalloc(&ctx->d_fuse_args, sizeof(FuseArgs)));
     // pageable source: the copy has left the host buffer when the call returns
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_fuse_args, &a, sizeof(FuseArgs), hipMemcpyHostToDevice, ctx->stream));
@@ -929,18 +1025,23 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
 }  // namespace
 
 int dmi_fuse(dmi_context *ctx) {
+  return guarded(ctx, "dmi_fuse", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   return dmi_fuse_range(ctx, 0, (int32_t)ctx->h_maps.size());
+  });
 }
 
 int dmi_synchronize(dmi_context *ctx) {
+  return guarded(ctx, "dmi_synchronize", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return drain_events(ctx);
+  });
 }
 
 int dmi_download_grid_f64(dmi_context *ctx, double *out) {
+  return guarded(ctx, "dmi_download_grid_f64", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_download_grid_f64: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   { int rc_ = flush_zero_fill(ctx); if (rc_ != DMI_OK) return rc_; }
@@ -950,17 +1051,17 @@ int dmi_download_grid_f64(dmi_context *ctx, double *out) {
     DMI_HIP(ctx, hipMemcpyAsync(out, ctx->d_grid, ctx->n_voxels * 8, hipMemcpyDeviceToHost, ctx->stream));
     DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
-    std::vector<float> tmp((size_t)ctx->n_voxels);
-    DMI_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->d_grid, ctx->n_voxels * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < ctx->n_voxels; ++i) out[i] = (double)tmp[(size_t)i];
+    int rc_ = download_converted<double>(ctx, out);  // widened on the device (exact)
+    if (rc_ != DMI_OK) return rc_;
   }
   ctx->timings.last_download_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return drain_events(ctx);
+  });
 }
 
 int dmi_download_grid_f32(dmi_context *ctx, float *out) {
+  return guarded(ctx, "dmi_download_grid_f32", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_download_grid_f32: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   { int rc_ = flush_zero_fill(ctx); if (rc_ != DMI_OK) return rc_; }
@@ -969,17 +1070,17 @@ int dmi_download_grid_f32(dmi_context *ctx, float *out) {
     DMI_HIP(ctx, hipMemcpyAsync(out, ctx->d_grid, ctx->n_voxels * 4, hipMemcpyDeviceToHost, ctx->stream));
     DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
-    std::vector<double> tmp((size_t)ctx->n_voxels);
-    DMI_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->d_grid, ctx->n_voxels * 8, hipMemcpyDeviceToHost, ctx->stream));
-    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < ctx->n_voxels; ++i) out[i] = (float)tmp[(size_t)i];
+    int rc_ = download_converted<float>(ctx, out);  // narrowed on the device (round to nearest, as the host cast)
+    if (rc_ != DMI_OK) return rc_;
   }
   ctx->timings.last_download_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return drain_events(ctx);
+  });
 }
 
 int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits) {
+  return guarded(ctx, "dmi_download_hits", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   if (!ctx->opt.count_hits) return fail(ctx, DMI_ERR_STATE, "dmi_download_hits: context created without count_hits");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
@@ -997,15 +1098,18 @@ int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits
   }
   DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return drain_events(ctx);
+  });
 }
 
 int dmi_grid_device_pointer(dmi_context *ctx, void **ptr) {
+  return guarded(ctx, "dmi_grid_device_pointer", [&]() -> int {
   if (!ctx || !ptr) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_grid_device_pointer: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   int rc = flush_zero_fill(ctx);
   if (rc != DMI_OK) return rc;
   *ptr = ctx->d_grid;
   return DMI_OK;
+  });
 }
 
 namespace {
@@ -1024,6 +1128,7 @@ int drain_c2p(dmi_context *ctx) {
 }  // namespace
 
 int dmi_cell_to_point(dmi_context *ctx) {
+  return guarded(ctx, "dmi_cell_to_point", [&]() -> int {
   if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   // an external grid can be changed by its owner (e.g. an all-reduce) without the context knowing: always recompute
@@ -1047,9 +1152,11 @@ int dmi_cell_to_point(dmi_context *ctx) {
   ctx->c2p_pending = true;
   ctx->points_valid = true;
   return DMI_OK;
+  });
 }
 
 int dmi_download_point_data_f64(dmi_context *ctx, double *out) {
+  return guarded(ctx, "dmi_download_point_data_f64", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_download_point_data_f64: null argument");
   int rc = dmi_cell_to_point(ctx);
   if (rc != DMI_OK) return rc;
@@ -1058,17 +1165,21 @@ int dmi_download_point_data_f64(dmi_context *ctx, double *out) {
   rc = drain_c2p(ctx);
   if (rc != DMI_OK) return rc;
   return drain_events(ctx);
+  });
 }
 
 int dmi_point_data_device_pointer(dmi_context *ctx, void **ptr) {
+  return guarded(ctx, "dmi_point_data_device_pointer", [&]() -> int {
   if (!ctx || !ptr) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_point_data_device_pointer: null argument");
   int rc = dmi_cell_to_point(ctx);
   if (rc != DMI_OK) return rc;
   *ptr = ctx->d_points;
   return DMI_OK;
+  });
 }
 
 int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]) {
+  return guarded(ctx, "dmi_get_brick_class_histogram", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_brick_class_histogram: null argument");
   out[0] = out[1] = out[2] = out[3] = 0;
   if (!ctx->last_fuse_classes) return DMI_OK;
@@ -1082,9 +1193,11 @@ int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]) {
     for (int32_t m = 0; m < ctx->last_count; ++m) out[row[m] & 3] += 1;
   }
   return DMI_OK;
+  });
 }
 
 int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]) {
+  return guarded(ctx, "dmi_get_mixed_reason_histogram", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_mixed_reason_histogram: null argument");
   for (int i = 0; i < 8; ++i) out[i] = 0;
   if (!ctx->last_fuse_classes) return DMI_OK;
@@ -1099,9 +1212,11 @@ int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]) {
       if ((row[m] & 3) == dmi::BRICK_MIXED) out[(row[m] >> 2) & 7] += 1;
   }
   return DMI_OK;
+  });
 }
 
 int dmi_get_timings(dmi_context *ctx, dmi_timings *out) {
+  return guarded(ctx, "dmi_get_timings", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_timings: null argument");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   int rc = drain_events(ctx);
@@ -1110,9 +1225,11 @@ int dmi_get_timings(dmi_context *ctx, dmi_timings *out) {
   if (rc != DMI_OK) return rc;
   *out = ctx->timings;
   return DMI_OK;
+  });
 }
 
 int dmi_get_info(dmi_context *ctx, dmi_info *out) {
+  return guarded(ctx, "dmi_get_info", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_info: null argument");
   std::memset(out, 0, sizeof(*out));
   out->n_voxels = ctx->n_voxels;
@@ -1126,9 +1243,11 @@ int dmi_get_info(dmi_context *ctx, dmi_info *out) {
   out->tiled_kernel = (ctx->h_maps.empty() ? 0 : (tile_eligible(ctx) ? 1 : 0));
   out->device_bytes = ctx->device_bytes;
   return DMI_OK;
+  });
 }
 
 int dmi_alloc_pinned(size_t bytes, void **out) {
+  return guarded(nullptr, "dmi_alloc_pinned", [&]() -> int {
   if (!out || bytes == 0) return DMI_ERR_INVALID_ARGUMENT;
   hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -1137,9 +1256,54 @@ int dmi_alloc_pinned(size_t bytes, void **out) {
     return e == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_DEVICE;
   }
   return DMI_OK;
+  });
+}
+
+int dmi_pcie_probe(int32_t device, size_t bytes, double *h2d_GBps, double *d2h_GBps) {
+  return guarded(nullptr, "dmi_pcie_probe", [&]() -> int {
+    if (bytes < (size_t(1) << 20) || (!h2d_GBps && !d2h_GBps))
+      return fail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_pcie_probe: at least 1 MiB and one output");
+    dmi_context *none = nullptr;
+    DMI_HIP(none, hipSetDevice(device));
+    void *host = nullptr, *dev = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipHostMalloc(&host, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&dev, bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double rate[2] = {0.0, 0.0};
+    if (e == hipSuccess) std::memset(host, 0, bytes);  // touch the pages
+    for (int dir = 0; e == hipSuccess && dir < 2; ++dir) {
+      for (int rep = 0; e == hipSuccess && rep < 3; ++rep) {  // the first pass warms up; the best of the others counts
+        e = hipEventRecord(e0, s);
+        if (e == hipSuccess)
+          e = dir == 0 ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && rep > 0 && ms > 0.f) rate[dir] = std::max(rate[dir], (double)bytes / (ms * 1e-3) / 1e9);
+      }
+    }
+    if (e1) (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (s) (void)hipStreamDestroy(s);
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(nullptr, DMI_ERR_DEVICE, std::string("dmi_pcie_probe: ") + hipGetErrorString(e));
+    }
+    if (h2d_GBps) *h2d_GBps = rate[0];
+    if (d2h_GBps) *d2h_GBps = rate[1];
+    return DMI_OK;
+  });
 }
 
 int dmi_free_pinned(void *ptr) {
+  return guarded(nullptr, "dmi_free_pinned", [&]() -> int {
   if (!ptr) return DMI_OK;
   hipError_t e = hipHostFree(ptr);
   if (e != hipSuccess) {
@@ -1147,6 +1311,7 @@ int dmi_free_pinned(void *ptr) {
     return DMI_ERR_DEVICE;
   }
   return DMI_OK;
+  });
 }
 
 }  // extern "C"

@@ -603,7 +603,9 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   // 8.4 M to 7.6 M and the fusion from 10.8 to 10.0 to 9.8 ms; more gains nothing at 8-pixel tiles, and 4-pixel tiles
   // cost more in this pass than they save in the next (profiles/r01zm_*)
   int q = 5;
-  if (const char *env = getenv("DMI_QUERY_TILES")) q = atoi(env);  // tuning experiments
+#ifdef DMI_TUNING
+  if (const char *env = getenv("DMI_QUERY_TILES")) q = atoi(env);  // tuning experiments (tools/gpu_query_tiles.sh)
+#endif
   const bool wide = tk == 8;  // 64 bricks per box
 #define DMI_LAUNCH_FINE_R(Q, C, R) \
   hipLaunchKernelGGL((classify_kernel<Q, C, R>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse)

@@ -193,6 +193,8 @@ hipError_t launch_convert_depth(const double *in, const double *best_cost, doubl
 hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int64_t n_maps, int W, int H,
                                  hipStream_t stream);
 hipError_t launch_widen_depth(const float *in, double *out, int64_t n, hipStream_t stream);
+// n grid elements f64 -> f32 (in_is_f64) or f32 -> f64, device to device
+hipError_t launch_convert_grid(const void *in, int in_is_f64, void *out, int64_t n, hipStream_t stream);
 
 // min/max pyramids of n_maps depth tables (device, top-down rows) into pyramids[n_maps][desc.total_tiles]
 PyramidDesc make_pyramid_desc(int W, int H);

@@ -177,6 +177,14 @@ __global__ __launch_bounds__(256) void widen_depth_kernel(const float *__restric
     out[i] = (double)in[i];
 }
 
+// grid element type conversion on the device (dmi_upload_grid / dmi_download_grid_* when the caller's type is not the
+// grid's): the same IEEE conversions as the host casts they replace, at HBM speed instead of one core's
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void convert_grid_kernel(const InT *__restrict__ in, OutT *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (OutT)in[i];
+}
+
 inline int blocks_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -227,6 +235,17 @@ hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int
   else
     hipLaunchKernelGGL((flip_depth_f32_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, stream, in,
                        static_cast<float *>(out), n, W, H);
+  return hipGetLastError();
+}
+
+hipError_t launch_convert_grid(const void *in, int in_is_f64, void *out, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (in_is_f64)
+    hipLaunchKernelGGL((convert_grid_kernel<double, float>), dim3(blocks_for(n)), dim3(256), 0, stream,
+                       static_cast<const double *>(in), static_cast<float *>(out), n);
+  else
+    hipLaunchKernelGGL((convert_grid_kernel<float, double>), dim3(blocks_for(n)), dim3(256), 0, stream,
+                       static_cast<const float *>(in), static_cast<double *>(out), n);
   return hipGetLastError();
 }
 

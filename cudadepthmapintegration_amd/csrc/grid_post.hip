@@ -92,7 +92,9 @@ void launch_kz(const GridT *cells, double *points, int nx, int ny, int nz, hipSt
 template <typename GridT>
 void launch_typed(const GridT *cells, double *points, int nx, int ny, int nz, hipStream_t stream) {
   int kz = 8;
-  if (const char *e = getenv("DMI_C2P_KZ")) kz = atoi(e);  // tuning experiments
+#ifdef DMI_TUNING
+  if (const char *e = getenv("DMI_C2P_KZ")) kz = atoi(e);  // tuning experiments (tools/gpu_c2p_tune.py)
+#endif
   switch (kz) {
     case 1: return launch_kz<GridT, 1>(cells, points, nx, ny, nz, stream);
     case 2: return launch_kz<GridT, 2>(cells, points, nx, ny, nz, stream);

@@ -17,9 +17,24 @@ struct dmi_filter {
   std::vector<std::unique_ptr<ReconstructionData>> views;
 };
 
+namespace {
+// No C++ exception may cross the C ABI: the readers and containers behind these entry points can throw
+// (std::bad_alloc, std::length_error); each entry point returns its own failure value instead.
+template <typename R, typename Body>
+R guarded(R on_failure, Body &&body) noexcept {
+  try {
+    return body();
+  } catch (...) {
+    return on_failure;
+  }
+}
+}  // namespace
+
 extern "C" {
 
-dmi_filter *dmi_filter_new(void) { return new (std::nothrow) dmi_filter(); }
+dmi_filter *dmi_filter_new(void) {
+  return guarded<dmi_filter *>(nullptr, [] { return new (std::nothrow) dmi_filter(); });
+}
 void dmi_filter_delete(dmi_filter *f) { delete f; }
 void dmi_filter_set_ray_potential_thickness(dmi_filter *f, double v) { if (f) f->filter.SetRayPotentialThickness(v); }
 void dmi_filter_set_ray_potential_rho(dmi_filter *f, double v) { if (f) f->filter.SetRayPotentialRho(v); }
@@ -37,6 +52,7 @@ void dmi_filter_set_input_data(dmi_filter *f, const int32_t dims[3], const doubl
 
 int dmi_filter_add_view(dmi_filter *f, const double *depths, const double *best_cost, int32_t width, int32_t height,
                         const double K3[9], const double RT[16]) {
+  return guarded<int>(0, [&]() -> int {
   if (!f || !depths || !K3 || !RT || width < 1 || height < 1) return 0;
   std::unique_ptr<ReconstructionData> d(new ReconstructionData());
   DepthImage img;
@@ -54,6 +70,7 @@ int dmi_filter_add_view(dmi_filter *f, const double *depths, const double *best_
   for (auto &v : f->views) raw.push_back(v.get());
   f->filter.SetViews(raw);
   return 1;
+  });
 }
 
 void dmi_filter_clear_views(dmi_filter *f) {
@@ -63,24 +80,39 @@ void dmi_filter_clear_views(dmi_filter *f) {
 }
 void dmi_filter_set_device(dmi_filter *f, int32_t device) { if (f) f->filter.SetDevice(device); }
 void dmi_filter_set_kernel_variant(dmi_filter *f, int32_t variant) { if (f) f->filter.SetKernelVariant(variant); }
-int dmi_filter_update(dmi_filter *f) { return f ? f->filter.Update() : 0; }
+int dmi_filter_update(dmi_filter *f) {
+  return guarded<int>(0, [&]() -> int { return f ? f->filter.Update() : 0; });
+}
+void dmi_filter_set_devices(dmi_filter *f, const int32_t *devices, int32_t n) {
+  if (!f) return;
+  guarded<int>(0, [&]() -> int {
+    f->filter.SetDevices(devices && n > 0 ? std::vector<int>(devices, devices + n) : std::vector<int>());
+    return 1;
+  });
+}
+void dmi_filter_set_partition(dmi_filter *f, int32_t partition) { if (f) f->filter.SetPartition(partition); }
 double dmi_filter_get_execution_time(const dmi_filter *f) { return f ? f->filter.GetExecutionTime() : -1.0; }
 double dmi_filter_get_fuse_kernel_ms(const dmi_filter *f) { return f ? f->filter.GetFuseKernelMs() : 0.0; }
 int64_t dmi_filter_get_number_of_cells(const dmi_filter *f) { return f ? f->filter.GetNumberOfCells() : 0; }
 int64_t dmi_filter_get_output(const dmi_filter *f, double *out) {
+  return guarded<int64_t>(0, [&]() -> int64_t {
   if (!f || !out) return 0;
   const std::vector<double> &s = f->filter.GetOutputScalars();
   if (!s.empty()) std::memcpy(out, s.data(), s.size() * sizeof(double));
   return (int64_t)s.size();
+  });
 }
 const char *dmi_filter_last_error(const dmi_filter *f) { return f ? f->filter.LastError().c_str() : "null filter"; }
 
 int dmi_read_krtd_file(const char *path, double K3[9], double RT[16]) {
+  return guarded<int>(0, [&]() -> int {
   if (!path || !K3 || !RT) return 0;
   return dmi::host::help::ReadKrtdFile(path, K3, RT) ? 1 : 0;
+  });
 }
 
 int dmi_extract_all_file_path(const char *list_path, char *buf, size_t buflen) {
+  return guarded<int>(0, [&]() -> int {
   if (!list_path) return 0;
   const std::vector<std::string> paths = dmi::host::help::ExtractAllFilePath(list_path);
   if (buf && buflen > 0) {
@@ -90,6 +122,7 @@ int dmi_extract_all_file_path(const char *list_path, char *buf, size_t buflen) {
     buf[buflen - 1] = 0;
   }
   return (int)paths.size();
+  });
 }
 
 void dmi_k3_to_k4(const double K3[9], double K4[16]) {
@@ -99,6 +132,7 @@ void dmi_k3_to_k4(const double K3[9], double K4[16]) {
 }
 
 int64_t dmi_apply_depth_threshold(double *depths, const double *best_cost, int64_t n, double threshold) {
+  return guarded<int64_t>(0, [&]() -> int64_t {
   if (!depths || !best_cost || n <= 0) return 0;
   ReconstructionData d;
   DepthImage img;
@@ -115,9 +149,11 @@ int64_t dmi_apply_depth_threshold(double *depths, const double *best_cost, int64
     depths[i] = out[i];
   }
   return changed;
+  });
 }
 
 int dmi_read_depth_map(const char *path, int32_t dims[3], double *depths, double *best_cost, int32_t *has_best_cost) {
+  return guarded<int>(0, [&]() -> int {
   if (!path || !dims) return 0;
   DepthImage img;
   if (!ReconstructionData::ReadDepthMap(path, &img)) return 0;
@@ -126,9 +162,11 @@ int dmi_read_depth_map(const char *path, int32_t dims[3], double *depths, double
   if (depths) std::memcpy(depths, img.depths.data(), img.depths.size() * sizeof(double));
   if (best_cost && !img.best_cost.empty()) std::memcpy(best_cost, img.best_cost.data(), img.best_cost.size() * sizeof(double));
   return 1;
+  });
 }
 
 int dmi_read_depth_map_color(const char *path, int32_t dims[3], uint8_t *color, int32_t *has_color) {
+  return guarded<int>(0, [&]() -> int {
   if (!path || !dims) return 0;
   DepthImage img;
   if (!ReconstructionData::ReadDepthMap(path, &img)) return 0;
@@ -136,10 +174,12 @@ int dmi_read_depth_map_color(const char *path, int32_t dims[3], uint8_t *color, 
   if (has_color) *has_color = img.color.empty() ? 0 : 1;
   if (color && !img.color.empty()) std::memcpy(color, img.color.data(), img.color.size());
   return 1;
+  });
 }
 
 int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const char *vti_list, const char *krtd_list,
                                    int32_t device, uint8_t *mean, uint8_t *median, int32_t *count, char *err, size_t errlen) {
+  return guarded<int>(0, [&]() -> int {
   auto fail = [&](const std::string &m) {
     if (err && errlen > 0) {
       std::strncpy(err, m.c_str(), errlen - 1);
@@ -155,6 +195,7 @@ int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const
   std::memcpy(median, mc.GetMedianColoration().data(), (size_t)n_points * 3);
   for (int64_t i = 0; i < n_points; ++i) count[i] = mc.GetNbProjectedDepthMap()[(size_t)i];
   return 1;
+  });
 }
 
 }  // extern "C"

@@ -11,8 +11,14 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <iostream>
+#include <mutex>
+#include <thread>
 #include <sstream>
+#include <string_view>
 
 namespace dmi {
 namespace host {
@@ -22,83 +28,128 @@ namespace host {
 // ====================================================================================================
 namespace help {
 
+namespace {
+
+// The whole file as one string; false when it cannot be opened.
+bool slurp(const std::string &path, std::string *out) {
+  std::ifstream in(path.c_str(), std::ios::binary);
+  if (!in.is_open()) return false;
+  in.seekg(0, std::ios::end);
+  const std::streamoff size = in.tellg();
+  in.seekg(0, std::ios::beg);
+  out->resize(size > 0 ? (size_t)size : 0);
+  if (size > 0) in.read(&(*out)[0], size);
+  out->resize((size_t)in.gcount());
+  return true;
+}
+
+// visit(line) for every line of `text`.  Lines end in "\n" or "\r\n" (a list written on Windows reads the same); a
+// last line without a terminator counts, an empty remainder after the last terminator does not.
+template <typename Visit>
+void for_each_line(std::string_view text, Visit &&visit) {
+  while (!text.empty()) {
+    const size_t nl = text.find('\n');
+    std::string_view line = text.substr(0, nl);
+    text.remove_prefix(nl == std::string_view::npos ? text.size() : nl + 1);
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    visit(line);
+  }
+}
+
+// Up to `want` numbers from the front of `line` into out[]; the ones that are not there stay 0 (what a failed
+// operator>> leaves behind in the reference's loops, Helper.h:124-128).
+void leading_numbers(std::string_view line, int want, double *out) {
+  const std::string z(line);  // strtod needs a terminator
+  const char *p = z.c_str();
+  for (int i = 0; i < want; ++i) {
+    out[i] = 0.0;
+    char *end = nullptr;
+    const double v = std::strtod(p, &end);
+    if (end == p) {
+      for (int j = i; j < want; ++j) out[j] = 0.0;
+      return;
+    }
+    out[i] = v;
+    p = end;
+  }
+}
+
+}  // namespace
+
 void SplitString(const std::string &s, char delim, std::vector<std::string> &elems) {
-  std::stringstream ss(s);
-  std::string item;
-  while (std::getline(ss, item, delim)) elems.push_back(item);  // Helper.h:21-26
+  // std::getline semantics (Helper.h:18-27): a piece per delimiter, no piece for a trailing delimiter
+  size_t from = 0;
+  while (from < s.size()) {
+    const size_t at = s.find(delim, from);
+    elems.emplace_back(s, from, at == std::string::npos ? std::string::npos : at - from);
+    if (at == std::string::npos) break;
+    from = at + 1;
+  }
 }
 
 std::string GetFilenamePath(const std::string &filename) {
-  std::string fn = filename;
-  std::replace(fn.begin(), fn.end(), '\\', '/');  // ConvertToUnixSlashes, Helper.h:35
-  const std::string::size_type slash_pos = fn.rfind('/');
-  if (slash_pos == std::string::npos) return "";  // Helper.h:51-54
-  std::string ret = fn.substr(0, slash_pos);
-  if (ret.size() == 2 && ret[1] == ':') return ret + '/';  // Helper.h:41-44
-  if (ret.empty()) return "/";                             // Helper.h:45-48
-  return ret;
+  // directory part with '/' separators (Helper.h:32-55): "" when there is none, "X:/" for a drive root, "/" for the root
+  std::string unix_style = filename;
+  for (char &c : unix_style)
+    if (c == '\\') c = '/';
+  const size_t cut = unix_style.rfind('/');
+  if (cut == std::string::npos) return std::string();
+  unix_style.resize(cut);
+  if (unix_style.size() == 2 && unix_style[1] == ':') unix_style.push_back('/');
+  if (unix_style.empty()) unix_style = "/";
+  return unix_style;
 }
 
 std::vector<std::string> ExtractAllFilePath(const char *globalPath) {
-  std::vector<std::string> pathList;
-  std::ifstream container(globalPath);
-  if (!container.is_open()) {
-    std::cerr << "Unable to open : " << globalPath << std::endl;  // Helper.h:66-70
-    return pathList;
+  std::vector<std::string> entries;
+  std::string listing;
+  if (!globalPath || !slurp(globalPath, &listing)) {
+    std::cerr << "Unable to open : " << (globalPath ? globalPath : "(null)") << std::endl;  // Helper.h:66-70
+    return entries;
   }
-  std::string directoryPath = GetFilenamePath(std::string(globalPath));
-  if (directoryPath == "") {  // Helper.h:76-79: current working directory
-    char buf[4096];
-    directoryPath = getcwd(buf, sizeof(buf)) ? std::string(buf) : std::string(".");
+  std::string base = GetFilenamePath(globalPath);
+  if (base.empty()) {  // a bare file name: relative to the working directory (Helper.h:76-79)
+    char cwd[4096];
+    base = getcwd(cwd, sizeof(cwd)) ? cwd : ".";
   }
-  std::string path;
-  while (!container.eof()) {  // Helper.h:82-97
-    std::getline(container, path);
-    std::vector<std::string> elems;
-    SplitString(path, ' ', elems);
-    if (elems.size() == 0) continue;  // empty line
-    pathList.push_back(directoryPath + "/" + elems[elems.size() - 1]);
-  }
-  return pathList;
+  for_each_line(listing, [&](std::string_view line) {
+    // the entry is the last blank-separated token (Helper.h:86-96: "<index> <file>" or just "<file>"); trailing blanks
+    // are not a token, and a line of nothing but blanks is an empty line
+    while (!line.empty() && line.back() == ' ') line.remove_suffix(1);
+    if (line.empty()) return;
+    const size_t blank = line.rfind(' ');
+    const std::string_view token = blank == std::string_view::npos ? line : line.substr(blank + 1);
+    entries.push_back(base + "/" + std::string(token));
+  });
+  return entries;
 }
 
 bool ReadKrtdFile(const std::string &filename, double K3[9], double RT[16]) {
-  std::ifstream file(filename.c_str());
-  if (!file.is_open()) {
+  std::string text;
+  if (!slurp(filename, &text)) {
     std::cerr << "Unable to open krtd file : " << filename << std::endl;  // Helper.h:110-114
     return false;
   }
-  std::string line;
+  // Helper.h:117-158: line 0-2 = rows of K, 3 skipped, 4-6 = rows of R, 7 skipped, 8 = T; whatever follows is ignored
+  // and lines that are missing read as zeros.  RT = [R | T; 0 0 0 1] (Helper.h:160-165).
+  for (int i = 0; i < 9; ++i) K3[i] = 0.0;
   for (int i = 0; i < 16; ++i) RT[i] = 0.0;
-  for (int i = 0; i < 3; i++) {  // matrix K, Helper.h:119-130
-    std::getline(file, line);
-    std::istringstream iss(line);
-    for (int j = 0; j < 3; j++) {
-      double value = 0.0;
-      iss >> value;
-      K3[3 * i + j] = value;
+  RT[15] = 1.0;
+  int index = 0;
+  for_each_line(text, [&](std::string_view line) {
+    double v[3];
+    if (index <= 2) {
+      leading_numbers(line, 3, v);
+      for (int c = 0; c < 3; ++c) K3[3 * index + c] = v[c];
+    } else if (index >= 4 && index <= 6) {
+      leading_numbers(line, 3, v);
+      for (int c = 0; c < 3; ++c) RT[4 * (index - 4) + c] = v[c];
+    } else if (index == 8) {
+      leading_numbers(line, 3, v);
+      for (int r = 0; r < 3; ++r) RT[4 * r + 3] = v[r];
     }
-  }
-  std::getline(file, line);      // Helper.h:132
-  for (int i = 0; i < 3; i++) {  // matrix R, Helper.h:135-146
-    std::getline(file, line);
-    std::istringstream iss(line);
-    for (int j = 0; j < 3; j++) {
-      double value = 0.0;
-      iss >> value;
-      RT[4 * i + j] = value;
-    }
-  }
-  std::getline(file, line);  // Helper.h:148
-  std::getline(file, line);  // T, Helper.h:151-158
-  std::istringstream iss(line);
-  for (int i = 0; i < 3; i++) {
-    double value = 0.0;
-    iss >> value;
-    RT[4 * i + 3] = value;
-  }
-  for (int j = 0; j < 4; j++) RT[12 + j] = 0;  // Helper.h:161-165
-  RT[15] = 1;
+    ++index;
+  });
   return true;
 }
 
@@ -250,14 +301,42 @@ int64_t FusionDriver::NumberOfCells() const {
   return (int64_t)Grid.cell_dims[0] * Grid.cell_dims[1] * Grid.cell_dims[2];
 }
 
-bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &views, double thresholdBestCost,
-                                   double *io_scalar) {
+namespace {
+
+// One pinned structure-of-arrays chunk of views ([n][H][W] depth, [n][H][W] best cost, [n][16] K, [n][16] RT) and its
+// place in the hand-over between the thread that fills chunks and the thread that uploads and fuses them.
+struct Chunk {
+  double *depth = nullptr, *cost = nullptr;  // pinned (dmi_alloc_pinned)
+  std::vector<double> K4, RT;
+  std::vector<char> has_cost;
+  size_t first = 0, count = 0;
+  bool filled = false;  // guarded by Feed::lock
+  bool failed = false;
+  std::string error;
+};
+
+struct Feed {
+  std::mutex lock;
+  std::condition_variable changed;
+  Chunk slot[2];
+  bool abandon = false;  // the consumer gave up: the filler stops at its next hand-over
+};
+
+}  // namespace
+
+// Fills slot `c` of a chunk from view `index`: depth (and best cost when the view has one) in vtk point order, the
+// identity-padded 4x4 K (cu:352) and [R|T] (cu:353).
+using ViewFill = std::function<bool(size_t index, double *depth, double *cost, bool *has_cost, double K4[16], double RT[16],
+                                    std::string *error)>;
+
+bool FusionDriver::Run(size_t n_views, const void *fill_ptr, double thresholdBestCost, double *io_scalar) {
+  const ViewFill &fill = *static_cast<const ViewFill *>(fill_ptr);
   Error.clear();
   if (!Initialized) {
     Error = "ProcessDepthMap: CudaInitialize has not been called";
     return false;
   }
-  if (views.empty()) {  // cu:304-308
+  if (n_views == 0) {  // cu:304-308
     Error = "Error, no depthMap or KRTD matrix have been loaded";
     std::cerr << Error << std::endl;
     return false;
@@ -267,27 +346,15 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
     return false;
   }
   const int W = DepthDims[0], H = DepthDims[1];
-  const size_t npix = (size_t)W * H;
-
-  dmi_options opt;
-  dmi_default_options(&opt);
-  opt.device = Device;
-  opt.grid_dtype = DMI_F64;  // ProcessDepthMap<double>, filt.cxx:175
-  opt.kernel_variant = KernelVariant;
-  dmi_context *ctx = nullptr;
-  int rc = dmi_create(&Grid, &Ray, &opt, &ctx);
-  if (rc != DMI_OK) {
-    Error = dmi_last_error(nullptr);
+  if (W < 1 || H < 1) {
+    Error = "ProcessDepthMap: CudaInitialize was given an empty depth-map size";
     return false;
   }
-  auto fail = [&](const std::string &what) {
-    Error = what + ": " + dmi_last_error(ctx);
-    dmi_destroy(ctx);
-    return false;
-  };
-  // cu:323-327: the accumulator starts from io_scalar
-  // +0.0 everywhere (all bits zero)?  The filter knows (RequestData has just filled the array, filt.cxx:133); other
-  // callers' arrays are scanned, eight bytes at a time.
+  const size_t npix = (size_t)W * H;
+  const bool multi = !Devices.empty();
+
+  // cu:323-327: the accumulator starts from io_scalar.  +0.0 everywhere (all bits zero)?  The filter knows (RequestData
+  // has just filled the array, filt.cxx:133); other callers' arrays are scanned, eight bytes at a time.
   bool all_zero = InitialGridIsZero;
   InitialGridIsZero = false;
   const int64_t nvox = NumberOfCells();
@@ -300,80 +367,210 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
     }
     all_zero = any == 0;
   }
-  if (!all_zero && dmi_upload_grid(ctx, io_scalar) != DMI_OK) return fail("dmi_upload_grid");
 
-  // Views go up as a pinned structure-of-arrays ([n][H][W] depth, [n][H][W] best cost, [n][16] K, [n][16] RT),
-  // a chunk of at most ~256 MiB at a time; dmi_add_views copies from it with hipMemcpyAsync on the context's upload
-  // stream and returns when the chunk is resident.  Each chunk is fused as soon as it is up (dmi_fuse_range,
-  // asynchronous on the compute stream), so the fusion of chunk i runs while chunk i+1 is packed and copied; every
-  // voxel still accumulates its views in order (cu:211), the f64 grid makes the chunking invisible in the result.
-  const size_t chunk = std::max<size_t>(1, std::min(views.size(), (size_t(256) << 20) / std::max<size_t>(1, npix * 16)));
-  double *p_depth = nullptr, *p_cost = nullptr;
-  void *pv = nullptr;
-  if (dmi_alloc_pinned(chunk * npix * 8, &pv) != DMI_OK) return fail("dmi_alloc_pinned(depth)");
-  p_depth = static_cast<double *>(pv);
-  if (dmi_alloc_pinned(chunk * npix * 8, &pv) != DMI_OK) {
-    dmi_free_pinned(p_depth);
-    return fail("dmi_alloc_pinned(best cost)");
+  dmi_context *ctx = nullptr;
+  dmi_multi_context *mctx = nullptr;
+  if (multi) {
+    if (!all_zero) {
+      Error = "ProcessDepthMap: a fusion over several GPUs (SetDevices) starts from a zero grid, as RequestData provides (filt.cxx:133)";
+      return false;
+    }
+    dmi_multi_options mo;
+    dmi_multi_default_options(&mo);
+    mo.partition = Partition;
+    // depth-map shards: the north star's float grid, summed by one RCCL all-reduce; z-slabs: the reference's f64, exact
+    mo.grid_dtype = Partition == DMI_PARTITION_Z_SLABS ? DMI_F64 : DMI_F32;
+    mo.kernel_variant = KernelVariant;
+    std::vector<int32_t> devs(Devices.begin(), Devices.end());
+    if (dmi_multi_create(&Grid, &Ray, &mo, devs.data(), (int32_t)devs.size(), &mctx) != DMI_OK) {
+      Error = dmi_multi_last_error(nullptr);
+      return false;
+    }
+  } else {
+    dmi_options opt;
+    dmi_default_options(&opt);
+    opt.device = Device;
+    opt.grid_dtype = DMI_F64;  // ProcessDepthMap<double>, filt.cxx:175
+    opt.kernel_variant = KernelVariant;
+    if (dmi_create(&Grid, &Ray, &opt, &ctx) != DMI_OK) {
+      Error = dmi_last_error(nullptr);
+      return false;
+    }
+    if (!all_zero && dmi_upload_grid(ctx, io_scalar) != DMI_OK) {
+      Error = std::string("dmi_upload_grid: ") + dmi_last_error(ctx);
+      dmi_destroy(ctx);
+      return false;
+    }
   }
-  p_cost = static_cast<double *>(pv);
-  std::vector<double> K4(chunk * 16), RT(chunk * 16);
+  auto last_error = [&]() -> std::string { return multi ? dmi_multi_last_error(mctx) : dmi_last_error(ctx); };
+  auto destroy = [&]() {
+    if (ctx) dmi_destroy(ctx);
+    if (mctx) dmi_multi_destroy(mctx);
+  };
+
+  // Views go up as pinned structure-of-arrays chunks of at most ~256 MiB.  Two chunks exist: while this thread copies
+  // chunk i to the device (dmi_add_views: hipMemcpyAsync on the upload stream, returns when the chunk is resident) and
+  // queues its fusion (dmi_fuse_range, asynchronous on the compute stream), a second thread fills chunk i+1 -- reading
+  // and parsing the .vti / .krtd files when the views come from list files, as the reference does one view at a time
+  // inside its loop (cu:343-353).  Host residency is two chunks whatever the number of views; every voxel still
+  // accumulates its views in order (cu:211), and the f64 grid makes the chunking invisible in the result.
+  const size_t chunk = std::max<size_t>(1, std::min(n_views, (size_t(256) << 20) / std::max<size_t>(1, npix * 16)));
+  Feed feed;
   bool ok = true;
-  for (size_t v0 = 0; ok && v0 < views.size(); v0 += chunk) {
-    const size_t cnt = std::min(chunk, views.size() - v0);
-    bool with_cost = true;
-    for (size_t c = 0; c < cnt; ++c) {
-      ReconstructionData *d = views[v0 + c];
-      DepthImage *img = d ? d->GetDepthMap() : nullptr;
-      if (!img || img->dims[0] != W || img->dims[1] != H || img->depths.size() != npix) {
-        // the reference takes the depth-map size from view 0 only (filt.cxx:167-168) and would read past
-        // the end of a smaller table; here a mismatch is an error
-        Error = "ProcessDepthMap: view " + std::to_string(v0 + c) + " has no depth map of the size given to CudaInitialize";
-        ok = false;
-        break;
-      }
-      std::memcpy(p_depth + c * npix, img->depths.data(), npix * 8);
-      // RD.cxx:156-157: the filter is skipped for a view whose cost array does not match
-      if (img->best_cost.size() == npix)
-        std::memcpy(p_cost + c * npix, img->best_cost.data(), npix * 8);
-      else
-        with_cost = false;
-      std::memcpy(&K4[c * 16], d->Get4MatrixK(), 16 * 8);   // cu:352
-      std::memcpy(&RT[c * 16], d->GetMatrixTR(), 16 * 8);   // cu:353
-    }
-    if (!ok) break;
-    if (!with_cost) {
-      // mixed chunk: apply the threshold on the host copy for the views that do have costs
-      for (size_t c = 0; c < cnt; ++c) {
-        DepthImage *img = views[v0 + c]->GetDepthMap();
-        if (img->best_cost.size() == npix)
-          for (size_t i = 0; i < npix; ++i)
-            if (img->best_cost[i] > thresholdBestCost) p_depth[c * npix + i] = -1;
-      }
-    }
-    rc = dmi_add_views(ctx, p_depth, with_cost ? p_cost : nullptr, thresholdBestCost, K4.data(), RT.data(), (int32_t)cnt, W, H);
-    if (rc != DMI_OK) {
-      Error = std::string("dmi_add_views: ") + dmi_last_error(ctx);
+  for (Chunk &c : feed.slot) {
+    void *pd = nullptr, *pc = nullptr;
+    if (dmi_alloc_pinned(chunk * npix * 8, &pd) != DMI_OK || dmi_alloc_pinned(chunk * npix * 8, &pc) != DMI_OK) {
+      if (pd) dmi_free_pinned(pd);
+      Error = "ProcessDepthMap: dmi_alloc_pinned failed";
       ok = false;
       break;
     }
-    rc = dmi_fuse_range(ctx, (int32_t)v0, (int32_t)cnt);  // replaces the kernel launches of these views (cu:363)
-    if (rc != DMI_OK) {
-      Error = std::string("dmi_fuse_range: ") + dmi_last_error(ctx);
-      ok = false;
-    }
+    c.depth = static_cast<double *>(pd);
+    c.cost = static_cast<double *>(pc);
+    c.K4.resize(chunk * 16);
+    c.RT.resize(chunk * 16);
+    c.has_cost.resize(chunk);
   }
-  dmi_free_pinned(p_depth);
-  dmi_free_pinned(p_cost);
+  auto free_chunks = [&]() {
+    for (Chunk &c : feed.slot) {
+      if (c.depth) dmi_free_pinned(c.depth);
+      if (c.cost) dmi_free_pinned(c.cost);
+      c.depth = c.cost = nullptr;
+    }
+  };
   if (!ok) {
-    dmi_destroy(ctx);
+    free_chunks();
+    destroy();
     return false;
   }
-  if (dmi_download_grid_f64(ctx, io_scalar) != DMI_OK) return fail("dmi_download_grid_f64");  // cu:368-371 (synchronises)
-  dmi_timings t;
-  if (dmi_get_timings(ctx, &t) == DMI_OK) FuseKernelMs = t.total_fuse_kernel_ms;
-  dmi_destroy(ctx);
+
+  const size_t n_chunks = (n_views + chunk - 1) / chunk;
+  std::thread filler([&]() {
+    for (size_t q = 0; q < n_chunks; ++q) {
+      Chunk &c = feed.slot[q & 1];
+      {
+        std::unique_lock<std::mutex> hold(feed.lock);
+        feed.changed.wait(hold, [&] { return !c.filled || feed.abandon; });
+        if (feed.abandon) return;
+      }
+      c.first = q * chunk;
+      c.count = std::min(chunk, n_views - c.first);
+      c.failed = false;
+      for (size_t v = 0; v < c.count && !c.failed; ++v) {
+        bool has_cost = false;
+        try {
+          if (!fill(c.first + v, c.depth + v * npix, c.cost + v * npix, &has_cost, &c.K4[v * 16], &c.RT[v * 16], &c.error)) c.failed = true;
+        } catch (const std::exception &e) {
+          c.error = std::string("view ") + std::to_string(c.first + v) + ": " + e.what();
+          c.failed = true;
+        }
+        c.has_cost[v] = has_cost ? 1 : 0;
+      }
+      {
+        std::lock_guard<std::mutex> hold(feed.lock);
+        c.filled = true;
+      }
+      feed.changed.notify_all();
+      if (c.failed) return;
+    }
+  });
+
+  for (size_t q = 0; ok && q < n_chunks; ++q) {
+    Chunk &c = feed.slot[q & 1];
+    {
+      std::unique_lock<std::mutex> hold(feed.lock);
+      feed.changed.wait(hold, [&] { return c.filled; });
+    }
+    if (c.failed) {
+      Error = c.error;
+      ok = false;
+      break;
+    }
+    // RD.cxx:156-157: the filter is skipped for a view whose cost array does not match.  A chunk whose views all have
+    // costs is thresholded on the device (fused into the upload kernel); a mixed chunk on this copy, view by view.
+    bool every_view_has_cost = true;
+    for (size_t v = 0; v < c.count; ++v) every_view_has_cost = every_view_has_cost && c.has_cost[v];
+    if (!every_view_has_cost)
+      for (size_t v = 0; v < c.count; ++v)
+        if (c.has_cost[v])
+          for (size_t i = 0; i < npix; ++i)
+            if (c.cost[v * npix + i] > thresholdBestCost) c.depth[v * npix + i] = -1;  // RD.cxx:159-166
+    const double *cost = every_view_has_cost ? c.cost : nullptr;
+    int rc;
+    if (multi) {
+      rc = dmi_multi_add_views(mctx, c.depth, cost, thresholdBestCost, c.K4.data(), c.RT.data(), (int32_t)c.count, W, H);
+    } else {
+      rc = dmi_add_views(ctx, c.depth, cost, thresholdBestCost, c.K4.data(), c.RT.data(), (int32_t)c.count, W, H);
+      // replaces the kernel launches of these views (cu:363); runs while the next chunk is filled and copied
+      if (rc == DMI_OK) rc = dmi_fuse_range(ctx, (int32_t)c.first, (int32_t)c.count);
+    }
+    if (rc != DMI_OK) {
+      Error = std::string(multi ? "dmi_multi_add_views: " : "dmi_add_views / dmi_fuse_range: ") + last_error();
+      ok = false;
+      break;
+    }
+    {
+      std::lock_guard<std::mutex> hold(feed.lock);
+      c.filled = false;  // the chunk is resident on the device: its buffers may be refilled
+    }
+    feed.changed.notify_all();
+  }
+  {
+    std::lock_guard<std::mutex> hold(feed.lock);
+    feed.abandon = !ok;
+  }
+  feed.changed.notify_all();
+  filler.join();
+  free_chunks();
+  if (!ok) {
+    destroy();
+    return false;
+  }
+  if (multi) {
+    // the whole fusion: every device fuses its share of the views, the library sums the grids (one RCCL all-reduce,
+    // overlapped slab by slab) or, for z-slabs, there is nothing to exchange
+    if (dmi_multi_fuse(mctx) != DMI_OK || dmi_multi_download_grid_f64(mctx, io_scalar, nullptr, nullptr) != DMI_OK) {
+      Error = std::string("dmi_multi_fuse / download: ") + last_error();
+      destroy();
+      return false;
+    }
+    dmi_multi_timings t;
+    if (dmi_multi_get_timings(mctx, &t) == DMI_OK) FuseKernelMs = t.last_step_ms;
+  } else {
+    if (dmi_download_grid_f64(ctx, io_scalar) != DMI_OK) {  // cu:368-371 (synchronises)
+      Error = std::string("dmi_download_grid_f64: ") + last_error();
+      destroy();
+      return false;
+    }
+    dmi_timings t;
+    if (dmi_get_timings(ctx, &t) == DMI_OK) FuseKernelMs = t.total_fuse_kernel_ms;
+  }
+  destroy();
   return true;
+}
+
+bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &views, double thresholdBestCost,
+                                   double *io_scalar) {
+  const int W = DepthDims[0], H = DepthDims[1];
+  const size_t npix = (size_t)W * H;
+  const ViewFill fill = [&](size_t index, double *depth, double *cost, bool *has_cost, double K4[16], double RT[16],
+                            std::string *error) {
+    ReconstructionData *d = views[index];
+    DepthImage *img = d ? d->GetDepthMap() : nullptr;
+    if (!img || img->dims[0] != W || img->dims[1] != H || img->depths.size() != npix) {
+      // the reference takes the depth-map size from view 0 only (filt.cxx:167-168) and would read past the end of a
+      // smaller table; here a mismatch is an error
+      *error = "ProcessDepthMap: view " + std::to_string(index) + " has no depth map of the size given to CudaInitialize";
+      return false;
+    }
+    std::memcpy(depth, img->depths.data(), npix * 8);
+    *has_cost = img->best_cost.size() == npix;
+    if (*has_cost) std::memcpy(cost, img->best_cost.data(), npix * 8);
+    std::memcpy(K4, d->Get4MatrixK(), 16 * 8);  // cu:352
+    std::memcpy(RT, d->GetMatrixTR(), 16 * 8);  // cu:353
+    return true;
+  };
+  return Run(views.size(), &fill, thresholdBestCost, io_scalar);
 }
 
 bool FusionDriver::ProcessDepthMap(const std::vector<std::string> &vtiList, const std::vector<std::string> &krtdList,
@@ -388,18 +585,30 @@ bool FusionDriver::ProcessDepthMap(const std::vector<std::string> &vtiList, cons
     Error = "ProcessDepthMap: fewer krtd files than depth maps";
     return false;
   }
-  std::vector<ReconstructionData> store;
-  store.reserve(n);
-  std::vector<ReconstructionData *> views;
-  for (size_t i = 0; i < n; ++i) {
-    store.emplace_back(vtiList[i], krtdList[i]);  // cu:347
-    if (!store.back().GetDepthMap()) {
-      Error = "ProcessDepthMap: cannot read depth map " + vtiList[i];
+  const int W = DepthDims[0], H = DepthDims[1];
+  const size_t npix = (size_t)W * H;
+  // one view at a time, read where the reference reads it (cu:347), straight into the pinned chunk: no view outlives
+  // the chunk it travels in
+  const ViewFill fill = [&](size_t index, double *depth, double *cost, bool *has_cost, double K4[16], double RT[16],
+                            std::string *error) {
+    ReconstructionData data(vtiList[index], krtdList[index]);
+    DepthImage *img = data.GetDepthMap();
+    if (!img) {
+      *error = "ProcessDepthMap: cannot read depth map " + vtiList[index];
       return false;
     }
-    views.push_back(&store.back());
-  }
-  return ProcessDepthMap(views, thresholdBestCost, io_scalar);
+    if (img->dims[0] != W || img->dims[1] != H || img->depths.size() != npix) {
+      *error = "ProcessDepthMap: depth map " + vtiList[index] + " does not have the size given to CudaInitialize";
+      return false;
+    }
+    std::memcpy(depth, img->depths.data(), npix * 8);
+    *has_cost = img->best_cost.size() == npix;
+    if (*has_cost) std::memcpy(cost, img->best_cost.data(), npix * 8);
+    std::memcpy(K4, data.Get4MatrixK(), 16 * 8);
+    std::memcpy(RT, data.GetMatrixTR(), 16 * 8);
+    return true;
+  };
+  return Run(n, &fill, thresholdBestCost, io_scalar);
 }
 
 // ====================================================================================================
@@ -485,9 +694,19 @@ int ReconstructionFilter::Compute(int gridDims[3], double gridOrig[3], double gr
     std::cerr << Error << std::endl;
     return -1;
   }
-  std::vector<ReconstructionData> store;
-  std::vector<ReconstructionData *> views = Views;
-  if (views.empty()) {
+  FusionDriver driver;
+  driver.SetDevice(Device);
+  driver.SetDevices(Devices);
+  driver.SetPartition(Partition);
+  driver.SetKernelVariant(KernelVariant);
+  driver.SetInitialGridIsZero(true);  // RequestData zero-filled outScalar just before (filt.cxx:133)
+  bool result;
+  if (!Views.empty()) {
+    int *depthMapGrid = Views[0]->GetDepthMapDimensions();  // filt.cxx:167-168: sizes from view 0
+    driver.CudaInitialize(GridMatrix, gridDims, gridOrig, gridSpacing, RayPotentialThickness, RayPotentialRho,
+                          RayPotentialEta, RayPotentialDelta, depthMapGrid);  // filt.cxx:171-173
+    result = driver.ProcessDepthMap(Views, ThresholdBestCost, outScalar->data());  // filt.cxx:175-176
+  } else {
     const std::vector<std::string> vtiList = help::ExtractAllFilePath(FilePathVTI.c_str());    // filt.cxx:158
     const std::vector<std::string> krtdList = help::ExtractAllFilePath(FilePathKRTD.c_str());  // filt.cxx:159
     if (vtiList.size() == 0 || krtdList.size() < vtiList.size()) {  // filt.cxx:161-165
@@ -495,25 +714,22 @@ int ReconstructionFilter::Compute(int gridDims[3], double gridOrig[3], double gr
       std::cerr << Error << std::endl;
       return -1;
     }
-    store.reserve(vtiList.size());
-    for (size_t i = 0; i < vtiList.size(); ++i) {
-      store.emplace_back(vtiList[i], krtdList[i]);
-      if (!store.back().GetDepthMap()) {
-        Error = "Error : cannot read depth map " + vtiList[i];
+    int depthMapGrid[2];
+    {
+      ReconstructionData data0(vtiList[0], krtdList[0]);  // filt.cxx:167: the first view, for the depth-map size only
+      if (!data0.GetDepthMap()) {
+        Error = "Error : cannot read depth map " + vtiList[0];
         std::cerr << Error << std::endl;
         return -1;
       }
-      views.push_back(&store.back());
+      depthMapGrid[0] = data0.GetDepthMapDimensions()[0];  // filt.cxx:168
+      depthMapGrid[1] = data0.GetDepthMapDimensions()[1];
     }
+    driver.CudaInitialize(GridMatrix, gridDims, gridOrig, gridSpacing, RayPotentialThickness, RayPotentialRho,
+                          RayPotentialEta, RayPotentialDelta, depthMapGrid);  // filt.cxx:171-173
+    // the views are read chunk by chunk inside the driver, as the reference reads them inside its loop (cu:343-353)
+    result = driver.ProcessDepthMap(vtiList, krtdList, ThresholdBestCost, outScalar->data());  // filt.cxx:175-176
   }
-  int *depthMapGrid = views[0]->GetDepthMapDimensions();  // filt.cxx:167-168: sizes from view 0
-  FusionDriver driver;
-  driver.SetDevice(Device);
-  driver.SetKernelVariant(KernelVariant);
-  driver.CudaInitialize(GridMatrix, gridDims, gridOrig, gridSpacing, RayPotentialThickness, RayPotentialRho,
-                        RayPotentialEta, RayPotentialDelta, depthMapGrid);  // filt.cxx:171-173
-  driver.SetInitialGridIsZero(true);  // RequestData zero-filled outScalar just before (filt.cxx:133)
-  const bool result = driver.ProcessDepthMap(views, ThresholdBestCost, outScalar->data());  // filt.cxx:175-176
   FuseKernelMs = driver.LastFuseKernelMs();
   if (!result) {
     Error = driver.LastError();

@@ -97,16 +97,26 @@ class FusionDriver {
                       const double h_gridSpacing[3], double h_rayPThick, double h_rayPRho, double h_rayPEta,
                       double h_rayPDelta, const int h_depthMapDim[2]);
 
-  // cu:302-386 with in-memory views: threshold (cu:348), upload as pinned SoA (replaces cu:351-360), one
-  // fused launch (replaces the per-map launches cu:363), download into io_scalar (cu:368-371).
+  // cu:302-386 with in-memory views: threshold (cu:348), upload as pinned SoA chunks (replaces cu:351-360), one fused
+  // launch per chunk (replaces the per-map launches cu:363) overlapped with the filling of the next chunk, download
+  // into io_scalar (cu:368-371).
   // io_scalar holds NumberOfCells doubles and is accumulated onto (cu:323-327).  Returns false on error
   // (message in LastError()); never calls exit() (the reference's gpuAssert does, cu:68-76).
   bool ProcessDepthMap(const std::vector<ReconstructionData *> &views, double thresholdBestCost, double *io_scalar);
-  // same, from list files as the reference (vtiList[i], krtdList[i] -> ReconstructionData, cu:347)
+  // same, from list files as the reference (vtiList[i], krtdList[i] -> ReconstructionData, cu:347): the files are read
+  // one view at a time by a second thread while the previous chunk uploads and fuses, so host memory holds two chunks
+  // (<= 2 x 256 MiB of depth + as much of best cost), never the whole set of views
   bool ProcessDepthMap(const std::vector<std::string> &vtiList, const std::vector<std::string> &krtdList,
                        double thresholdBestCost, double *io_scalar);
 
   void SetDevice(int device) { Device = device; }
+  // Several GPUs of the node for ONE fusion (none in the reference; north star: depth maps shard across the GPUs, one
+  // RCCL all-reduce of the float TSDF grid).  Empty = single GPU (SetDevice).  Non-empty: ProcessDepthMap runs through
+  // dmi_multi_* -- DMI_PARTITION_VIEWS (default): f32 grids summed over xGMI, |result - single GPU| within
+  // 2*G*2^-24*sum|partials| per voxel; DMI_PARTITION_Z_SLABS: every GPU fuses all views into its own cell layers, f64,
+  // no exchange, bit-identical to one GPU.  The grid must start from zeros (as RequestData provides, filt.cxx:133).
+  void SetDevices(const std::vector<int> &devices) { Devices = devices; }
+  void SetPartition(int partition) { Partition = partition; }
   void SetKernelVariant(int v) { KernelVariant = v; }
   // the next ProcessDepthMap's io_scalar is known to hold +0.0 everywhere: skips the scan and the upload (cu:323-327)
   void SetInitialGridIsZero(bool yes) { InitialGridIsZero = yes; }
@@ -120,7 +130,12 @@ class FusionDriver {
   int DepthDims[2];
   bool Initialized = false;
   bool InitialGridIsZero = false;
+  // the driver loop behind both ProcessDepthMap forms: n_views views produced by *fill (a ViewFill, recon_host.cpp)
+  bool Run(size_t n_views, const void *fill, double thresholdBestCost, double *io_scalar);
+
   int Device = 0;
+  std::vector<int> Devices;
+  int Partition = DMI_PARTITION_VIEWS;
   int KernelVariant = 0;
   double FuseKernelMs = 0.0;
   std::string Error;
@@ -163,6 +178,9 @@ class ReconstructionFilter {
   const std::string &LastError() const { return Error; }
 
   void SetDevice(int d) { Device = d; }
+  // new, optional, default = the reference's single GPU: see FusionDriver::SetDevices / SetPartition
+  void SetDevices(const std::vector<int> &devices) { Devices = devices; }
+  void SetPartition(int partition) { Partition = partition; }
   void SetKernelVariant(int v) { KernelVariant = v; }
   double GetFuseKernelMs() const { return FuseKernelMs; }
 
@@ -185,6 +203,8 @@ class ReconstructionFilter {
   std::vector<double> OutScalar;
   std::string Error;
   int Device = 0, KernelVariant = 0;
+  std::vector<int> Devices;
+  int Partition = DMI_PARTITION_VIEWS;
   double FuseKernelMs = 0.0;
 };
 

@@ -7,6 +7,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <sstream>
 
@@ -108,8 +109,11 @@ uint64_t header_word(const unsigned char *p, const Format &f, size_t index) {
   return v;
 }
 
-// `expect` = the byte count the extent and the array's type call for: sizes read from the file are checked against
-// it BEFORE anything is allocated, so a corrupt header cannot ask for terabytes.
+// `expect` = the byte count the extent and the array's type call for.  The extent is itself read from the file, so
+// `expect` is bounded by what the compressed bytes actually present could inflate to (deflate's ratio never exceeds
+// 1032 : 1) BEFORE anything is allocated: a tiny crafted file cannot ask for terabytes.
+constexpr uint64_t kMaxInflateRatio = 1032;
+
 bool inflate_blocks(const unsigned char *src, size_t src_len, const std::vector<uint64_t> &csize, uint64_t block,
                     uint64_t last, size_t expect, std::vector<unsigned char> *out, std::string *err) {
   const size_t nb = csize.size();
@@ -119,6 +123,14 @@ bool inflate_blocks(const unsigned char *src, size_t src_len, const std::vector<
   uint64_t total = 0;
   for (size_t b = 0; b < nb; ++b) total += (b + 1 == nb && last != 0) ? last : block;
   if (total != expect) return fail(err, "compressed array does not have the size its extent and type call for");
+  uint64_t cbytes = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    if (csize[b] > src_len) return fail(err, "compressed block runs past the end of the data");
+    cbytes += csize[b];
+  }
+  if (cbytes > src_len) return fail(err, "compressed blocks run past the end of the data");
+  if (total > kMaxInflateRatio * cbytes + 64 * (uint64_t)nb)
+    return fail(err, "the extent asks for more bytes than the compressed data can hold");
   out->resize((size_t)total);
   size_t in_off = 0, out_off = 0;
   for (size_t b = 0; b < nb; ++b) {
@@ -165,6 +177,8 @@ bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f
     if (!b64_decode(text, &p, end, hw, &head)) return fail(err, "base64: truncated header");
     const uint64_t n = header_word(head.data(), f, 0);
     if (n != expect) return fail(err, "array does not have the size its extent and type call for");
+    // four characters carry three bytes: the text that is left bounds the array before anything is reserved
+    if (n > (uint64_t)(end - pos) / 4 * 3 + 3) return fail(err, "base64: array data is shorter than its header says");
     std::vector<unsigned char> all;
     all.reserve((size_t)n + hw + 3);
     p = pos;
@@ -205,7 +219,24 @@ bool decode_b64(const std::string &text, size_t pos, size_t end, const Format &f
 
 }  // namespace
 
+namespace {
+bool read_image_data(const std::string &path, const std::vector<std::string> &wanted, Image *out, std::string *err);
+}
+
 bool ReadImageData(const std::string &path, const std::vector<std::string> &wanted, Image *out, std::string *err) {
+  // nothing thrown by the containers (bad_alloc, length_error) may leave this function: its callers sit right below
+  // extern "C" entry points
+  try {
+    return read_image_data(path, wanted, out, err);
+  } catch (const std::exception &e) {
+    return fail(err, path + ": " + e.what());
+  } catch (...) {
+    return fail(err, path + ": unknown failure while reading");
+  }
+}
+
+namespace {
+bool read_image_data(const std::string &path, const std::vector<std::string> &wanted, Image *out, std::string *err) {
   std::ifstream f(path.c_str(), std::ios::binary);
   if (!f.is_open()) return fail(err, "cannot open " + path);
   std::stringstream ss;
@@ -356,6 +387,7 @@ bool ReadImageData(const std::string &path, const std::vector<std::string> &want
   }
   return true;
 }
+}  // namespace
 
 }  // namespace vti
 }  // namespace host

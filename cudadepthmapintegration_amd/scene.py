@@ -141,26 +141,31 @@ def render_sphere_depth(K: np.ndarray, RT: np.ndarray, W: int, H: int, center=(0
 
 def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", dense: bool = False,
                with_best_cost: bool = False, radius: float = 3.0, focal_scale: float = 0.9,
-               dtype=np.float64) -> Views:
+               dtype=np.float64, view_range: tuple | None = None) -> Views:
     """n cameras around the sphere scene.  dense=True adds a background at camera z = radius + 0.5
-    so nearly every in-frustum voxel reaches the accumulate (hit rate ~100 % instead of ~30 %)."""
+    so nearly every in-frustum voxel reaches the accumulate (hit rate ~100 % instead of ~30 %).
+    view_range=(lo, hi) renders only views lo .. hi-1 of that same n-camera scene (a rank of a multi-GPU run renders
+    its own share; view g is the same whoever renders it)."""
     K = np.eye(4)
     K[0, 0] = K[1, 1] = focal_scale * W
     K[0, 2] = W / 2.0
     K[1, 2] = H / 2.0
     pos = camera_positions(n, radius=radius, layout=layout)
     rng = np.random.default_rng(seed)
-    depth = np.empty((n, H, W), dtype=dtype)  # values are f32-representable either way
-    K4 = np.empty((n, 4, 4))
-    RT4 = np.empty((n, 4, 4))
-    for m in range(n):
-        # small deterministic jitter so no two cameras share exact symmetries
-        jitter = 0.02 * rng.standard_normal(3)
-        RT4[m] = look_at_rt(pos[m], target=jitter)
-        K4[m] = K
-        depth[m] = render_sphere_depth(K[:3, :3], RT4[m], W, H,
-                                       background=(radius + 0.5) if dense else None)
-    best = rng.random((n, H, W)) if with_best_cost else None
+    # small deterministic jitter so no two cameras share exact symmetries (drawn for all n: the stream position of
+    # view g's jitter does not depend on who asks)
+    jitter = 0.02 * rng.standard_normal((n, 3))
+    lo, hi = (0, n) if view_range is None else (int(view_range[0]), int(view_range[1]))
+    cnt = hi - lo
+    depth = np.empty((cnt, H, W), dtype=dtype)  # values are f32-representable either way
+    K4 = np.empty((cnt, 4, 4))
+    RT4 = np.empty((cnt, 4, 4))
+    for m in range(lo, hi):
+        RT4[m - lo] = look_at_rt(pos[m], target=jitter[m])
+        K4[m - lo] = K
+        depth[m - lo] = render_sphere_depth(K[:3, :3], RT4[m - lo], W, H,
+                                            background=(radius + 0.5) if dense else None)
+    best = rng.random((n, H, W))[lo:hi] if with_best_cost else None
     return Views(depth, K4, RT4, best)
 
 
@@ -233,3 +238,16 @@ def make_mesh_points(n: int, seed: int = 0, radius: float = 0.6) -> np.ndarray:
     k = n // 4
     pts[:k] = rng.uniform(-1.6, 1.6, size=(k, 3))
     return pts
+
+
+def morton_order(points: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Indices that sort points along a Z-order curve of their bounding box: neighbours in space become neighbours in
+    the array, as the vertices a marching-cubes sweep emits are (the coloration bench's "mesh-ordered" vertex set)."""
+    p = np.asarray(points, dtype=np.float64)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    q = np.clip(((p - lo) / np.maximum(hi - lo, 1e-300) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+    key = np.zeros(len(p), dtype=np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            key |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return np.argsort(key, kind="stable")

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DMI_ABI_VERSION 1
+#define DMI_ABI_VERSION 2
 
 typedef struct dmi_context dmi_context;
 
@@ -177,7 +177,10 @@ int dmi_fuse_slab(dmi_context *ctx, int32_t z_first, int32_t z_count);
 
 int dmi_synchronize(dmi_context *ctx);
 
-/* Replace the D2H copy and the per-tuple copy into io_scalar (cu:368-371).  They synchronise. */
+/* Replace the D2H copy and the per-tuple copy into io_scalar (cu:368-371).  They synchronise.  When the requested type
+ * is not the grid's, the conversion runs on the device and the host side is plain copies: `out` in pinned memory
+ * (dmi_alloc_pinned, or a buffer the caller registered) is filled at DMA speed, pageable memory at the runtime's
+ * staging speed.  The same holds for dmi_upload_grid into an f32 grid. */
 int dmi_download_grid_f64(dmi_context *ctx, double *out);
 int dmi_download_grid_f32(dmi_context *ctx, float *out);
 
@@ -216,6 +219,9 @@ int dmi_get_info(dmi_context *ctx, dmi_info *out);
 /* Pinned host memory for the SoA staging buffers of the host side (hipHostMalloc). */
 int dmi_alloc_pinned(size_t bytes, void **out);
 int dmi_free_pinned(void *ptr);
+/* Diagnostic: the host <-> device copy rates (GB/s, pinned memory, one hipMemcpyAsync of `bytes` each way, best of two)
+ * that bound every PCIe-inclusive figure of this path -- the roof next to which bench.py quotes its end-to-end numbers. */
+int dmi_pcie_probe(int32_t device, size_t bytes, double *h2d_GBps, double *d2h_GBps);
 
 /* ---- MeshColoration pass (Coloration/MeshColoration.cxx:98-199; the reference runs it on the CPU) ----
  * For every mesh vertex: the views whose projection of the vertex (RD.cxx:169-182: no z-sign test, no depth
@@ -242,8 +248,125 @@ int dmi_color_add_views(dmi_color_context *ctx, const uint8_t *colors, const dou
 int dmi_color_clear_views(dmi_color_context *ctx);
 int dmi_color_process(dmi_color_context *ctx, const double *points, int64_t n_points, uint8_t *mean, uint8_t *median,
                       int32_t *count);
+/* Upper bound, in bytes, of the device scratch one chunk of vertices may use (default 1 GiB, at least 1024): a smaller
+ * budget means more, smaller chunks, never a different result. */
+int dmi_color_set_scratch_budget(dmi_color_context *ctx, uint64_t bytes);
 /* hipEvent time of the kernels (projection + median) of the last dmi_color_process, summed over its chunks */
 int dmi_color_get_kernel_ms(dmi_color_context *ctx, double *out);
+
+/* ---- One fusion over several MI355X of a node (north star: "depth maps shard across the 8 GPUs of one node with a
+ * single RCCL all-reduce of the float TSDF grid over xGMI").  The reference has nothing of the kind (one GPU, default
+ * stream, cu:302-386); the seam where this plugs in is the pair of driver calls at
+ * Reconstruction/vtkCudaReconstructionFilter.cxx:171-176.
+ *
+ * A dmi_multi_context is `world` ranks, one per GPU, either all inside this process (dmi_multi_create: one thread
+ * drives every device, ncclCommInitAll) or one per process (dmi_multi_create_rank: ncclCommInitRank with a unique id
+ * that the launcher distributes -- MPI, torch.distributed, a file).  RCCL (librccl.so.1) is loaded on first use;
+ * single-GPU users never need it.
+ *
+ * Partitions:
+ *   DMI_PARTITION_VIEWS    rank r fuses its contiguous share of every batch of views into a private full grid, then
+ *                          the grids are summed across ranks (exchange below).  Per-voxel summation order changes:
+ *                          |result - single-GPU f64 result| <= 2*world*2^-24*sum|partials| for an f32 grid.
+ *   DMI_PARTITION_Z_SLABS  rank r owns the cell layers dmi_multi_z_slab(nz, r, world) and fuses ALL views into them:
+ *                          no exchange step at all, bit-identical to one single-GPU fusion.
+ * Exchange (VIEWS only):
+ *   DMI_EXCHANGE_ALL_REDUCE      the contract: every rank ends with the whole summed grid.  The fusion runs in
+ *                                n_slabs z-slabs (dmi_fuse_slab) and the all-reduce of slab i runs on a second stream
+ *                                while slab i+1 is fused; the last slab is the thinnest (its exchange is the only part
+ *                                nothing hides).
+ *   DMI_EXCHANGE_REDUCE_SCATTER  for when only the host consumes the grid: rank r ends with the sum of its own 1/world
+ *                                of the grid (half the xGMI traffic) and downloads just that. */
+typedef struct dmi_multi_context dmi_multi_context;
+
+typedef enum dmi_partition { DMI_PARTITION_VIEWS = 0, DMI_PARTITION_Z_SLABS = 1 } dmi_partition;
+typedef enum dmi_exchange { DMI_EXCHANGE_ALL_REDUCE = 0, DMI_EXCHANGE_REDUCE_SCATTER = 1 } dmi_exchange;
+
+#define DMI_UNIQUE_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+typedef struct dmi_multi_options {
+  int32_t grid_dtype;     /* DMI_F32 (the north star's all-reduce type) or DMI_F64 */
+  int32_t depth_storage;  /* dmi_depth_storage */
+  int32_t kernel_variant; /* as dmi_options */
+  int32_t partition;      /* dmi_partition */
+  int32_t exchange;       /* dmi_exchange */
+  int32_t n_slabs;        /* z-slabs of the overlapped all-reduce; 0 = default (4), 1 = fuse whole grid, then exchange */
+} dmi_multi_options;
+
+typedef struct dmi_multi_info {
+  int32_t world;          /* ranks of the fusion = GPUs */
+  int32_t n_local;        /* ranks driven by this process */
+  int32_t first_rank;     /* rank of local device 0 (the others follow consecutively) */
+  int32_t rccl_ranks;     /* what ncclCommCount reports for local rank 0's communicator; 0 = no communicator (Z_SLABS) */
+  int32_t rccl_version;   /* ncclGetVersion, 0 when RCCL was never loaded */
+  int32_t partition, exchange, n_slabs;
+  int64_t n_voxels;       /* of the whole grid */
+  int64_t n_views_total;  /* views handed to dmi_multi_add_views so far */
+  int64_t n_views_local;  /* of those, resident on this process's devices (VIEWS: the shards; Z_SLABS: all, per device) */
+} dmi_multi_info;
+
+typedef struct dmi_multi_timings {
+  double last_step_ms;        /* hipEvents on local rank 0's compute stream around one dmi_multi_fuse: reset + fusion +
+                                 whatever of the exchange the fusion did not hide */
+  double last_fuse_kernel_ms; /* of that, the fusion launches of local rank 0 (dmi_timings.last_fuse_kernel_ms summed
+                                 over the slabs) */
+  double total_step_ms;
+  uint64_t steps;
+} dmi_multi_timings;
+
+void dmi_multi_default_options(dmi_multi_options *opt); /* f32 grid, AUTO depth storage, VIEWS + ALL_REDUCE, 4 slabs */
+
+/* Pure partition arithmetic (no GPU needed), the same on every rank:
+ * contiguous balanced share [*first, *first + *count) of n items for `rank` of `world` (the first n % world ranks
+ * get one more) */
+int dmi_multi_view_shard(int64_t n, int32_t rank, int32_t world, int64_t *first, int64_t *count);
+/* cell layers [*z_first, *z_first + *z_count) owned by `rank` under DMI_PARTITION_Z_SLABS: boundaries are multiples of
+ * DMI_SLAB_ALIGNMENT except the top of the grid; a rank may own nothing when nz is small */
+int dmi_multi_z_slab(int32_t nz, int32_t rank, int32_t world, int32_t *z_first, int32_t *z_count);
+/* the z-slabs of the overlapped exchange: writes at most max_slabs (z_first, z_count) pairs, returns how many */
+int dmi_multi_slab_ranges(int32_t nz, int32_t n_slabs, int32_t *z_first, int32_t *z_count, int32_t max_slabs);
+
+/* All ranks in this process: devices[0..n) are HIP ordinals, rank i runs on devices[i]. */
+int dmi_multi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dmi_multi_options *opt,
+                     const int32_t *devices, int32_t n, dmi_multi_context **out);
+/* One rank per process.  Rank 0 calls dmi_multi_get_unique_id and the launcher hands the 128 bytes to every rank;
+ * all ranks then call dmi_multi_create_rank (collective: returns when every rank has joined). */
+int dmi_multi_get_unique_id(uint8_t id[DMI_UNIQUE_ID_BYTES]);
+int dmi_multi_create_rank(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dmi_multi_options *opt,
+                          int32_t device, int32_t rank, int32_t world, const uint8_t id[DMI_UNIQUE_ID_BYTES],
+                          dmi_multi_context **out);
+void dmi_multi_destroy(dmi_multi_context *ctx);
+const char *dmi_multi_last_error(const dmi_multi_context *ctx); /* ctx == NULL: the thread's last create failure */
+
+/* Same arguments as dmi_add_views / dmi_add_views_f32, called with the SAME batch on every rank (every process passes
+ * the whole batch; each takes what its ranks need: VIEWS -> the rank's share of this batch, Z_SLABS -> all of it). */
+int dmi_multi_add_views(dmi_multi_context *ctx, const double *depth, const double *best_cost, double threshold,
+                        const double *K4, const double *RT4, int32_t n, int32_t width, int32_t height);
+int dmi_multi_add_views_f32(dmi_multi_context *ctx, const float *depth, const double *K4, const double *RT4, int32_t n,
+                            int32_t width, int32_t height);
+/* Views that belong to local rank `local_index` only, for callers that partition themselves (dmi_multi_view_shard) and
+ * never hold the whole batch in one process -- e.g. one process per GPU, each reading its own share of the list files. */
+int dmi_multi_add_local_views(dmi_multi_context *ctx, int32_t local_index, const double *depth, const double *best_cost,
+                              double threshold, const double *K4, const double *RT4, int32_t n, int32_t width, int32_t height);
+int dmi_multi_add_local_views_f32(dmi_multi_context *ctx, int32_t local_index, const float *depth, const double *K4,
+                                  const double *RT4, int32_t n, int32_t width, int32_t height);
+int dmi_multi_clear_views(dmi_multi_context *ctx);
+
+/* One whole fusion: zero the grids, fuse every resident view, exchange.  Asynchronous; collective across ranks. */
+int dmi_multi_fuse(dmi_multi_context *ctx);
+int dmi_multi_synchronize(dmi_multi_context *ctx);
+
+/* The fused grid, n_voxels elements, x fastest.  What this process can write, it writes:
+ *   ALL_REDUCE: the whole grid (from local rank 0);  REDUCE_SCATTER / Z_SLABS: the parts its ranks own, at their
+ *   place in `out` (a single-process context therefore always fills all of `out`).
+ * owned_first / owned_count (nullable) receive the contiguous element range this process wrote. */
+int dmi_multi_download_grid_f32(dmi_multi_context *ctx, float *out, int64_t *owned_first, int64_t *owned_count);
+int dmi_multi_download_grid_f64(dmi_multi_context *ctx, double *out, int64_t *owned_first, int64_t *owned_count);
+
+int dmi_multi_get_info(dmi_multi_context *ctx, dmi_multi_info *out);
+int dmi_multi_get_timings(dmi_multi_context *ctx, dmi_multi_timings *out);
+/* the single-GPU context of local rank i (views, timings, diagnostics); owned by the multi context */
+int dmi_multi_local_context(dmi_multi_context *ctx, int32_t local_index, dmi_context **out);
 
 int dmi_abi_version(void);
 int dmi_device_count(void);

@@ -38,6 +38,11 @@ int dmi_filter_add_view(dmi_filter *f, const double *depths, const double *best_
 void dmi_filter_clear_views(dmi_filter *f);
 void dmi_filter_set_device(dmi_filter *f, int32_t device);
 void dmi_filter_set_kernel_variant(dmi_filter *f, int32_t variant);
+/* New and optional (the reference drives one GPU): fuse on several GPUs of the node through dmi_multi_* (dmi.h).
+ * n == 0 (the default) = single GPU.  partition: DMI_PARTITION_VIEWS (depth-map shards + one RCCL all-reduce of the
+ * f32 grid; the default) or DMI_PARTITION_Z_SLABS (no exchange, f64, bit-identical to one GPU). */
+void dmi_filter_set_devices(dmi_filter *f, const int32_t *devices, int32_t n);
+void dmi_filter_set_partition(dmi_filter *f, int32_t partition);
 /* Update() -> RequestData (filt.cxx:96-151): 1 on success, 0 on error */
 int dmi_filter_update(dmi_filter *f);
 double dmi_filter_get_execution_time(const dmi_filter *f);            /* filt.h:81 */

@@ -141,38 +141,58 @@ static int project_one(const oracle_params *p, const double *depths, const doubl
  *
  * The hit counters are not a reference output; they expose every
  * in-frustum / sentinel decision so parity can be checked on integers.
- * n_threads <= 1 runs serially; otherwise OpenMP over z slabs (each voxel is
- * still accumulated in depth-map order, so results do not depend on it). */
+ * n_threads <= 1 replays the reference's order exactly (map by map, cu:343; within a map z, y, x).  n_threads > 1
+ * is the timed CPU baseline: ONE parallel region, z-layers dealt dynamically, and the thread that takes a layer runs
+ * it through every map (k outer, m inner).  Each voxel still receives its increments in depth-map order, so the grid
+ * and both counters are bit-identical to the serial replay (tests/test_oracle.py); what changes is that there is no
+ * barrier per map, layers of uneven work balance, and a layer's grid pages are first touched -- hence NUMA-placed --
+ * by the thread that keeps working on them. */
+static void fuse_layer(const oracle_params *p, const double *dm, const double *K, const double *RT, int nx, int ny,
+                       int k, double *grid, uint32_t *voxel_hits, uint64_t *hits_this_map)
+{
+  for (int j = 0; j < ny; ++j)
+    for (int i = 0; i < nx; ++i) {
+      double inc;
+      if (project_one(p, dm, K, RT, i, j, k, &inc)) {
+        int64_t grid_id = ((int64_t)k * ny + j) * nx + i; /* cu:126-134 */
+        grid[grid_id] += inc;                             /* cu:211 */
+        if (voxel_hits)
+          voxel_hits[grid_id] += 1;
+        *hits_this_map += 1;
+      }
+    }
+}
+
 void oracle_fuse(const oracle_params *p, const double *depths, const double *K16,
                  const double *RT16, int n_maps, double *grid, uint32_t *voxel_hits,
                  uint64_t *map_hits, int n_threads)
 {
   const int nx = p->point_dims[0] - 1, ny = p->point_dims[1] - 1, nz = p->point_dims[2] - 1;
   const int64_t n_pix = (int64_t)p->depth_dims[0] * p->depth_dims[1];
-  (void)n_threads;
-  for (int m = 0; m < n_maps; ++m) {
-    const double *dm = depths + (int64_t)m * n_pix;
-    const double *K = K16 + 16 * m;
-    const double *RT = RT16 + 16 * m;
-    uint64_t hits_this_map = 0;
-#ifdef _OPENMP
-#pragma omp parallel for schedule(static) reduction(+ : hits_this_map) num_threads(n_threads > 1 ? n_threads : 1)
-#endif
-    for (int k = 0; k < nz; ++k)
-      for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i) {
-          double inc;
-          if (project_one(p, dm, K, RT, i, j, k, &inc)) {
-            int64_t grid_id = ((int64_t)k * ny + j) * nx + i; /* cu:126-134 */
-            grid[grid_id] += inc;                             /* cu:211 */
-            if (voxel_hits)
-              voxel_hits[grid_id] += 1;
-            hits_this_map += 1;
-          }
-        }
-    if (map_hits)
-      map_hits[m] += hits_this_map;
+  if (n_threads <= 1) {
+    for (int m = 0; m < n_maps; ++m) { /* cu:343 */
+      uint64_t hits_this_map = 0;
+      for (int k = 0; k < nz; ++k)
+        fuse_layer(p, depths + (int64_t)m * n_pix, K16 + 16 * m, RT16 + 16 * m, nx, ny, k, grid, voxel_hits, &hits_this_map);
+      if (map_hits)
+        map_hits[m] += hits_this_map;
+    }
+    return;
   }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#endif
+  for (int k = 0; k < nz; ++k)
+    for (int m = 0; m < n_maps; ++m) {
+      uint64_t hits_this_map = 0;
+      fuse_layer(p, depths + (int64_t)m * n_pix, K16 + 16 * m, RT16 + 16 * m, nx, ny, k, grid, voxel_hits, &hits_this_map);
+      if (map_hits && hits_this_map) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        map_hits[m] += hits_this_map;
+      }
+    }
 }
 
 /* Same arithmetic for a caller-chosen list of voxel ids (x-fastest linear

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_defaults():
     lib = capi.load()
-    assert lib.dmi_abi_version() == 1
+    assert lib.dmi_abi_version() == 2
     o = capi.OptionsC()
     lib.dmi_default_options(ctypes.byref(o))
     assert (o.device, o.grid_dtype, o.depth_storage, o.count_hits, o.kernel_variant) == (0, capi.DMI_F64, 0, 0, 0)
@@ -63,3 +63,34 @@ def test_product_package_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
                 assert "liboracle" not in src and "tsdf_oracle.c\"" not in src
+
+
+def test_accumulator_register_audit_covers_this_build():
+    """fusion_tile.hip keeps its running sums in VGPRs the compiler only knows as clobbers (fusion_tile_acc.inc): a
+    toolchain that allocates one of them would corrupt sums silently.  build() audits the gfx950 assembly whenever the
+    kernel is recompiled; here: the audit record exists, is not older than the kernel source, and saw every shape."""
+    import json
+
+    from cudadepthmapintegration_amd import build
+
+    capi.load()
+    marker = os.path.join(build.OBJ_DIR, "acc_audit.json")
+    src = os.path.join(build.CSRC, "fusion_tile.hip")
+    if not os.path.exists(marker) or os.path.getmtime(marker) < os.path.getmtime(src):
+        build.run_accumulator_audit()           # e.g. a prebuilt .so copied without build/: audit now (hipcc -S, ~30 s)
+    rec = json.load(open(marker))
+    assert rec["violations"] == 0 and rec["instantiations"] >= 30
+
+
+def test_accumulator_register_audit_flags_a_violation():
+    from cudadepthmapintegration_amd import build
+
+    name = "_ZN3dmi12_GLOBAL__N_116fuse_tile_kernelIffLi8ELi1ELi1ELi6ELi8ELb0ELb0EEEvNS_8TileArgsE"
+    ok = (f"\n{name}:\n\tv_add_f64 v[2:3], v[4:5], v[6:7]\n\t;;#ASMSTART\n\tv_add_f64 v[80:81], v[80:81], s[2:3]\n\t;;#ASMEND\n"
+          f"\ts_endpgm\n.amdhsa_kernel {name}\n\t\t.amdhsa_next_free_vgpr 96\n.end_amdhsa_kernel\n")
+    assert build.audit_accumulator_registers(ok) == (1, [])
+    clobbered = ok.replace("v_add_f64 v[2:3], v[4:5], v[6:7]", "v_mov_b32_e32 v81, v3")
+    n, bad = build.audit_accumulator_registers(clobbered)
+    assert n == 1 and len(bad) == 1 and "v81" in bad[0]
+    short = ok.replace("next_free_vgpr 96", "next_free_vgpr 88")
+    assert len(build.audit_accumulator_registers(short)[1]) == 1

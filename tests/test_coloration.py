@@ -97,7 +97,7 @@ def test_mesh_coloration_from_lists_reports_missing_files(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_color_context_resident_views_chunks_and_batches(monkeypatch):
+def test_gpu_color_context_resident_views_chunks_and_batches():
     """dmi_color_context: views added in two batches stay resident, several vertex sets are coloured against them,
     and a small scratch budget forces the chunked path -- all bit-identical to the oracle."""
     K4, RT4, colors = _views(9, 80, 60, seed=31)
@@ -112,11 +112,11 @@ def test_gpu_color_context_resident_views_chunks_and_batches(monkeypatch):
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
         assert c.kernel_ms() > 0
-        monkeypatch.setenv("DMI_COLOR_SCRATCH_BYTES", str(9 * 4 * 1024))   # 1024 vertices per chunk -> 7 chunks
+        c.set_scratch_budget(9 * 4 * 1024)           # 1024 vertices per chunk -> 7 chunks
         got = c.process(pts)
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
-        monkeypatch.delenv("DMI_COLOR_SCRATCH_BYTES")
+        c.set_scratch_budget(1 << 30)
         sub = c.process(pts[100:1100])               # another vertex set, same resident views
         for g, w in zip(sub, want):
             assert np.array_equal(g, w[100:1100])

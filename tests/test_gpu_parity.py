@@ -304,7 +304,7 @@ def test_z_slab_contexts_are_bit_identical_to_one_fusion(variant):
     world = 3
     parts, hits = [], []
     for r in range(world):
-        z0, z1 = sharding.z_slab(37, r, world, multiple=16)
+        z0, z1 = sharding.z_slab(37, r, world)
         if z1 == z0:
             continue
         slab = scene.GridDesc((40, 24, z1 - z0), grid.origin, grid.spacing, grid.grid_matrix)
@@ -415,48 +415,67 @@ def test_slab_fuses_equal_one_fuse(variant):
             ctx.fuse_slab(96, 32)       # beyond the grid
 
 
-def test_overlapped_fuse_and_all_reduce_single_rank(tmp_path):
-    """sharding.fuse_and_all_reduce with a one-rank RCCL group on this GPU: streams, events and the slab API work
-    together and the result equals a plain fuse (the N > 1 arithmetic is covered by tests/test_sharding.py)."""
-    import os
-    import socket
-    import torch
-    import torch.distributed as dist
-    from cudadepthmapintegration_amd import sharding
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        grid = scene.default_grid((48, 40, 96))
-        rp = scene.default_ray_potential(grid)
-        views = scene.make_views(4, 80, 60, seed=23, dense=True, dtype=np.float32)
-        torch.cuda.set_device(0)
-        grid_t = torch.zeros(grid.n_voxels, dtype=torch.float32, device="cuda")
-        fuse_stream, comm_stream = torch.cuda.Stream(), torch.cuda.Stream()
-        torch.cuda.synchronize()
-        with capi.FusionContext(grid, rp, grid_dtype="f32", stream=fuse_stream.cuda_stream,
-                                external_grid=grid_t.data_ptr()) as ctx:
-            ctx.add_views(views)
-            for _ in range(2):
-                ctx.reset_grid()
-                sharding.fuse_and_all_reduce(ctx, grid_t, grid.cell_dims, 3, fuse_stream, comm_stream)
-            torch.cuda.synchronize()
-            got = grid_t.cpu().numpy().copy()
-            ctx.reset_grid()
-            ctx.fuse()
-            ctx.synchronize()
-            torch.cuda.synchronize()
-            plain = grid_t.cpu().numpy()
-        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)) and np.abs(plain).max() > 0
-        # the cheaper exchange (every rank keeps its own 1/N): with one rank the slice is the whole grid
-        part, first, count = sharding.reduce_scatter_grid(grid_t, 0, 1)
-        torch.cuda.synchronize()
-        assert first == 0 and count == grid.n_voxels and torch.equal(part, grid_t)
-    finally:
-        dist.destroy_process_group()
+@pytest.mark.parametrize("mode", ["one_process", "rank"])
+@pytest.mark.parametrize("exchange", ["all_reduce", "reduce_scatter"])
+def test_multi_context_with_one_rank_equals_plain_fuse(mode, exchange):
+    """dmi_multi_* (the multi-GPU step behind the C ABI) on this one GPU, world = 1, both ways of joining (all ranks
+    in this process: ncclCommInitAll; one rank per process: unique id + ncclCommInitRank): RCCL is loaded, the
+    communicator reports one rank, the fusion runs slab by slab with the all-reduce of each slab on the second stream,
+    and the grid is bit-identical to a plain dmi_fuse.  N > 1 arithmetic: tests/test_sharding.py."""
+    grid = scene.default_grid((48, 40, 96))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(5, 80, 60, seed=23, dense=True, dtype=np.float32)
+    with capi.FusionContext(grid, rp, grid_dtype="f32") as ctx:
+        ctx.add_views(views)
+        ctx.fuse()
+        plain = ctx.download_grid(np.float32).copy()
+    kw = dict(devices=[0]) if mode == "one_process" else dict(rank=0, world=1, unique_id=capi.multi_unique_id(), device=0)
+    with capi.MultiContext(grid, rp, grid_dtype="f32", exchange=exchange, n_slabs=3, **kw) as m:
+        with pytest.raises(capi.DmiError):
+            m.fuse()                                   # no views yet
+        m.add_views(views.subset(0, 3))
+        m.add_views(views.subset(3, 5))
+        for _ in range(2):                             # a second step starts from zeros again (filt.cxx:133)
+            m.fuse()
+        got, (first, count) = m.download_grid(np.float32)
+        info = m.info()
+        t = m.timings()
+        assert (info.world, info.n_local, info.rccl_ranks, info.n_views_total, info.n_views_local) == (1, 1, 1, 5, 5)
+        assert info.rccl_version > 0 and info.n_slabs == (3 if exchange == "all_reduce" else 3)
+        assert (first, count) == (0, grid.n_voxels)
+        assert t.steps == 2 and t.last_step_ms > 0 and 0 < t.last_fuse_kernel_ms <= t.last_step_ms * 1.05
+        got64, _ = m.download_grid(np.float64)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)) and np.abs(plain).max() > 0
+    assert np.array_equal(got64, plain.astype(np.float64))
+
+
+def test_multi_context_z_slab_partition_is_bit_identical():
+    """DMI_PARTITION_Z_SLABS with one rank: no communicator at all, f64 grid bit-identical to the oracle."""
+    grid = scene.default_grid((40, 24, 37))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(6, 80, 60, seed=13, dense=True)
+    want, _, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                             n_threads=oracle.max_threads())
+    with capi.MultiContext(grid, rp, devices=[0], grid_dtype="f64", partition="z_slabs") as m:
+        m.add_views(views)
+        m.fuse()
+        got, (first, count) = m.download_grid(np.float64)
+        assert m.info().rccl_ranks == 0 and (first, count) == (0, grid.n_voxels)
+    assert bits_equal(got, want)
+
+
+def test_multi_context_rejects_bad_arguments():
+    grid = scene.default_grid((16, 16, 16))
+    rp = scene.default_ray_potential(grid)
+    with pytest.raises(capi.DmiError):
+        capi.MultiContext(grid, rp, devices=[0, 0])                      # a device twice
+    with pytest.raises(capi.DmiError):
+        capi.MultiContext(grid, rp, devices=[capi.device_count()])       # no such device
+    with pytest.raises(capi.DmiError):
+        capi.MultiContext(grid, rp, rank=1, world=1, unique_id=bytes(128))  # rank outside the world
+    with pytest.raises(capi.DmiError):
+        capi.MultiContext(scene.default_grid((3, 3, 3)), rp, rank=0, world=2, unique_id=bytes(128),
+                          exchange="reduce_scatter")                     # 27 voxels do not split over 2 ranks
 
 
 def test_diagnostics_and_layer_tracking():

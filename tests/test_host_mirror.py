@@ -62,6 +62,33 @@ def test_extract_all_file_path(tmp_path):
     assert capi.extract_all_file_path(str(tmp_path / "nope.txt")) == []
 
 
+def test_extract_all_file_path_line_endings_and_blanks(tmp_path):
+    """Lists written on Windows (CRLF), entries followed by blanks, blank-only lines, no final newline: the entry is
+    still the last blank-separated token.  (The reference keeps the CR in the name and turns a blank-only line into the
+    directory itself -- both would only make it fail to open a file; here they read as intended.)"""
+    lst = tmp_path / "list.txt"
+    lst.write_bytes(b"0 a.vti\r\n1 b.vti   \r\n   \r\n\r\n2  c d.vti \n3 last.vti")
+    got = capi.extract_all_file_path(str(lst))
+    assert got == [f"{tmp_path}/a.vti", f"{tmp_path}/b.vti", f"{tmp_path}/d.vti", f"{tmp_path}/last.vti"]
+    empty = tmp_path / "empty.txt"
+    empty.write_text("")
+    assert capi.extract_all_file_path(str(empty)) == []
+
+
+def test_read_krtd_file_tolerates_crlf_and_short_files(tmp_path):
+    """CRLF files read the same; missing numbers and missing lines read as zeros (a failed operator>> in the
+    reference, Helper.h:124-128), the last row of RT is always 0 0 0 1."""
+    p = tmp_path / "crlf.krtd"
+    p.write_bytes(KRTD.replace("\n", "\r\n").encode())
+    ok, K, RT = capi.read_krtd_file(str(p))
+    assert ok and K[0, 1] == 0.5 and RT[2, 3] == 3.125 and np.array_equal(RT[3], [0, 0, 0, 1])
+    q = tmp_path / "short.krtd"
+    q.write_text("1 2\n3\n")
+    ok, K, RT = capi.read_krtd_file(str(q))
+    assert ok and np.array_equal(K, [[1, 2, 0], [3, 0, 0], [0, 0, 0]])
+    assert np.array_equal(RT, [[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1]])
+
+
 def test_k3_to_k4_matches_oracle():
     """RD.cxx:192-212."""
     K3 = np.array([[1152.0, 0.25, 640.5], [0, 1150.0, 360.25], [0, 0, 1]])

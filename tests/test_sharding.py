@@ -1,8 +1,9 @@
 """Multi-process CPU tests (gloo, world_size 2) of the N > 1 path: view shards + one all-reduce of the f32
-grid, and z-slab ownership.  The per-rank fusion is done by the oracle here (there is no GPU in this
-container; the oracle is the checker's arithmetic), so what is under test is the partition arithmetic,
-the collective and the stated tolerance; tests/test_gpu_parity.py runs the same partitions through the
-HIP path on one GPU."""
+grid, and z-slab ownership.  The partition arithmetic is the library's own (dmi_multi_view_shard / dmi_multi_z_slab /
+dmi_multi_slab_ranges through cudadepthmapintegration_amd.sharding: host code, no GPU needed); the per-rank fusion
+is done by the oracle here (there is no GPU in this container; the oracle is the checker's arithmetic) and gloo
+stands in for the RCCL all-reduce that dmi_multi_fuse issues, so what is under test is the partition, the shape of
+the exchange and the stated tolerance; tests/test_gpu_parity.py drives dmi_multi_* itself on one GPU."""
 import os
 import socket
 import sys
@@ -26,13 +27,13 @@ def test_view_shard_is_a_balanced_partition():
 
 
 def test_z_slab_respects_column_height():
-    for nz in (1, 17, 512, 1000):
+    for nz in (1, 17, 512, 1000, 1024):
         for world in (1, 2, 8):
-            for mult in (1, 16, 32):
-                r = [sharding.z_slab(nz, k, world, mult) for k in range(world)]
-                assert r[0][0] == 0 and r[-1][1] == nz
-                assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
-                assert all(lo % mult == 0 for lo, hi in r if lo < nz)
+            r = [sharding.z_slab(nz, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == nz
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert all(lo % 16 == 0 for lo, hi in r if lo < nz)
+    assert [sharding.z_slab(512, k, 8) for k in range(8)] == [(64 * k, 64 * k + 64) for k in range(8)]
 
 
 def test_slab_ranges_cover_the_grid_on_aligned_boundaries():
@@ -42,6 +43,14 @@ def test_slab_ranges_cover_the_grid_on_aligned_boundaries():
             assert r[0][0] == 0 and r[-1][0] + r[-1][1] == nz and len(r) <= n
             assert all(a[0] + a[1] == b[0] for a, b in zip(r, r[1:]))
             assert all(z0 % 32 == 0 for z0, _ in r)
+    # the last slab is the thin one: its all-reduce is what no fusion hides
+    assert sharding.slab_ranges(512, 4) == [(0, 160), (160, 160), (320, 128), (448, 64)]
+
+
+def test_partition_functions_reject_bad_ranks():
+    for fn in (lambda: sharding.view_shard(10, 2, 2), lambda: sharding.view_shard(10, -1, 2), lambda: sharding.z_slab(10, 0, 0)):
+        with pytest.raises(ValueError):
+            fn()
 
 
 def _free_port():
@@ -64,7 +73,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    grid = scene.default_grid((28, 24, 20))
+    grid = scene.default_grid((28, 24, 72))
     rp = scene.default_ray_potential(grid)
     views = scene.make_views(9, 64, 48, seed=5, dense=True)   # 9 views over 2 ranks: 5 + 4
     p = oracle_params_from_scene(grid, rp, views)
@@ -73,11 +82,15 @@ def _worker(rank, world, port, out_dir):
     g32 = torch.from_numpy(part.astype(np.float32))            # each rank's grid is f32 on the device
     absum = torch.from_numpy(np.abs(part))
     hits = torch.from_numpy(vh.astype(np.int64))
-    sharding.all_reduce_grid(g32)                               # the path's single exchange step
-    sharding.all_reduce_grid(absum)
-    sharding.all_reduce_grid(hits)
+    # the path's single exchange step: a sum all-reduce of the f32 grid (RCCL inside dmi_multi_fuse on GPUs, gloo here),
+    # slab by slab exactly as the library cuts it
+    plane = grid.cell_dims[0] * grid.cell_dims[1]
+    for z0, zc in sharding.slab_ranges(grid.cell_dims[2], 2):
+        dist.all_reduce(g32.view(-1)[z0 * plane:(z0 + zc) * plane], op=dist.ReduceOp.SUM)
+    dist.all_reduce(absum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(hits, op=dist.ReduceOp.SUM)
     # z-slab ownership: every rank fuses all views into its own layers
-    z0, z1 = sharding.z_slab(grid.cell_dims[2], rank, world, multiple=8)
+    z0, z1 = sharding.z_slab(grid.cell_dims[2], rank, world)
     if rank == 0:
         np.savez(os.path.join(out_dir, "reduced.npz"), grid=g32.numpy(), absum=absum.numpy(), hits=hits.numpy())
     np.save(os.path.join(out_dir, f"slab_{rank}.npy"), np.array([z0, z1]))
@@ -94,7 +107,7 @@ def test_view_shards_plus_all_reduce_match_single_fusion(tmp_path):
 
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    grid = scene.default_grid((28, 24, 20))
+    grid = scene.default_grid((28, 24, 72))
     rp = scene.default_ray_potential(grid)
     views = scene.make_views(9, 64, 48, seed=5, dense=True)
     want, vh, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4)
@@ -104,7 +117,7 @@ def test_view_shards_plus_all_reduce_match_single_fusion(tmp_path):
     assert np.all(np.abs(got["grid"].astype(np.float64) - want) <= tol)    # stated float tolerance
     assert np.abs(want).max() > 0.1
     slabs = [tuple(np.load(tmp_path / f"slab_{r}.npy")) for r in range(world)]
-    assert slabs[0][0] == 0 and slabs[-1][1] == 20 and slabs[0][1] == slabs[1][0] and slabs[0][1] % 8 == 0
+    assert slabs[0][0] == 0 and slabs[-1][1] == 72 and slabs[0][1] == slabs[1][0] and slabs[0][1] % 16 == 0
 
 
 def _color_worker(rank, world, port, out_dir):

@@ -58,3 +58,55 @@ def test_vti_reader_survives_mutated_files(harness, tmp_path):
     # the unmutated files all parse
     r = subprocess.run([harness] + files[::61][:len(MODES)], capture_output=True, text=True, env=env, timeout=60)
     assert r.returncode == 0 and f"parsed {len(MODES)} rejected 0" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_vti_reader_rejects_extents_its_payload_cannot_fill(harness, tmp_path):
+    """A few hundred bytes that claim 4e9 points x 1024 components: every data mode must refuse BEFORE allocating (under
+    ASan a terabyte allocation aborts the harness), and must not throw through the C ABI."""
+    huge = "0 1999999 0 1999 0 0"                      # 2e6 x 2e3 points, inside the per-axis and total limits
+    head = ('<?xml version="1.0"?>\n<VTKFile type="ImageData" version="1.0" byte_order="LittleEndian" header_type="UInt64"{comp}>\n'
+            f'  <ImageData WholeExtent="{huge}" Origin="0 0 0" Spacing="1 1 1">\n    <Piece Extent="{huge}">\n      <PointData>\n')
+    tail = "      </PointData>\n    </Piece>\n  </ImageData>\n{app}</VTKFile>\n"
+    import base64
+    import struct
+    import zlib
+    n_bytes = 2000000 * 2000 * 1024 * 8
+    blob = zlib.compress(b"\0" * 64)
+    comp_head = struct.pack("<QQQQ", 1, n_bytes, 0, len(blob))
+    cases = {
+        "ascii": head.format(comp="") + '<DataArray type="Float64" Name="Depths" NumberOfComponents="1024" format="ascii">1 2 3</DataArray>\n'
+                 + tail.format(app=""),
+        "binary": head.format(comp="") + '<DataArray type="Float64" Name="Depths" NumberOfComponents="1024" format="binary">'
+                  + base64.b64encode(struct.pack("<Q", n_bytes) + b"\0" * 30).decode() + "</DataArray>\n" + tail.format(app=""),
+        "binary_zlib": head.format(comp=' compressor="vtkZLibDataCompressor"')
+                       + '<DataArray type="Float64" Name="Depths" NumberOfComponents="1024" format="binary">'
+                       + base64.b64encode(comp_head).decode() + base64.b64encode(blob).decode() + "</DataArray>\n" + tail.format(app=""),
+        "appended_zlib": head.format(comp=' compressor="vtkZLibDataCompressor"')
+                         + '<DataArray type="Float64" Name="Depths" NumberOfComponents="1024" format="appended" offset="0"/>\n'
+                         + tail.format(app='  <AppendedData encoding="base64">_' + base64.b64encode(comp_head).decode()
+                                       + base64.b64encode(blob).decode() + "</AppendedData>\n"),
+    }
+    files = []
+    for name, text in cases.items():
+        p = tmp_path / f"huge_{name}.vti"
+        p.write_text(text)
+        files.append(str(p))
+    raw = tmp_path / "huge_raw.vti"
+    raw.write_bytes((head.format(comp="") + '<DataArray type="Float64" Name="Depths" NumberOfComponents="1024" format="appended" offset="0"/>\n'
+                     + "      </PointData>\n    </Piece>\n  </ImageData>\n  <AppendedData encoding=\"raw\">_").encode()
+                    + struct.pack("<Q", n_bytes) + b"\0" * 40 + b"</AppendedData>\n</VTKFile>\n")
+    files.append(str(raw))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([harness] + files, capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and f"parsed 0 rejected {len(files)}" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_huge_extent_is_an_error_through_the_c_abi(tmp_path):
+    """The same through dmi_read_depth_map (ctypes): an error return, not a C++ exception that ends the process."""
+    from cudadepthmapintegration_amd import capi
+    p = tmp_path / "huge.vti"
+    p.write_text('<?xml version="1.0"?>\n<VTKFile type="ImageData" version="0.1" byte_order="LittleEndian">\n'
+                 '  <ImageData WholeExtent="0 1999999 0 1999 0 0">\n    <Piece Extent="0 1999999 0 1999 0 0">\n      <PointData>\n'
+                 '<DataArray type="Float64" Name="Depths" format="binary">AAAAAAAAAAA=</DataArray>\n'
+                 '      </PointData>\n    </Piece>\n  </ImageData>\n</VTKFile>\n')
+    assert capi.read_depth_map(str(p)) is None
