@@ -414,7 +414,7 @@ bool FusionDriver::Run(size_t n_views, const void *fill_ptr, double thresholdBes
   // and parsing the .vti / .krtd files when the views come from list files, as the reference does one view at a time
   // inside its loop (cu:343-353).  Host residency is two chunks whatever the number of views; every voxel still
   // accumulates its views in order (cu:211), and the f64 grid makes the chunking invisible in the result.
-  const size_t chunk = std::max<size_t>(1, std::min(n_views, (size_t(256) << 20) / std::max<size_t>(1, npix * 16)));
+  const size_t chunk = std::max<size_t>(1, std::min(n_views, HostChunkBytes / std::max<size_t>(1, npix * 16)));
   Feed feed;
   bool ok = true;
   for (Chunk &c : feed.slot) {
@@ -699,6 +699,7 @@ int ReconstructionFilter::Compute(int gridDims[3], double gridOrig[3], double gr
   driver.SetDevices(Devices);
   driver.SetPartition(Partition);
   driver.SetKernelVariant(KernelVariant);
+  driver.SetHostChunkBytes(HostChunkBytes);
   driver.SetInitialGridIsZero(true);  // RequestData zero-filled outScalar just before (filt.cxx:133)
   bool result;
   if (!Views.empty()) {

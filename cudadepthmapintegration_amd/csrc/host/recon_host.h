@@ -118,6 +118,9 @@ class FusionDriver {
   void SetDevices(const std::vector<int> &devices) { Devices = devices; }
   void SetPartition(int partition) { Partition = partition; }
   void SetKernelVariant(int v) { KernelVariant = v; }
+  // pinned host memory of ONE staging chunk (depth + best cost of as many views as fit, at least one); two chunks exist.
+  // Default 256 MiB.
+  void SetHostChunkBytes(size_t bytes) { HostChunkBytes = bytes < 1 ? 1 : bytes; }
   // the next ProcessDepthMap's io_scalar is known to hold +0.0 everywhere: skips the scan and the upload (cu:323-327)
   void SetInitialGridIsZero(bool yes) { InitialGridIsZero = yes; }
   const std::string &LastError() const { return Error; }
@@ -137,6 +140,7 @@ class FusionDriver {
   std::vector<int> Devices;
   int Partition = DMI_PARTITION_VIEWS;
   int KernelVariant = 0;
+  size_t HostChunkBytes = size_t(256) << 20;
   double FuseKernelMs = 0.0;
   std::string Error;
 };
@@ -181,6 +185,7 @@ class ReconstructionFilter {
   // new, optional, default = the reference's single GPU: see FusionDriver::SetDevices / SetPartition
   void SetDevices(const std::vector<int> &devices) { Devices = devices; }
   void SetPartition(int partition) { Partition = partition; }
+  void SetHostChunkBytes(size_t bytes) { HostChunkBytes = bytes < 1 ? 1 : bytes; }  // FusionDriver::SetHostChunkBytes
   void SetKernelVariant(int v) { KernelVariant = v; }
   double GetFuseKernelMs() const { return FuseKernelMs; }
 
@@ -205,6 +210,7 @@ class ReconstructionFilter {
   int Device = 0, KernelVariant = 0;
   std::vector<int> Devices;
   int Partition = DMI_PARTITION_VIEWS;
+  size_t HostChunkBytes = size_t(256) << 20;
   double FuseKernelMs = 0.0;
 };
 

@@ -43,6 +43,10 @@ void dmi_filter_set_kernel_variant(dmi_filter *f, int32_t variant);
  * f32 grid; the default) or DMI_PARTITION_Z_SLABS (no exchange, f64, bit-identical to one GPU). */
 void dmi_filter_set_devices(dmi_filter *f, const int32_t *devices, int32_t n);
 void dmi_filter_set_partition(dmi_filter *f, int32_t partition);
+/* Pinned host memory of one staging chunk of views (two exist; default 256 MiB): bounds the filter's host memory
+ * whatever the number of views -- the list files are read chunk by chunk, as the reference reads them view by view
+ * inside its loop (cu:343-353). */
+void dmi_filter_set_host_chunk_bytes(dmi_filter *f, uint64_t bytes);
 /* Update() -> RequestData (filt.cxx:96-151): 1 on success, 0 on error */
 int dmi_filter_update(dmi_filter *f);
 double dmi_filter_get_execution_time(const dmi_filter *f);            /* filt.h:81 */

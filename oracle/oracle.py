@@ -106,7 +106,28 @@ def make_params(cell_dims, origin, spacing, grid_matrix, thick, rho, eta, delta,
 
 
 def max_threads() -> int:
-    return int(lib().oracle_max_threads())
+    """Threads worth using: OpenMP's maximum, capped by this process's CPU affinity and by the cgroup's CPU quota (a GPU
+    box hands a job a share of the host's cores; oversubscribing that share only adds context switches)."""
+    n = int(lib().oracle_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if text[0] != "max":
+                    n = min(n, max(1, -(-int(text[0]) // int(text[1]))))
+            else:
+                quota = int(text[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, -(-quota // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def fuse(params: _Params, depths, K4, RT4, init_grid=None, count_hits=True, n_threads=1):

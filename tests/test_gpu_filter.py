@@ -94,3 +94,118 @@ def test_filter_rejects_mismatching_view_sizes():
         f.AddView(a.depth[0], a.K4[0][:3, :3], a.RT4[0])
         f.AddView(b.depth[0], b.K4[0][:3, :3], b.RT4[0])
         assert f.Update() == 0 and "size" in f.LastError()
+
+
+@pytest.mark.parametrize("partition", ["views", "z_slabs"])
+def test_filter_on_a_device_list_runs_through_the_multi_gpu_path(partition, tmp_path):
+    """SetDevices([0]): the filter drives dmi_multi_* (world = 1 on this box).  z-slabs keep the reference's f64 grid
+    and are bit-identical to the oracle; depth-map shards use the north star's f32 grid: exactly one f32 rounding of
+    the f64 sums here (one rank), the stated 2*G*2^-24*sum|partials| tolerance in general."""
+    grid = scene.default_grid((40, 33, 70))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(5, 96, 72, seed=21, dense=True, with_best_cost=True)
+    lv, lk = scene.write_view_files(str(tmp_path), views)
+    thr = 0.8
+    want = _oracle(grid, rp, views, thr)
+    with capi.ReconstructionFilter() as f:
+        _configure(f, grid, rp, thr)
+        f.SetFilePathVTI(lv)
+        f.SetFilePathKRTD(lk)
+        f.SetDevices([0])
+        f.SetPartition(partition)
+        assert f.Update() == 1, f.LastError()
+        out = f.GetOutputScalars()
+        assert f.GetFuseKernelMs() > 0
+    if partition == "z_slabs":
+        assert bits_equal(out, want)
+    else:
+        assert np.array_equal(out, want.astype(np.float32).astype(np.float64))
+
+
+def test_filter_streams_list_files_with_bounded_host_memory(tmp_path):
+    """The views are read inside the chunk loop (as the reference reads them inside its loop, cu:343-353), two pinned
+    chunks at a time: with 64 MiB chunks (13 VGA views each) the peak host memory of an 80-view list-file run grows by
+    less than three chunks (two pinned chunks + the one view being read and parsed), although the views together are
+    more than six; the grid is bit-identical to the oracle's
+    fusion of the same views."""
+    import json
+    import subprocess
+    import sys
+    from vti_writer import write_vti
+    W, H, n = 640, 480, 80
+    grid = scene.default_grid((64, 64, 64))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(n, W, H, seed=31, dense=True)
+    cost = np.random.default_rng(32).random((n, H, W))
+    lv, lk = str(tmp_path / "vtiList.txt"), str(tmp_path / "krtdList.txt")
+    with open(lv, "w") as fv, open(lk, "w") as fk:
+        for m in range(n):
+            write_vti(str(tmp_path / f"v{m:03d}.vti"), {"Depths": views.depth[m], "Best Cost Values": cost[m]}, W, H,
+                      mode="appended-raw")
+            scene.write_krtd(str(tmp_path / f"v{m:03d}.krtd"), views.K4[m][:3, :3], views.RT4[m])
+            fv.write(f"{m} v{m:03d}.vti\n")
+            fk.write(f"{m} v{m:03d}.krtd\n")
+    thr = 0.9
+    child = r'''
+import json, sys, threading, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from cudadepthmapintegration_amd import capi, scene
+grid = scene.default_grid((64, 64, 64)); rp = scene.default_ray_potential(grid)
+def status_kib(key):
+    return int(open("/proc/self/status").read().split(key + ":")[1].split()[0])
+samples = []
+stop = threading.Event()
+def sample():
+    while not stop.is_set():
+        samples.append(status_kib("VmRSS"))
+        time.sleep(0.002)
+with capi.ReconstructionFilter() as f:
+    f.SetRayPotentialThickness(rp.thickness); f.SetRayPotentialRho(rp.rho); f.SetRayPotentialEta(rp.eta)
+    f.SetRayPotentialDelta(rp.delta); f.SetThresholdBestCost(float(sys.argv[4])); f.SetGridMatrix(grid.grid_matrix)
+    f.SetInputData([65, 65, 65], grid.origin, grid.spacing)
+    # a tiny fusion first: HIP runtime, code objects, queues and allocator pools are resident before the baseline
+    tiny = scene.make_views(2, 16, 12, seed=1, dense=True, with_best_cost=True)
+    with capi.ReconstructionFilter() as w:
+        w.SetRayPotentialThickness(rp.thickness); w.SetRayPotentialRho(rp.rho); w.SetRayPotentialEta(rp.eta)
+        w.SetRayPotentialDelta(rp.delta); w.SetThresholdBestCost(0.5); w.SetGridMatrix(grid.grid_matrix)
+        w.SetInputData([65, 65, 65], grid.origin, grid.spacing)
+        w.SetFilePathVTI("in memory"); w.SetFilePathKRTD("in memory")
+        for m in range(2):
+            w.AddView(tiny.depth[m], tiny.K4[m][:3, :3], tiny.RT4[m], tiny.best_cost[m])
+        assert w.Update() == 1, w.LastError()
+    base = status_kib("VmRSS")
+    try:                                   # restart the kernel's high-water mark here (it includes start-up otherwise)
+        open("/proc/self/clear_refs", "w").write("5")
+        hwm_reset = True
+    except OSError:
+        hwm_reset = False
+    f.SetFilePathVTI(sys.argv[2]); f.SetFilePathKRTD(sys.argv[3])
+    f.SetHostChunkBytes(64 << 20)
+    t = threading.Thread(target=sample); t.start()
+    ok = f.Update()
+    stop.set(); t.join()
+    peak = max(samples + [status_kib("VmRSS")])
+    if hwm_reset:
+        peak = max(peak, status_kib("VmHWM"))
+    out = f.GetOutputScalars()
+    np.save(sys.argv[5], out)
+    print(json.dumps({"ok": ok, "base_kib": base, "peak_kib": peak, "err": f.LastError()}))
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", child, root, lv, lk, str(thr), str(tmp_path / "out.npy")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["ok"] == 1, rec["err"]
+    npix = W * H
+    chunk_views = max(1, min(n, (64 << 20) // (npix * 16)))
+    chunk_bytes = chunk_views * npix * 16                          # depth + best cost of one chunk
+    all_views_bytes = n * npix * 16
+    grew = (rec["peak_kib"] - rec["base_kib"]) * 1024
+    assert all_views_bytes > 5 * chunk_bytes
+    assert grew <= 3 * chunk_bytes, (grew, chunk_bytes)
+    got = np.load(tmp_path / "out.npy")
+    views.best_cost = cost
+    assert bits_equal(got, _oracle(grid, rp, views, thr))

@@ -105,3 +105,60 @@ def test_1024cubed_grid_indexing():
                                  views.RT4, ids, n_threads=oracle.max_threads())
     assert np.array_equal(out["tiled"].reshape(-1)[ids], want.astype(np.float32))
     assert np.abs(want).max() > 0.5
+
+
+def _tiled_general_and_oracle_sample(grid, rp, views, n_sample, seed):
+    """tiled == general over the whole f32 grid, and n_sample oracle spot voxels (exactly the f32 rounding of the f64 sum)."""
+    out = {}
+    for name, variant in (("tiled", 0), ("general", G)):
+        with capi.FusionContext(grid, rp, grid_dtype="f32", kernel_variant=variant) as ctx:
+            ctx.add_views(views)
+            assert ctx.info().tiled_kernel == (1 if name == "tiled" else 0)
+            ctx.fuse()
+            out[name] = ctx.download_grid(np.float32)
+    assert np.array_equal(out["tiled"].view(np.uint32), out["general"].view(np.uint32))
+    ids = _sample_ids(grid, n_sample, seed)
+    want, _ = oracle.fuse_voxels(oracle_params_from_scene(grid, rp, views), views.depth.astype(np.float64), views.K4,
+                                 views.RT4, ids, n_threads=oracle.max_threads())
+    assert np.array_equal(out["tiled"].reshape(-1)[ids], want.astype(np.float32))
+    return want
+
+
+def test_cfg4_share_512cubed_128_maps_vga():
+    """BASELINE configs[3], one GPU's share of the 8-way split: 512^3 x 128 of the 1024 views of 640x480 (the views
+    rank 0 takes, dmi_multi_view_shard) -- the very views bench.py's strong-scaling run of cfg4 gives that rank."""
+    grid = scene.default_grid(512)
+    rp = scene.default_ray_potential(grid)
+    lo, hi = capi.multi_view_shard(1024, 0, 8)
+    assert (lo, hi) == (0, 128)
+    views = scene.make_views(1024, 640, 480, seed=1004, dense=True, layout="sphere", dtype=np.float32, view_range=(lo, hi))
+    want = _tiled_general_and_oracle_sample(grid, rp, views, 4096, 4)
+    assert np.abs(want).max() > 1.0
+
+
+def test_cfg5_share_1024cubed_64_maps_1080p():
+    """BASELINE configs[4], one GPU's share: 1024^3 voxels x 64 of the 512 views of 1920x1080."""
+    grid = scene.default_grid(1024)
+    rp = scene.default_ray_potential(grid)
+    lo, hi = capi.multi_view_shard(512, 3, 8)
+    views = scene.make_views(512, 1920, 1080, seed=1005, dense=True, layout="sphere", dtype=np.float32, view_range=(lo, hi))
+    want = _tiled_general_and_oracle_sample(grid, rp, views, 4096, 5)
+    assert np.abs(want).max() > 0.5
+
+
+def test_grid_transfers_convert_on_the_device():
+    """dmi_upload_grid into an f32 grid and dmi_download_grid_* of the other type convert on the device, chunk by chunk
+    (32 Mi elements per chunk: 320^3 needs two chunks); values are exactly the host casts they replace."""
+    grid = scene.default_grid((320, 320, 330))
+    rp = scene.default_ray_potential(grid)
+    rng = np.random.default_rng(8)
+    init = rng.standard_normal(grid.n_voxels) * 3.0
+    with capi.FusionContext(grid, rp, grid_dtype="f32") as ctx:
+        ctx.upload_grid(init)
+        as32 = ctx.download_grid(np.float32).reshape(-1)
+        as64 = ctx.download_grid(np.float64).reshape(-1)
+    assert np.array_equal(as32, init.astype(np.float32)) and np.array_equal(as64, init.astype(np.float32).astype(np.float64))
+    with capi.FusionContext(grid, rp, grid_dtype="f64") as ctx:
+        ctx.upload_grid(init)
+        assert np.array_equal(ctx.download_grid(np.float32).reshape(-1), init.astype(np.float32))
+        assert np.array_equal(ctx.download_grid(np.float64).reshape(-1), init)

@@ -431,8 +431,13 @@ def test_multi_context_with_one_rank_equals_plain_fuse(mode, exchange):
         plain = ctx.download_grid(np.float32).copy()
     kw = dict(devices=[0]) if mode == "one_process" else dict(rank=0, world=1, unique_id=capi.multi_unique_id(), device=0)
     with capi.MultiContext(grid, rp, grid_dtype="f32", exchange=exchange, n_slabs=3, **kw) as m:
-        with pytest.raises(capi.DmiError):
-            m.fuse()                                   # no views yet
+        if mode == "one_process":
+            with pytest.raises(capi.DmiError):
+                m.fuse()                               # no views anywhere: an error
+        else:
+            m.fuse()                                   # a rank of several may hold no view: it contributes zeros
+            zeros, _ = m.download_grid(np.float32)
+            assert not zeros.any()
         m.add_views(views.subset(0, 3))
         m.add_views(views.subset(3, 5))
         for _ in range(2):                             # a second step starts from zeros again (filt.cxx:133)
@@ -443,7 +448,7 @@ def test_multi_context_with_one_rank_equals_plain_fuse(mode, exchange):
         assert (info.world, info.n_local, info.rccl_ranks, info.n_views_total, info.n_views_local) == (1, 1, 1, 5, 5)
         assert info.rccl_version > 0 and info.n_slabs == (3 if exchange == "all_reduce" else 3)
         assert (first, count) == (0, grid.n_voxels)
-        assert t.steps == 2 and t.last_step_ms > 0 and 0 < t.last_fuse_kernel_ms <= t.last_step_ms * 1.05
+        assert t.steps >= 2 and t.last_step_ms > 0 and 0 < t.last_fuse_kernel_ms <= t.last_step_ms * 1.05
         got64, _ = m.download_grid(np.float64)
     assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)) and np.abs(plain).max() > 0
     assert np.array_equal(got64, plain.astype(np.float64))
