@@ -32,6 +32,11 @@ COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-ma
 HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector"]
 # DMI_TUNING=1 in the environment of the BUILD compiles the experiment switches of tools/ in (getenv-driven launch
 # geometry, dropped depth loads ...).  The default library contains none of them.
+if os.environ.get("DMI_EXP"):  # tools/gpu_exp.sh: "NAME:-DDMI_EXP_X=0 ..." -> build/obj_exp_NAME, libdmi_hip_exp_NAME.so
+    _name, _, _defs = os.environ["DMI_EXP"].partition(":")
+    COMMON_FLAGS = COMMON_FLAGS + _defs.split()
+    OBJ_DIR = os.path.join(ROOT, "build", "obj_exp_" + _name)
+    LIB_PATH = os.path.join(CSRC, "libdmi_hip_exp_" + _name + ".so")
 if os.environ.get("DMI_TUNING"):  # a separate library and object directory: never mistaken for the shipped one
     COMMON_FLAGS = COMMON_FLAGS + ["-DDMI_TUNING"]
     OBJ_DIR = os.path.join(ROOT, "build", "obj_tuning")
@@ -64,7 +69,15 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# A prebuilt library to load instead (A/B timing against an older build in the same GPU call): never rebuilt
+LIB_OVERRIDE = os.environ.get("DMI_LIB_OVERRIDE")
+if LIB_OVERRIDE:
+    LIB_PATH = os.path.abspath(LIB_OVERRIDE)
+
+
 def needs_build() -> bool:
+    if LIB_OVERRIDE:
+        return False
     deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
     return _stale(LIB_PATH, deps)
 

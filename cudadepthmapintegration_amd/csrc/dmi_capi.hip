@@ -362,6 +362,9 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   // rotated grid: the computed c.z (9 + 6 rounded operations on terms bounded by M[2]) is within 8 ulp(M[2]) of the
   // real, exactly affine one; four times that as the margin of the brick classification
   t.cz_err = aligned ? 0.0 : M[2] * 0x1p-47;
+  // the kernel accepts a pixel iff |frac| + errk * r < 1/2 with r = (1 +- 2^-39) / c.z: errk * r covers err / c.z plus the
+  // 2^-22 of DESIGN.md 4.4 because M[2] bounds |c.z| everywhere in the grid (M[2] * r >= 1 - 2^-39)
+  t.errk = t.err + 0x1p-22 * M[2] * (1.0 + 0x1p-20);
   t.depth = r.depth;
   return t;
 }
@@ -891,6 +894,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
     t.grid = a.grid; t.voxel_hits = a.voxel_hits; t.map_hits = a.map_hits;
     // r22*wz(k) table, one row of kpad doubles per resident view
     t.rotated = grid_axis_aligned(ctx->grid) ? 0 : 1;
+    t.flags = (cfg.variant & dmi::VAR_NO_INTERIOR) ? dmi::TILE_FLAG_NO_INTERIOR : 0;
     t.maps = ctx->d_maps;
     const size_t need = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;  // rotated: [kpad][4]
     if (ctx->cz_table_capacity < need) {

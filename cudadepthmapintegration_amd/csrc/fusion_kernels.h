@@ -55,8 +55,11 @@ struct alignas(16) TileMapRec {
   const void *depth;       // same table as MapRec::depth
   double cz_err;           // rotated grids: bound on |computed c.z - real c.z| (0 for axis-aligned grids, where the
                            // computed c.z is monotone in every index and needs no margin)
+  double errk;             // what the fusion kernel multiplies by 1/c.z in its acceptance test: err plus 2^-22 times a
+                           // bound on c.z over the grid, so that errk/c.z >= err/c.z + 2^-22 and the test compares with 1/2
+  double pad[7];
 };
-static_assert(sizeof(TileMapRec) == 128, "TileMapRec layout");
+static_assert(sizeof(TileMapRec) == 192, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical
 // shortcuts proven in DESIGN.md ("K specialisation").
@@ -121,9 +124,11 @@ struct TileArgs {
   // Rotated grid (the 3x3 part of the grid matrix is not diagonal): w depends on all of (i, j, k), so c.z cannot
   // be split into a per-lane part and a per-(view, k) table; cz_table then holds [kpad][4] = the k-dependent products
   // (g02, g12, g22) * gz(k) of cu:168, and the kernel forms w and c.z per voxel in the reference's order
-  int32_t rotated, pad4;
+  int32_t rotated;
+  int32_t flags;                         // TileFlags2 bits
   const MapRec *maps;                    // RT row 2 in full for the rotated path
 };
+enum TileKernelFlags : int32_t { TILE_FLAG_NO_INTERIOR = 1 };  // tuning / tests: never take the INTERIOR column variant
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
 // corner voxels and the depth table's min/max pyramid (fusion_classify.hip):
@@ -165,7 +170,8 @@ enum VariantBits : int {
   VAR_NO_BRICK_CLASSES = 256,  // tiled kernel: every (brick, map) pair takes the per-voxel path
   VAR_SPATIAL_ORDER = 512,     // tiled kernel: workgroups in spatial order, not heaviest bricks first
   VAR_FIXED_TILE_SHAPE = 4096,  // tiled kernel: tile-shape bits 0 mean shape 0 whatever the grid size (no automatic choice)
-  VAR_KEEP_BEHIND_ADDS = 1024  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
+  VAR_KEEP_BEHIND_ADDS = 1024,  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
+  VAR_NO_INTERIOR = 2048        // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

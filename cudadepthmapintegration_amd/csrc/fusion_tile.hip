@@ -29,6 +29,8 @@
 //   * rayPotential is the reference's arithmetic; its three-way select is executed as EXEC-masked
 //     adds of the class constants, so a wave pays only for the classes it contains.
 // Results are bit-identical to the general kernel and to oracle/tsdf_oracle.c (tests/test_gpu_parity.py).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "fusion_kernels.h"
@@ -41,10 +43,30 @@ int tile_shape_index(int variant);
 namespace {
 
 constexpr int kLX = 8, kLY = 8;                   // lanes of a wave over (i, j)
-constexpr double kMagic = 6755399441055744.0;      // 1.5 * 2^52: x + kMagic rounds x to an integer (RNE)
-constexpr double kDecide = 0.5 - 0x1p-22;          // see DESIGN.md "Tiled kernel: proof obligations"
-constexpr double kRcpResidual = 0x1p-20;           // |1 - cz*r0| below this => |1 - cz*r| < 2^-39
 typedef unsigned long long mask_t;
+
+// Experiment switches of the column (tools/gpu_exp.sh builds one library per combination; the defaults are what ships)
+#ifndef DMI_EXP_ARGS
+#define DMI_EXP_ARGS 1    // 1: argument block read through the kernarg pointer, hot values pinned; 0: by-value parameter
+#endif
+#ifndef DMI_EXP_ROUND
+#define DMI_EXP_ROUND 1   // 1: v_rndne + v_cvt_i32, integer range tests; 0: magic-number adds, high-dword range tests
+#endif
+#ifndef DMI_EXP_CHK
+#define DMI_EXP_CHK 1     // 1: reciprocal residual folded into the acceptance value, one compare with 0.5; 0: two compares
+#endif
+#ifndef DMI_EXP_PHASEB
+#define DMI_EXP_PHASEB 1  // 1: class adds under possibly empty masks; 0: a test and a branch per class
+#endif
+#ifndef DMI_EXP_PB2
+#define DMI_EXP_PB2 1     // 1: phase B compares diff with -delta and +delta; 0: |diff| with delta, then the sign
+#endif
+#ifndef DMI_EXP_PINPTR
+#define DMI_EXP_PINPTR 0  // 1: the two per-view table pointers and the cz row pitch stay in SGPRs; 0: re-read per view
+#endif
+#ifndef DMI_EXP_CZPRE
+#define DMI_EXP_CZPRE 1   // 1: the group's exact c.z first; 0: inside each projection
+#endif
 
 // EXEC-masked accumulates with the running sums pinned to fixed VGPR pairs (generated; see the script for why)
 #include "fusion_tile_acc.inc"
@@ -56,6 +78,36 @@ __device__ __forceinline__ void or_where(uint32_t &bits, mask_t m, uint32_t bit 
 }
 
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// the same pointer, but through an asm the optimiser cannot see through: a load from it stays where it is written
+template <typename P>
+__device__ __forceinline__ P launder(P p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// A wave-uniform value the optimiser can no longer trace back to the load it came from (so it keeps the value in SGPRs
+// instead of re-loading it at every use): through a VGPR it cannot see into and back with v_readfirstlane.
+__device__ __forceinline__ int pinned_word(int x) {
+  asm volatile("" : "+v"(x));
+  return __builtin_amdgcn_readfirstlane(x);
+}
+template <typename T>
+__device__ __forceinline__ const T *pinned_ptr(const T *p) {
+  const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+  const uint32_t lo = (uint32_t)pinned_word((int)(uint32_t)v), hi = (uint32_t)pinned_word((int)(uint32_t)(v >> 32));
+  return reinterpret_cast<const T *>(((uintptr_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double pinned(double x) {
+  return __hiloint2double(pinned_word(__double2hiint(x)), pinned_word(__double2loint(x)));
+}
+
+// (int)x as the hardware does it: saturating, NaN -> 0 (a C cast is undefined outside int's range)
+__device__ __forceinline__ int cvt_saturating(double x) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 // Read-only, wave-uniform data (camera records, the cz table, the FuseArgs copy) is read through the
 // constant address space: with a uniform address that is a scalar load into SGPRs.
@@ -77,6 +129,7 @@ struct DepthLoad<float> {
   }
   static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
   static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0f; }  // cu:202; f32 holds the f64 exactly
+  static __device__ __forceinline__ raw_t sentinel() { return -1.0f; }
   static __device__ __forceinline__ double widen(raw_t d) { return (double)d; }
 };
 template <>
@@ -89,6 +142,7 @@ struct DepthLoad<double> {
   }
   static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
   static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0; }
+  static __device__ __forceinline__ raw_t sentinel() { return -1.0; }
   static __device__ __forceinline__ double widen(raw_t d) { return d; }
 };
 
@@ -154,6 +208,24 @@ constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
+  // The argument block is read where it is needed, straight from the kernarg segment (scalar loads), instead of through
+  // the by-value parameter: the view loop below has no scalar registers to spare, and what it does not use must not stay
+  // live across it.  KA(f): a plain load (the compiler may keep it); KC(f): a load the compiler cannot hoist or merge
+  // (the pointer goes through an opaque asm), for fields used once per view, after the loop or on rare paths.
+#if DMI_EXP_ARGS
+  typedef const TileArgs __attribute__((address_space(4))) *kernarg_t;
+  const kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)a;
+#define KA(f) (ka->f)
+#define KC(f) (launder(ka)->f)
+#define KFRESH() launder(ka)
+#else
+  typedef const TileArgs *kernarg_t;
+  const kernarg_t ka = &a;
+#define KA(f) (a.f)
+#define KC(f) (a.f)
+#define KFRESH() ka
+#endif
   constexpr int BASE = acc_base(MINW);
   constexpr int kGroup = GROUP;
   typedef double czvec __attribute__((ext_vector_type(GROUP)));
@@ -161,55 +233,55 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD), and
   // an XCD runs about 32 of these workgroups at a time.  So consecutive blocks OF ONE XCD enumerate one
   // super-brick of 4 x 4 x 2 bricks: the workgroups an XCD runs together are neighbours in space and their
-  // depth-map footprints overlap in that XCD's L2.  Super-bricks are dealt to the XCDs in runs of a.xcd_run
+  // depth-map footprints overlap in that XCD's L2.  Super-bricks are dealt to the XCDs in runs of KA(xcd_run)
   // (one z-layer of super-bricks): long enough that an XCD keeps working on one region of every depth map
   // (dealing single super-bricks round-robin cost 12 %), short enough that every XCD gets layers from all over
   // the grid (the work per brick depends on how close it is to a surface).
   const int b = blockIdx.x;
   const int q = b >> 3;                         // q-th workgroup of this block's XCD
-  const int run = a.xcd_run_wg;                 // workgroups dealt to one XCD in a row
+  const int run = KA(xcd_run_wg);                 // workgroups dealt to one XCD in a row
   const int p = (q / run) * (8 * run) + (b & 7) * run + q % run;
   // heaviest bricks first when the classification has ordered them (fusion_classify.hip), else spatial order
   // slots are absolute (whole grid); a slab fuse (dmi_fuse_slab) covers slots [slot_base, slot_base + slot_count)
-  int slot = p + a.slot_base;
-  if (a.order) {
-    if (p >= cload(a.n_order)) return;
-    slot = cload(a.order + p);
-  } else if (p >= a.slot_count) {
+  int slot = p + KA(slot_base);
+  if (KA(order)) {
+    if (p >= cload(KA(n_order))) return;
+    slot = cload(KA(order) + p);
+  } else if (p >= KA(slot_count)) {
     return;
   }
   const int sb = slot >> 5, within = slot & 31;
-  const int sbx = sb % a.super_x;
-  const int sbt = sb / a.super_x;
-  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
+  const int sbx = sb % KA(super_x);
+  const int sbt = sb / KA(super_x);
+  const int sby = sbt % KA(super_y), sbz = sbt / KA(super_y);
   const int bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
-  if (bx >= a.bricks_x || by >= a.bricks_y || bz >= a.bricks_z) return;  // padding of the super-brick grid
+  if (bx >= KA(bricks_x) || by >= KA(bricks_y) || bz >= KA(bricks_z)) return;  // padding of the super-brick grid
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and provably so
   const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
-  if (wbx >= a.wbricks_x || wby >= a.wbricks_y) return;            // wave entirely outside the grid
+  if (wbx >= KA(wbricks_x) || wby >= KA(wbricks_y)) return;            // wave entirely outside the grid
   const int i = wbx * kLX + (lane % kLX);
   const int j = wby * kLY + (lane / kLX);
   const int k0 = bz * TK;
-  const int kcount = a.nz - k0 < TK ? a.nz - k0 : TK;  // wave-uniform, >= 1
-  const bool lane_ok = i < a.nx && j < a.ny;
+  const int kcount = KA(nz) - k0 < TK ? KA(nz) - k0 : TK;  // wave-uniform, >= 1
+  const bool lane_ok = i < KA(nx) && j < KA(ny);
 
   // cu:78-83 + cu:168 once per lane.  With a diagonal 3x3 grid matrix wx depends on i only, wy on j
   // only, wz on k only (the off-diagonal products are exact zeros; only the sign of a zero result can
   // depend on the other indices, and no later step observes it: DESIGN.md).
-  const double gx = a.ox + (i + 0.5) * a.sx;
-  const double gy = a.oy + (j + 0.5) * a.sy;
-  const double gz0 = a.oz + ((k0 + a.kz0) + 0.5) * a.sz;
+  const double gx = KA(ox) + (i + 0.5) * KA(sx);
+  const double gy = KA(oy) + (j + 0.5) * KA(sy);
+  const double gz0 = KA(oz) + ((k0 + KA(kz0)) + 0.5) * KA(sz);
   // axis-aligned: the lane's world x, y and the column's first z.  Rotated: the (i, j)-dependent part of each world
   // coordinate, fl(fl(g_r0*gx) + fl(g_r1*gy)) -- the first sum of cu:90-92, which does not depend on k.
-  const double wx = ROT ? a.g[0] * gx + a.g[1] * gy : row4(a.g + 0, gx, gy, gz0);
-  const double wy = ROT ? a.g[4] * gx + a.g[5] * gy : row4(a.g + 4, gx, gy, gz0);
-  const double wz0 = ROT ? a.g[8] * gx + a.g[9] * gy : row4(a.g + 8, gx, gy, gz0);
+  double gm[12];  // rows 0..2 of the grid matrix
+#pragma unroll
+  for (int q = 0; q < 12; ++q) gm[q] = KA(g)[q];
+  const double wx = ROT ? gm[0] * gx + gm[1] * gy : row4(gm + 0, gx, gy, gz0);
+  const double wy = ROT ? gm[4] * gx + gm[5] * gy : row4(gm + 4, gx, gy, gz0);
+  const double wz0 = ROT ? gm[8] * gx + gm[9] * gy : row4(gm + 8, gx, gy, gz0);
 
-  GridT *__restrict__ grid = static_cast<GridT *>(a.grid);
-  const int64_t plane = (int64_t)a.ny * a.nx;
-  const int64_t gid0 = ((int64_t)k0 * a.ny + j) * a.nx + i;  // cu:126-134
 
   // the TK running sums live in v[BASE ...], outside the compiler's register budget (fusion_tile_acc.inc)
   uint32_t nh[COUNT ? TK : 1];
@@ -217,64 +289,110 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   for (int kk = 0; kk < TK; ++kk) {
     double v0 = 0.0;
     if (COUNT) nh[kk] = 0;
-    if (a.init_from_grid && lane_ok && kk < kcount) v0 = (double)grid[gid0 + kk * plane];  // cu:211 accumulates
+    if (KA(init_from_grid) && lane_ok && kk < kcount)  // cu:211 accumulates onto what the grid holds
+      v0 = (double)static_cast<const GridT *>(KA(grid))[(((int64_t)(k0 + kk)) * KA(ny) + j) * KA(nx) + i];
     acc_set<BASE, TK>(kk, v0);
   }
 
-  // 0 <= r < W for an integer-valued double r, on its high dword alone: the high dword is monotone
-  // in r, W's low dword is zero (W <= 2^20), and negative values have the sign bit set.
-  const uint32_t hiW = (uint32_t)__double2hiint((double)a.W);
-  const uint32_t hiH = (uint32_t)__double2hiint((double)a.H);
-
   const mask_t m_lane_ok = ballot(lane_ok);
-  const int m_end = a.first_map + a.n_maps;
+  const int first_map = KA(first_map);
+  const int m_end = first_map + KA(n_maps);
+  // what every voxel-projection needs: the ray potential's constants (cu:60-63 as FuseArgs holds them) in SGPRs, the
+  // depth-map size in VGPRs (two registers the vector file can spare more easily than the scalar one)
+  // (rho * -1 == -(rho * +1) exactly, cu:117: one register pair serves both plateau values)
+  double delta = KA(delta), thick = KA(thick), free_space = KA(free_space), rho_pos = KA(rho_pos), slope = KA(slope);
+  int keep_zero_adds = KA(behind_mask) == 0 ? 1 : 0;
+  // Values, not loads: without this the compiler re-reads them from the argument block (a scalar load and a wait) next
+  // to every use.  The two thresholds and the slope only ever meet per-lane operands: they live in VGPRs.
+#if DMI_EXP_ARGS
+  free_space = pinned(free_space), rho_pos = pinned(rho_pos);
+  keep_zero_adds = pinned_word(keep_zero_adds);
+  asm volatile("" : "+v"(delta), "+v"(thick), "+v"(slope));
+#endif
+  [[maybe_unused]] double resid_limit = 0x1p-20;  // |1 - cz*r0| below this => |1 - cz*r| < 2^-39
+#if DMI_EXP_CHK == 2
+  resid_limit = pinned(resid_limit);
+#endif
+#if DMI_EXP_ARGS && DMI_EXP_PINPTR
+  // where a view's record and its row of the cz table are: in SGPRs, so that both loads of a view go out at once (read
+  // per view from the argument block they would be a second, dependent round trip to the scalar cache at the head of
+  // every view)
+  const TileMapRec *const tile_maps = pinned_ptr(KA(tile_maps));
+  const double *const cz_table = pinned_ptr(KA(cz_table));
+  const int kpad = pinned_word(KA(kpad));
+#endif
+  unsigned vW = (unsigned)KA(W), vH = (unsigned)KA(H);
+  asm("" : "+v"(vW));
+  asm("" : "+v"(vH));
+  [[maybe_unused]] uint32_t hiW = (uint32_t)__double2hiint((double)KA(W)), hiH = (uint32_t)__double2hiint((double)KA(H));
+#if !DMI_EXP_ROUND
+  asm("" : "+v"(hiW));
+  asm("" : "+v"(hiH));
+#endif
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
   // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
   const unsigned long long *crow = reinterpret_cast<const unsigned long long *>(
-      a.classes + (((int64_t)bz * a.wbricks_y + wby) * a.wbricks_x + wbx) * (int64_t)a.class_pitch);
+      KA(classes) + (((int64_t)bz * KA(wbricks_y) + wby) * KA(wbricks_x) + wbx) * (int64_t)KA(class_pitch));
 
+  // The views of this brick.  The scalar unit -- one instruction per cycle for the whole CU -- is the resource this
+  // kernel runs out of first (DESIGN.md "Roofline"), so the loop is built to spend few scalar operations per view:
+  // skipped views cost none (one bit per view that needs work, found with s_ff1), and a run of BRICK_FREE views before
+  // the next view that needs its own treatment is counted (s_bcnt1) and executed as that many blocks of adds.  The only
+  // state carried across the per-voxel body below is (cword, cnext, m): the body has no scalar registers to spare.
   unsigned long long cword = 0ull;
-  unsigned long long cnext = cload(crow + (a.first_map >> 3));
-  for (int m = a.first_map; m < m_end; ++m) {
-    if ((m & 7) == 0 || m == a.first_map) {
-      // fetched one block ahead: its latency hides behind the previous eight maps.  behind_mask turns BEHIND (2) into
-      // SKIP (3) when x + 0.0 == x for every running sum: sums that start at +0.0 never become -0.0
-      cword = cnext | ((cnext >> 1) & a.behind_mask);
+  unsigned long long cnext = cload(crow + (first_map >> 3));
+  for (int m = first_map; m < m_end; ++m) {
+    if ((m & 7) == 0 || m == first_map) {
+      // fetched one word ahead: its latency hides behind this word's views.  behind_mask turns BEHIND (2) into SKIP (3)
+      // when x + 0.0 == x for every running sum: sums that start at +0.0 never become -0.0
+      cword = cnext | ((cnext >> 1) & KC(behind_mask));
       if ((((m >> 3) + 1) << 3) < m_end) cnext = cload(crow + (m >> 3) + 1);
     }
-    // Step straight to the next view of this class word that needs work (not BRICK_SKIP): one bit per such view,
-    // shifted so that bit 0 is view m.  Skipped views cost no loop iteration.
+    const int shift = (m & 7) * 8;
     const unsigned long long nonskip = cword ^ 0x0303030303030303ull;  // a BRICK_SKIP byte becomes 0
-    const unsigned long long todo = ((nonskip | (nonskip >> 1)) & 0x0101010101010101ull) >> ((m & 7) * 8);
-    if (todo == 0) {  // none of the remaining views of this word touches the brick
+    unsigned long long todo = ((nonskip | (nonskip >> 1)) & 0x0101010101010101ull) >> shift;  // bit 8i: view m + i needs work
+    if ((m | 7) >= m_end) todo &= (1ull << ((m_end - m) * 8)) - 1;  // the last word: views beyond the fused range
+    // BRICK_FREE views (byte == 1) before the next view that needs its own treatment: -eta*rho (cu:115) to every voxel of
+    // the brick, once per view.  All TK slots, also in a brick that sticks out of the top of the grid (the slots above
+    // the grid are never stored; lanes outside the grid store nothing).  With hit counters every view is taken singly.
+    const unsigned long long fr = COUNT ? 0ull : (todo & ((cword & ~(cword >> 1) & 0x0101010101010101ull) >> shift));
+    const unsigned long long other = todo ^ fr;             // BRICK_MIXED views (and BEHIND / counted FREE ones)
+    const unsigned long long below = (other - 1) & ~other;  // the bits below the next such view (all bits, if none)
+    for (int n_free = __builtin_popcountll(fr & below); n_free > 0; --n_free) {
+#pragma unroll
+      for (int q = 0; q < TK; q += 8) acc_add8_all<BASE, TK>(q, free_space);
+    }
+    if (other == 0) {  // nothing else in this word
       m |= 7;
       continue;
     }
-    m += __builtin_ctzll(todo) >> 3;
-    if (m >= m_end) break;  // the next view that needs work lies beyond the fused range
-    const unsigned cls = (unsigned)(cword >> ((m & 7) * 8)) & 3u;
+    m += __builtin_ctzll(other) >> 3;
+    const unsigned cbyte = (unsigned)(cword >> ((m & 7) * 8)) & 0x1fu;  // class in bits 0..1, MixedReason above it
+    const unsigned cls = cbyte & 3u;
     if (cls != BRICK_MIXED) {
-      // proven: the reference does the same to every voxel of this brick for this map
-      {
-        const double v = cls == BRICK_FREE ? a.free_space : 0.0;  // cu:115 (adding 0 keeps -0.0 + 0.0 = +0.0)
-        // all TK slots, also in a brick that sticks out of the top of the grid (kcount < TK): the slots above the grid
-        // are never stored, and treating them alike keeps per-slot predicates out of the loop
+      // BEHIND: +0 (cu:115; adding 0 turns -0.0 into +0.0 as the reference does); FREE when hits are counted
+      const double v = cls == BRICK_FREE ? free_space : 0.0;
 #pragma unroll
-        for (int q = 0; q < TK; q += 8) acc_add8_all<BASE, TK>(q, v);  // every lane: those outside the grid store nothing
-        if (COUNT) {
+      for (int q = 0; q < TK; q += 8) acc_add8_all<BASE, TK>(q, v);
+      if (COUNT) {
 #pragma unroll
-          for (int q = 0; q < TK; ++q) nh[q] += lane_ok ? 1u : 0u;
-          const uint32_t hits = (uint32_t)__popcll(m_lane_ok) * (uint32_t)kcount;
-          if (hits != 0 && lane == 0) atomicAdd(&a.map_hits[m], (unsigned long long)hits);
-        }
+        for (int q = 0; q < TK; ++q) nh[q] += lane_ok ? 1u : 0u;
+        const uint32_t hits = (uint32_t)__popcll(m_lane_ok) * (uint32_t)kcount;
+        if (hits != 0 && lane == 0) atomicAdd(&KC(map_hits)[m], (unsigned long long)hits);
       }
       continue;
     }
-    const TileMapRec *rec = a.tile_maps + m;                     // wave-uniform -> scalar loads
-    const double *ct = a.cz_table + (int64_t)m * a.kpad + k0;  // r22*wz(k), wave-uniform
+    const kernarg_t kv = KFRESH();                              // this view's reads of the argument block
+#if DMI_EXP_ARGS && DMI_EXP_PINPTR
+    const TileMapRec *rec = tile_maps + m;                      // wave-uniform -> scalar loads
+    const double *ct = cz_table + (int64_t)m * kpad + k0;       // r22*wz(k), wave-uniform
+#else
+    const TileMapRec *rec = kv->tile_maps + m;                  // wave-uniform -> scalar loads
+    const double *ct = kv->cz_table + (int64_t)m * kv->kpad + k0;  // r22*wz(k), wave-uniform
+#endif
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&rec->depth)), (short)0, a.depth_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&rec->depth)), (short)0, kv->depth_bytes, 0x00020000);
 
     // exact: the part of c.z shared by the whole column, (r20*wx + r21*wy)  (cu:92).  Lanes outside
     // the grid get -inf: their c.z is -inf, i.e. "behind the camera" (cu:177), at no cost per voxel.
@@ -284,7 +402,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     if constexpr (ROT) {
       r20 = cload(&rec->rz0);
       r21 = cload(&rec->rz1);
-      r22 = cload(&a.maps[m].rt[10]);
+      r22 = cload(&kv->maps[m].rt[10]);
       sz = lane_ok ? cload(&rec->rz3) : -__builtin_inf();  // r23 per lane: -inf puts lanes outside the grid behind the camera
       rz3 = 0;
       hx = hy = 0;  // set at the column's first voxel below
@@ -298,113 +416,195 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       hy = __builtin_fma(cload(&rec->qx), wx,
                          __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
     }
-    const double dhx = cload(&rec->dhx), dhy = cload(&rec->dhy), err = cload(&rec->err);
+    const double dhx = cload(&rec->dhx), dhy = cload(&rec->dhy), errk = cload(&rec->errk);
 
     uint32_t undecided = 0;  // per lane: bit kk set = redo voxel kk of this map exactly
     uint32_t map_hits = 0;   // wave-uniform
 
-    // r22*wz(k) for one group of the column per scalar load, fetched one group ahead of its use
-    czvec ct_cur = {};
-    if constexpr (!ROT) ct_cur = cload(reinterpret_cast<const czvec *>(ct));
-#pragma unroll
-    for (int g0 = 0; g0 < TK; g0 += kGroup) {
-      czvec ct_next = ct_cur;
-      if (!ROT && g0 + kGroup < TK) ct_next = cload(reinterpret_cast<const czvec *>(ct + g0 + kGroup));
-      double czg[kGroup];
-      typename DL::raw_t dg[kGroup] = {};  // defined on every path: no loop-carried undefined values to shuffle around
-      mask_t ing[kGroup];
-      // ---- phase A: project the group's voxels and issue their depth loads
-#pragma unroll
-      for (int q = 0; q < kGroup; ++q) {
-        const int kk = g0 + q;
-        double cz;
-        if constexpr (ROT) {
-          ing[q] = 0;
-          if (kk >= kcount) continue;  // wave-uniform: a voxel above the grid (the table has no -inf trick here)
-          // the k-dependent products g_r2*gz(k) of cu:168 (wk table, scalar load), then w and c.z in the reference's order
-          const czvec4 b = cload(reinterpret_cast<const czvec4 *>(a.cz_table + (int64_t)(k0 + kk) * 4));
-          const double wxk = (wx + b[0]) + a.g[3], wyk = (wy + b[1]) + a.g[7], wzk = (wz0 + b[2]) + a.g[11];
-          cz = ((r20 * wxk + r21 * wyk) + r22 * wzk) + sz;
-          if (kk == 0) {
-            hx = __builtin_fma(cload(&rec->px), wxk,
-                               __builtin_fma(cload(&rec->py), wyk, __builtin_fma(cload(&rec->pz), wzk, cload(&rec->p0))));
-            hy = __builtin_fma(cload(&rec->qx), wxk,
-                               __builtin_fma(cload(&rec->qy), wyk, __builtin_fma(cload(&rec->qz), wzk, cload(&rec->q0))));
+    // The column, in two instantiations chosen per (brick, view): INTERIOR when the classification has proven every
+    // voxel of the brick in front of the camera and inside the depth map for this view (the mixed pairs that are mixed
+    // because a surface is near: MIXED_NAN_DEPTH and above), the full tests otherwise.
+    auto column = [&](auto interior_tag) __attribute__((always_inline)) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
+  #pragma unroll
+      for (int g0 = 0; g0 < TK; g0 += kGroup) {
+        double czg[kGroup];
+        // Every lane starts from the "no depth" sentinel and only the lanes that are in the map load over it: phase B then
+        // needs no mask from phase A (eight lane masks = sixteen SGPRs the loop does not have), cu:202 covers both.
+        typename DL::raw_t dg[kGroup];
+        [[maybe_unused]] czvec ctq = {};
+        if constexpr (!ROT && !DMI_EXP_CZPRE) ctq = cload(reinterpret_cast<const czvec *>(ct + g0));
+        if constexpr (!ROT && DMI_EXP_CZPRE) {
+          // exact c.z of the group's voxels first (cu:92, cu:172; h.z == c.z for a pinhole K): r22*wz(k) comes as one
+          // scalar load for the group and its sixteen SGPRs are free again before the projections start
+          const czvec ctg = cload(reinterpret_cast<const czvec *>(ct + g0));
+  #pragma unroll
+          for (int q = 0; q < kGroup; ++q) czg[q] = (sz + ctg[q]) + rz3;
+          __builtin_amdgcn_sched_barrier(0);  // here, not sunk into the projections: that would keep ctg's SGPRs alive
+        }
+        // ---- phase A: project the group's voxels and issue their depth loads
+  #pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+          const int kk = g0 + q;
+          dg[q] = DL::sentinel();
+          if constexpr (ROT) {
+            if (kk >= kcount) continue;  // wave-uniform: a voxel above the grid (the table has no -inf trick here)
+            // the k-dependent products g_r2*gz(k) of cu:168 (wk table, scalar load), then w and c.z in the reference's order
+            const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kv->cz_table + (int64_t)(k0 + kk) * 4));
+            const double wxk = (wx + b[0]) + KA(g)[3], wyk = (wy + b[1]) + KA(g)[7], wzk = (wz0 + b[2]) + KA(g)[11];
+            czg[q] = ((r20 * wxk + r21 * wyk) + r22 * wzk) + sz;
+            if (kk == 0) {
+              hx = __builtin_fma(cload(&rec->px), wxk,
+                                 __builtin_fma(cload(&rec->py), wyk, __builtin_fma(cload(&rec->pz), wzk, cload(&rec->p0))));
+              hy = __builtin_fma(cload(&rec->qx), wxk,
+                                 __builtin_fma(cload(&rec->qy), wyk, __builtin_fma(cload(&rec->qz), wzk, cload(&rec->q0))));
+            } else {
+              hx += dhx;
+              hy += dhy;
+            }
           } else {
-            hx += dhx;
-            hy += dhy;
+            if (kk > 0) {
+              hx += dhx;
+              hy += dhy;
+            }
+            if constexpr (!DMI_EXP_CZPRE) czg[q] = (sz + ctq[q]) + rz3;
           }
-        } else {
-          if (kk > 0) {
-            hx += dhx;
-            hy += dhy;
+          const double cz = czg[q];
+          // reciprocal: hardware seed + one Newton step; e0 is the seed's residual, checked below
+          const double r0 = __builtin_amdgcn_rcp(cz);
+          const double e0 = __builtin_fma(-cz, r0, 1.0);
+          const double r = __builtin_fma(r0, e0, r0);
+          const double ua = hx * r, va = hy * r;
+          // nearest integers (ties never accepted, so RNE vs the reference's half-away does not matter)
+#if DMI_EXP_ROUND
+          const double ru = __builtin_rint(ua), rv = __builtin_rint(va);
+          const int px = cvt_saturating(ru), py = cvt_saturating(rv);
+#else
+          constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: x + kMagic rounds x to an integer (RNE)
+          const double tu = ua + kMagic, tv = va + kMagic;
+          const double ru = tu - kMagic, rv = tv - kMagic;
+          const int px = __double2loint(tu), py = __double2loint(tv);  // two's complement below 2^31
+#endif
+          const double fu = ua - ru, fv = va - rv;  // exact: signed distance to the chosen integer
+#if DMI_EXP_CHK == 1
+          // Accepted iff |frac| + (bound on |u_ref - ua|) < 1/2, a bound that holds only with a good reciprocal: the seed's
+          // residual |e0| must be below 2^-20, i.e. |e0| * 2^19 below 1/2 -- it joins the maximum, so ONE compare against an
+          // inline constant decides (errk includes the 2^-22 of DESIGN.md 4.4, scaled so that errk * r covers it).  A NaN
+          // anywhere makes r, and with it chk, a NaN: not accepted.
+          const double resid = __builtin_ldexp(__builtin_fabs(e0), 19);
+          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)), resid));
+          const mask_t m_proven = ballot(chk < 0.5);
+#elif DMI_EXP_CHK == 2
+          // one VALU instruction fewer than folding the residual in: its own compare against 2^-20 (a pinned SGPR pair),
+          // the acceptance value against the inline constant 0.5 (errk carries the 2^-22 of DESIGN.md 4.4)
+          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
+          const mask_t m_proven = ballot(__builtin_fabs(e0) < resid_limit) & ballot(chk < 0.5);
+#else
+          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
+          const mask_t m_proven = ballot(__builtin_fabs(e0) < 0x1p-20) & ballot(chk < 0.5 - 0x1p-22);
+#endif
+          // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot is one v_cmp, all the logic
+          // between them runs on the scalar unit.
+          mask_t m_in, m_und;
+          if constexpr (INTERIOR) {
+            // The classification has proven, for EVERY voxel of this brick and this view, that the reference's c.z is
+            // positive and its rounded pixel inside the depth map (box_footprint: fp.query).  A proven lane's
+            // pixel IS the reference's pixel, so the tests of cu:177 and cu:192-197 are decided already; what is left is
+            // which lanes are voxels at all (bricks that stick out of the top of the grid take the other variant).
+            m_in = m_proven & m_lane_ok;
+            m_und = m_lane_ok & ~m_proven;
+          } else {
+            const mask_t m_front = ballot(!(cz < 0.0));  // cu:177: not behind the camera
+#if DMI_EXP_ROUND
+            // cu:192-197 on the integers: a saturated conversion (|ru| >= 2^31) is >= 2^31 as unsigned, outside any map
+            m_in = m_front & m_proven & ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
+#else
+            // 0 <= r < W for an integer-valued double r, on its high dword alone: the high dword is monotone in r, W's low
+            // dword is zero (W <= 2^20), and negative values have the sign bit set
+            uint32_t hu = (uint32_t)__double2hiint(ru), hv = (uint32_t)__double2hiint(rv);
+            asm("" : "+v"(hu));
+            asm("" : "+v"(hv));
+            m_in = m_front & m_proven & ballot(hu < hiW) & ballot(hv < hiH);
+#endif
+            m_und = m_front & ~m_proven;
           }
-          cz = (sz + ct_cur[q]) + rz3;  // exact c.z (cu:92, cu:172); h.z == c.z for a pinhole K
+          if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
+          if (__builtin_amdgcn_inverse_ballot_w64(m_in))
+            dg[q] = DL::load(rsrc, __umul24((unsigned)py, vW) + (unsigned)px);  // cu:201
+          // keep the voxels' instruction streams apart: interleaving them buys nothing (other waves fill the
+          // gaps) and costs the registers that decide the occupancy
+          __builtin_amdgcn_sched_barrier(0);
         }
-        czg[q] = cz;
-        // reciprocal: hardware seed + one Newton step; e0 is the seed's residual, checked below
-        const double r0 = __builtin_amdgcn_rcp(cz);
-        const double e0 = __builtin_fma(-cz, r0, 1.0);
-        const double r = __builtin_fma(r0, e0, r0);
-        const double ua = hx * r, va = hy * r;
-        // nearest integers (ties never accepted, so RNE vs the reference's half-away does not matter)
-        const double tu = ua + kMagic, tv = va + kMagic;
-        const double ru = tu - kMagic, rv = tv - kMagic;
-        const double fu = ua - ru, fv = va - rv;  // exact: signed distance to the chosen integer
-        // accepted iff |frac| + (bound on |u_ref - ua|) < 1/2 - 2^-22; a NaN anywhere fails a compare
-        const double chk = __builtin_fma(err, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
-        // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot below is one
-        // v_cmp, all the logic between them runs on the scalar unit.
-        const mask_t m_front = ballot(!(cz < 0.0));  // cu:177: not behind the camera
-        const mask_t m_proven = ballot(__builtin_fabs(e0) < kRcpResidual) & ballot(chk < kDecide);
-        uint32_t hu = (uint32_t)__double2hiint(ru), hv = (uint32_t)__double2hiint(rv);
-        asm("" : "+v"(hu));  // keep these two as plain 32-bit compares
-        asm("" : "+v"(hv));
-        const mask_t m_in = m_front & m_proven & ballot(hu < hiW) & ballot(hv < hiH);  // cu:192-197
-        ing[q] = m_in;
-        const mask_t m_und = m_front & ~m_proven;
-        if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
-        if (__builtin_amdgcn_inverse_ballot_w64(m_in)) {
-          // the integers themselves are the low dwords of tu, tv (two's complement below 2^31)
-          const unsigned px = (unsigned)__double2loint(tu), py = (unsigned)__double2loint(tv);
-          dg[q] = DL::load(rsrc, __umul24(py, (unsigned)a.W) + px);  // cu:201
+        // ---- phase B: ray potential of the group (cu:105-120) as EXEC-masked adds.  The scalar unit is what this kernel
+        // runs out of, so a class that may be absent is still added (under an empty mask) rather than tested for.
+  #pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+          const int kk = g0 + q;
+          const typename DL::raw_t d = dg[q];  // lanes that did not load still hold the sentinel
+          const mask_t m_hit = ballot(!DL::is_sentinel(d));  // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike
+          if (m_hit) {  // wave-uniform: skip the potential when no lane accumulates
+            const double diff = czg[q] - DL::widen(d);  // cu:108
+#if DMI_EXP_PHASEB && DMI_EXP_PB2
+            // cu:114-115 as two signed compares: diff < -delta is "far in front" (-eta*rho), diff > delta "far behind" (+0);
+            // a NaN diff fails both and ends, as in the reference, in the last else branch (cu:119)
+            const mask_t m_front_far = ballot(diff < -delta);  // (also set on lanes that did not hit: masked below)
+            const mask_t m_behind_far = ballot(diff > delta);
+            acc_add_s<BASE, TK>(kk, m_hit & m_front_far, free_space);  // -eta*rho (cu:115)
+            // + 0 (cu:115) matters only where a sum can be -0.0: never, when the grid started at +0.0 (behind_mask set)
+            if (keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_behind_far);
+            const mask_t m_near = m_hit & ~(m_front_far | m_behind_far);
+            if (m_near) {
+              const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
+              const mask_t m_pos = ballot(diff > 0);                                 // the sign of cu:112
+              acc_add_s<BASE, TK>(kk, m_plat & m_pos, rho_pos);                       // rho * +1 (cu:117)
+              acc_sub_s<BASE, TK>(kk, m_plat & ~m_pos, rho_pos);                      // rho * -1
+              // the rest, a NaN diff included, is the reference's else branch: (rho/thick)*diff (cu:119)
+              acc_add_v<BASE, TK>(kk, m_near & ~m_plat, slope * diff);
+            }
+#elif DMI_EXP_PHASEB
+            const mask_t m_farv = ballot(__builtin_fabs(diff) > delta);  // cu:114 (also set on lanes that did not hit)
+            const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
+            acc_add_s<BASE, TK>(kk, m_hit & m_farv & ~m_pos, free_space);  // -eta*rho (cu:115)
+            // + 0 (cu:115) matters only where a sum can be -0.0: never, when the grid started at +0.0 (behind_mask set)
+            if (keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_farv & m_pos);
+            const mask_t m_near = m_hit & ~m_farv;
+            if (m_near) {
+              const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
+              acc_add_s<BASE, TK>(kk, m_plat & m_pos, rho_pos);                       // rho * +1 (cu:117)
+              acc_sub_s<BASE, TK>(kk, m_plat & ~m_pos, rho_pos);                      // rho * -1
+              // the rest, a NaN diff included, is the reference's else branch: (rho/thick)*diff (cu:119)
+              acc_add_v<BASE, TK>(kk, m_near & ~m_plat, slope * diff);
+            }
+#else
+            const mask_t m_far = m_hit & ballot(__builtin_fabs(diff) > delta);  // cu:114
+            const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
+            if (m_far) {
+              const mask_t m_free = m_far & ~m_pos, m_zero = m_far & m_pos;
+              if (m_free) acc_add_s<BASE, TK>(kk, m_free, free_space);              // -eta*rho (cu:115)
+              if (keep_zero_adds && m_zero) acc_add_zero<BASE, TK>(kk, m_zero);      // + 0 (cu:115): -0.0 + 0.0 = +0.0
+            }
+            const mask_t m_near = m_hit & ~m_far;
+            if (m_near) {
+              const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
+              const mask_t m_ramp = m_near & ~m_plat;  // includes a NaN diff, as the reference's else branch
+              const mask_t m_pp = m_plat & m_pos, m_pn = m_plat & ~m_pos;
+              if (m_pp) acc_add_s<BASE, TK>(kk, m_pp, rho_pos);           // rho * +1 (cu:117)
+              if (m_pn) acc_sub_s<BASE, TK>(kk, m_pn, rho_pos);           // rho * -1
+              if (m_ramp) acc_add_v<BASE, TK>(kk, m_ramp, slope * diff);  // (rho/thick)*diff (cu:119)
+            }
+#endif
+            if (COUNT) {
+              nh[kk] += __builtin_amdgcn_inverse_ballot_w64(m_hit) ? 1u : 0u;
+              map_hits += (uint32_t)__popcll(m_hit);
+            }
+          }
         }
-        // keep the voxels' instruction streams apart: interleaving them buys nothing (other waves fill the
-        // gaps) and costs the registers that decide the occupancy
-        __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- phase B: ray potential of the group (cu:105-120) as EXEC-masked adds
-#pragma unroll
-      for (int q = 0; q < kGroup; ++q) {
-        const int kk = g0 + q;
-        const typename DL::raw_t d = dg[q];  // lanes that did not load hold garbage, masked by ing[q]
-        const mask_t m_hit = ing[q] & ballot(!DL::is_sentinel(d));  // cu:202
-        if (m_hit) {  // wave-uniform: skip the potential when no lane accumulates
-          const double diff = czg[q] - DL::widen(d);  // cu:108
-          const mask_t m_far = m_hit & ballot(__builtin_fabs(diff) > a.delta);  // cu:114
-          const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
-          if (m_far) {
-            const mask_t m_free = m_far & ~m_pos, m_zero = m_far & m_pos;
-            if (m_free) acc_add_s<BASE, TK>(kk, m_free, a.free_space);  // -eta*rho (cu:115)
-            if (m_zero) acc_add_zero<BASE, TK>(kk, m_zero);             // + 0 (cu:115): keeps -0.0 + 0.0 = +0.0
-          }
-          const mask_t m_near = m_hit & ~m_far;
-          if (m_near) {
-            const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > a.thick);  // cu:116
-            const mask_t m_ramp = m_near & ~m_plat;  // includes a NaN diff, as the reference's else branch
-            const mask_t m_pp = m_plat & m_pos, m_pn = m_plat & ~m_pos;
-            if (m_pp) acc_add_s<BASE, TK>(kk, m_pp, a.rho_pos);           // rho * +1 (cu:117)
-            if (m_pn) acc_add_s<BASE, TK>(kk, m_pn, a.rho_neg);           // rho * -1
-            if (m_ramp) acc_add_v<BASE, TK>(kk, m_ramp, a.slope * diff);  // (rho/thick)*diff (cu:119)
-          }
-          if (COUNT) {
-            nh[kk] += __builtin_amdgcn_inverse_ballot_w64(m_hit) ? 1u : 0u;
-            map_hits += (uint32_t)__popcll(m_hit);
-          }
-        }
-      }
-      ct_cur = ct_next;
-    }
+    };
+    if (!ROT && kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR))
+      column(std::true_type{});
+    else
+      column(std::false_type{});
 
     // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so
     // doing them after the column keeps every voxel's accumulation in map order, cu:211)
@@ -415,7 +615,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         if (!ballot(mine)) continue;
         double val = 0.0;
         bool hit = false;
-        if (mine) hit = tile_exact<DepthT>(a.full, m, rsrc, i, j, k0 + kk, val);
+        if (mine) hit = tile_exact<DepthT>(KC(full), m, rsrc, i, j, k0 + kk, val);
 #pragma unroll
         for (int q = 0; q < TK; ++q) {
           if (kk == q) {  // wave-uniform
@@ -427,25 +627,30 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       }
     }
     if (COUNT) {
-      if (map_hits != 0 && lane == 0) atomicAdd(&a.map_hits[m], (unsigned long long)map_hits);
+      if (map_hits != 0 && lane == 0) atomicAdd(&KC(map_hits)[m], (unsigned long long)map_hits);
     }
   }
 
   if (lane_ok) {
-    // Recompute the store addresses here: without this barrier the compiler keeps the TK addresses it formed
-    // for the initial loads alive across the whole map loop (2 VGPRs each).
-    int64_t gid = gid0;
-    asm("" : "+v"(gid));
+    // The store addresses are formed here, from a fresh read of the argument block: nothing of them (TK addresses of 2
+    // VGPRs each, the grid pointer, the row and plane pitches) stays live across the view loop.
+    const kernarg_t ke = KFRESH();
+    GridT *__restrict__ grid = static_cast<GridT *>(ke->grid);
+    const int64_t plane = (int64_t)ke->ny * ke->nx;
+    int64_t gid = ((int64_t)k0 * ke->ny + j) * ke->nx + i;  // cu:126-134
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
       if (kk < kcount) {
         grid[gid] = (GridT)acc_get<BASE, TK>(kk);
-        if (COUNT) a.voxel_hits[gid] += nh[kk];
+        if (COUNT) ke->voxel_hits[gid] += nh[kk];
       }
       gid += plane;
     }
   }
 }
+#undef KA
+#undef KC
+#undef KFRESH
 
 // r22[m] * wz(k): the one product of c.z that depends on (map, k) only.  Exact fp64 multiply.
 __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const MapRec *__restrict__ maps,
@@ -532,6 +737,17 @@ TileShape tile_shape(int variant, bool depth_is_f64, bool rotated) {
   }
 }
 
+#ifdef DMI_TUNING
+// timing experiments only (results are wrong): rewrite class bytes after the classification, e.g. FREE -> SKIP to see
+// what the uniform adds cost, MIXED -> SKIP to see what everything but the per-voxel path costs
+__global__ __launch_bounds__(256) void remap_classes_kernel(uint8_t *classes, int64_t n, uint32_t table) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint8_t b = classes[i];
+    classes[i] = (uint8_t)((table >> (8 * (b & 3))) & 0xff);
+  }
+}
+#endif
+
 hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const FuseConfig &cfg, const PyramidDesc &pyramid,
                              uint8_t *order_scratch, uint8_t *coarse_classes, hipEvent_t before_main_kernel,
                              hipStream_t stream) {
@@ -547,6 +763,13 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
     const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, stream);
     if (e != hipSuccess) return e;
+#ifdef DMI_TUNING
+    if (const char *env = getenv("DMI_DEBUG_CLASS_REMAP")) {  // e.g. 0x03020300: byte c = what class c becomes
+      const int64_t n = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z * (int64_t)a.class_pitch;
+      hipLaunchKernelGGL(remap_classes_kernel, dim3(4096), dim3(256), 0, stream, const_cast<uint8_t *>(a.classes), n,
+                         (uint32_t)strtoul(env, nullptr, 0));
+    }
+#endif
     if (a.order) {
       e = launch_order_bricks(a, sh.wx, sh.wy, order_scratch, const_cast<int *>(a.order), const_cast<int *>(a.n_order), stream);
       if (e != hipSuccess) return e;

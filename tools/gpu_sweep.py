@@ -45,6 +45,7 @@ def main():
             c.add_views(views)
             ctxs[v] = c
         times = {v: [] for v in variants}
+        main_times = {v: [] for v in variants}
         for r in range(args.rounds + 1):
             for v in variants:
                 c = ctxs[v]
@@ -53,11 +54,13 @@ def main():
                 c.synchronize()
                 if r > 0:
                     times[v].append(c.timings().last_fuse_kernel_ms)
+                    main_times[v].append(c.timings().last_fuse_main_kernel_ms)
         proj = grid.n_voxels * n_maps
         for v in variants:
             t = np.array(times[v])
             rec = {"workload": args.workload, "scene": sc, "variant": v, "k_mode": int(ctxs[v].info().k_mode),
                    "median_ms": float(np.median(t)), "min_ms": float(t.min()),
+                   "main_median_ms": float(np.median(main_times[v])),
                    "gproj_per_s_median": proj / np.median(t) / 1e6, "gen_s": gen_s,
                    "tiled": int(ctxs[v].info().tiled_kernel), "brick_classes": ctxs[v].brick_class_histogram(), "mixed_reasons": ctxs[v].mixed_reason_histogram()}
             results.append(rec)
