@@ -65,7 +65,9 @@ struct dmi_context {
   int32_t W = 0, H = 0;
   bool depth_f64 = false;
   bool finite_bounded = true;  // grid descriptor magnitudes allow the K shortcuts
-  int k_mode = dmi::K_PINHOLE;
+  int k_mode = dmi::K_PINHOLE;          // the least structured K among the resident views (dmi_info)
+  std::vector<uint8_t> view_k_mode;     // per view: dmi::KMode of its K
+  std::vector<uint8_t> view_tile_ok;    // per view: meets the tiled kernel's per-view preconditions (make_tile_rec)
   std::vector<Batch> batches;
   std::vector<MapRec> h_maps;
   MapRec *d_maps = nullptr;
@@ -320,19 +322,36 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   t.rz0 = rt[8];
   t.rz1 = rt[9];
   t.rz3 = rt[11];
-  double P[4], Q[4];
+  // rows of K * [R|T]: h.x, h.y (and, for a K whose third row is not 0 0 1 0, h.z) as affine functions of the world
+  // position.  A pinhole K keeps the shorter sums it always had (the dropped terms are exact zeros).
+  const bool general = classify_k(r.k, r.rt) == dmi::K_GENERAL;
+  double P[4], Q[4], S[4];
   for (int c = 0; c < 4; ++c) {
-    P[c] = k[0] * rt[c] + k[1] * rt[4 + c] + k[2] * rt[8 + c];  // row 0 of K (fx s cx0 0) times [R|T]
-    Q[c] = k[5] * rt[4 + c] + k[6] * rt[8 + c];                 // row 1 of K (0 fy cy0 0)
+    if (general) {
+      P[c] = (k[0] * rt[c] + k[1] * rt[4 + c]) + k[2] * rt[8 + c];
+      Q[c] = (k[4] * rt[c] + k[5] * rt[4 + c]) + k[6] * rt[8 + c];
+      S[c] = (k[8] * rt[c] + k[9] * rt[4 + c]) + k[10] * rt[8 + c];
+    } else {
+      P[c] = k[0] * rt[c] + k[1] * rt[4 + c] + k[2] * rt[8 + c];  // row 0 of K (fx s cx0 0) times [R|T]
+      Q[c] = k[5] * rt[4 + c] + k[6] * rt[8 + c];                 // row 1 of K (0 fy cy0 0)
+      S[c] = rt[8 + c];                                           // row 2 of K (0 0 1 0): h.z == c.z
+    }
+  }
+  if (general) {  // the fourth column of K multiplies the homogeneous 1 (cu:90-92)
+    P[3] += k[3];
+    Q[3] += k[7];
+    S[3] += k[11];
   }
   t.px = P[0]; t.py = P[1]; t.pz = P[2]; t.p0 = P[3];
   t.qx = Q[0]; t.qy = Q[1]; t.qz = Q[2]; t.q0 = Q[3];
+  t.sx = S[0]; t.sy = S[1]; t.sz = S[2]; t.s0 = S[3];
   // step of the world position per voxel along k: column 2 of the grid matrix times the spacing (for an axis-aligned
   // grid only its z component is non-zero)
   const double *g = ctx->grid.grid_matrix;
   const double sz = ctx->grid.spacing[2];
   t.dhx = (P[0] * (g[2] * sz) + P[1] * (g[6] * sz)) + P[2] * (g[10] * sz);
   t.dhy = (Q[0] * (g[2] * sz) + Q[1] * (g[6] * sz)) + Q[2] * (g[10] * sz);
+  t.dhz = (S[0] * (g[2] * sz) + S[1] * (g[6] * sz)) + S[2] * (g[10] * sz);
   // magnitudes of the world coordinates over the grid (plus one column height)
   double wm[3];
   const bool aligned = grid_axis_aligned(ctx->grid);
@@ -356,28 +375,34 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   for (int row = 0; row < 3; ++row)
     M[row] = std::fabs(rt[4 * row]) * wm[0] + std::fabs(rt[4 * row + 1]) * wm[1] + std::fabs(rt[4 * row + 2]) * wm[2] +
              std::fabs(rt[4 * row + 3]);
-  const double Sx = std::fabs(k[0]) * M[0] + std::fabs(k[1]) * M[1] + std::fabs(k[2]) * M[2];
-  const double Sy = std::fabs(k[5]) * M[1] + std::fabs(k[6]) * M[2];
+  // magnitudes of the terms of h.x, h.y, h.z: every row of K against (|c.x|, |c.y|, |c.z|, 1)
+  const double Sx = std::fabs(k[0]) * M[0] + std::fabs(k[1]) * M[1] + std::fabs(k[2]) * M[2] + (general ? std::fabs(k[3]) : 0.0);
+  const double Sy = (general ? std::fabs(k[4]) * M[0] : 0.0) + std::fabs(k[5]) * M[1] + std::fabs(k[6]) * M[2] +
+                    (general ? std::fabs(k[7]) : 0.0);
+  const double Sz = general ? std::fabs(k[8]) * M[0] + std::fabs(k[9]) * M[1] + std::fabs(k[10]) * M[2] + std::fabs(k[11]) : M[2];
   t.err = std::max(Sx, Sy) * 0x1p-44;  // 512 ulps of the term magnitudes
+  // general K: the same bound for the affine h.z.  0 for a pinhole K, where the kernel's h.z is the reference's own c.z
+  t.errz = general ? Sz * 0x1p-44 : 0.0;
   // rotated grid: the computed c.z (9 + 6 rounded operations on terms bounded by M[2]) is within 8 ulp(M[2]) of the
   // real, exactly affine one; four times that as the margin of the brick classification
   t.cz_err = aligned ? 0.0 : M[2] * 0x1p-47;
-  // the kernel accepts a pixel iff |frac| + errk * r < 1/2 with r = (1 +- 2^-39) / c.z: errk * r covers err / c.z plus the
-  // 2^-22 of DESIGN.md 4.4 because M[2] bounds |c.z| everywhere in the grid (M[2] * r >= 1 - 2^-39)
-  t.errk = t.err + 0x1p-22 * M[2] * (1.0 + 0x1p-20);
+  // The kernel accepts a pixel iff |frac| + errk * r < 1/2 with r = (1 +- 2^-39) / h.z.  errk * r covers
+  //   err / h.z                      the error of h.x, h.y,
+  //   2^16 * errz / h.z              that of h.z, times |u| < 2^16 (beyond that both are outside any map),
+  //   2^-22                          the slack of DESIGN.md 4.4, because Sz bounds |h.z| everywhere in the grid
+  //                                  (Sz * r >= 1 - 2^-39).
+  t.errk = (t.err + 65536.0 * t.errz) + 0x1p-22 * Sz * (1.0 + 0x1p-20);
   t.depth = r.depth;
   return t;
 }
 
 // Preconditions of the tiled kernel (fusion_tile.hip header); otherwise the general kernel runs.
+// The part that does not depend on the view; the per-view part is view_tile_ok (add_views_impl).
 bool tile_eligible(const dmi_context *ctx) {
   if (ctx->opt.kernel_variant & dmi::VAR_FORCE_GENERAL) return false;
   if (!ctx->finite_bounded) return false;  // any grid matrix: axis-aligned or rotated (TileArgs::rotated)
-  if (ctx->k_mode < (int)dmi::K_PINHOLE_SKEW) return false;
   if (!(ctx->ray.thickness >= 0) || !(ctx->ray.delta >= 0)) return false;
   if ((int64_t)ctx->W * ctx->H * (int64_t)(ctx->depth_f64 ? 8 : 4) >= (int64_t(1) << 31)) return false;
-  // pixel selection must be provable for nearly every lane: err / c.z must stay far below one pixel
-  if (!(ctx->max_tile_err < 0x1p-14)) return false;
   return true;
 }
 
@@ -427,11 +452,16 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     r.depth = static_cast<const char *>(b.d_depth) + (size_t)m * npix * esz;
     r.pyramid = b.d_pyramid + (size_t)m * ctx->pyramid.total_tiles;
     ctx->h_maps.push_back(r);
+    bool finite = true;
+    for (int q = 0; q < 12; ++q) finite = finite && bounded(r.k[q]) && bounded(r.rt[q]);
     const int km = classify_k(r.k, r.rt);
     if (km < ctx->k_mode) ctx->k_mode = km;
     const TileMapRec t = make_tile_rec(ctx, r);
     ctx->h_tile_maps.push_back(t);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
+    ctx->view_k_mode.push_back((uint8_t)km);
+    // pixel selection must be provable for nearly every lane: the error bounds over h.z must stay far below one pixel
+    ctx->view_tile_ok.push_back(finite && t.err < 0x1p-14 && 65536.0 * t.errz < 0x1p-14 ? 1 : 0);
   }
   ctx->maps_dirty = true;
   ctx->timings.last_upload_ms =
@@ -717,6 +747,8 @@ int dmi_clear_views(dmi_context *ctx) {
   ctx->batches.clear();
   ctx->h_maps.clear();
   ctx->h_tile_maps.clear();
+  ctx->view_k_mode.clear();
+  ctx->view_tile_ok.clear();
   ctx->max_tile_err = 0.0;
   ctx->maps_dirty = true;
   ctx->W = ctx->H = 0;
@@ -787,12 +819,42 @@ int dmi_fuse_slab(dmi_context *ctx, int32_t z_first, int32_t z_count) {
 }
 
 namespace {
+int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, int32_t z_count, bool tiled, int run_k_mode,
+             bool general_k);
+
+// Views [first, first + count) into the cell layers [z_first, z_first + z_count).  The reference handles any 4x4 K at
+// one speed (cu:176); here the register-tiled kernel takes every view that meets its per-view preconditions (a K with a
+// general third row through its GENK instantiation) and the general kernel the rest: maximal runs of consecutive views
+// of one kind, launched in view order, so every voxel still accumulates its views in order (cu:211).  An f32 grid is
+// rounded once per launch, i.e. once per run.
 int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, int32_t z_count) {
   const int32_t n_views = (int32_t)ctx->h_maps.size();
   if (n_views == 0) return fail(ctx, DMI_ERR_STATE, "dmi_fuse: no views resident (call dmi_add_views first)");
   if (first < 0 || count < 0 || first > n_views || count > n_views - first)
     return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range: range outside the resident views");
   if (count == 0) return DMI_OK;
+  const bool tile_possible = tile_eligible(ctx);
+  int32_t m = first;
+  while (m < first + count) {
+    const bool tiled = tile_possible && ctx->view_tile_ok[(size_t)m];
+    int32_t e = m;
+    int km = dmi::K_PINHOLE;
+    bool general_k = false;
+    while (e < first + count && (tile_possible && ctx->view_tile_ok[(size_t)e]) == tiled) {
+      km = std::min(km, (int)ctx->view_k_mode[(size_t)e]);
+      general_k = general_k || ctx->view_k_mode[(size_t)e] == dmi::K_GENERAL;
+      ++e;
+    }
+    const int rc = fuse_run(ctx, m, e - m, z_first, z_count, tiled, km, general_k);
+    if (rc != DMI_OK) return rc;
+    m = e;
+  }
+  return DMI_OK;
+}
+
+int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, int32_t z_count, bool tiled, int run_k_mode,
+             bool general_k) {
+  const int32_t n_views = (int32_t)ctx->h_maps.size();
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
   int rc = sync_maps(ctx);
   if (rc != DMI_OK) return rc;
@@ -842,11 +904,12 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   FuseConfig cfg;
   cfg.depth_is_f64 = ctx->depth_f64 ? 1 : 0;
   cfg.grid_is_f64 = ctx->opt.grid_dtype == DMI_F64 ? 1 : 0;
-  cfg.k_mode = ctx->k_mode;
+  cfg.k_mode = run_k_mode;
   cfg.count_hits = ctx->opt.count_hits ? 1 : 0;
   cfg.variant = ctx->opt.kernel_variant;
 
-  cfg.use_tile = tile_eligible(ctx) ? 1 : 0;
+  cfg.use_tile = tiled ? 1 : 0;
+  cfg.general_k = tiled && general_k ? 1 : 0;
   // Tile shape when the caller did not pick one: grids up to 512^3 do better with 8-voxel columns at five waves per
   // SIMD (more, smaller work items and a finer brick classification: 0.65 vs 0.74 ms at 256^3 x 64 views, 11.2 vs 11.5
   // ms at 512^3 x 256), 1024^3 with 16-voxel columns (15.5 vs 17.7 ms at 1024^3 x 64: the classification of twice as
@@ -859,7 +922,7 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   TileArgs t;
   std::memset(&t, 0, sizeof(t));
   if (cfg.use_tile) {
-    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64, !grid_axis_aligned(ctx->grid));
+    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64, !grid_axis_aligned(ctx->grid) || cfg.general_k);
     t.nx = a.nx; t.ny = a.ny; t.nz = a.nz; t.W = a.W; t.H = a.H;
     t.first_map = first; t.n_maps = count; t.init_from_grid = a.init_from_grid;
     t.kpad = (a.nz + sh.tk - 1) / sh.tk * sh.tk;
@@ -1244,7 +1307,10 @@ int dmi_get_info(dmi_context *ctx, dmi_info *out) {
   out->grid_dtype = ctx->opt.grid_dtype;
   out->k_mode = (ctx->opt.kernel_variant & 2) ? 0 : ctx->k_mode;
   out->kernel_variant = ctx->opt.kernel_variant;
-  out->tiled_kernel = (ctx->h_maps.empty() ? 0 : (tile_eligible(ctx) ? 1 : 0));
+  // 1: every resident view takes the register-tiled kernel; 0: at least one run goes through the general kernel
+  bool all_tiled = !ctx->h_maps.empty() && tile_eligible(ctx);
+  for (uint8_t ok : ctx->view_tile_ok) all_tiled = all_tiled && ok;
+  out->tiled_kernel = all_tiled ? 1 : 0;
   out->device_bytes = ctx->device_bytes;
   return DMI_OK;
   });

@@ -280,6 +280,9 @@ template <int kQueryTiles, bool ROT>
 __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
                                                 const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
                                                 int j0, int j1, int k0, int k1) {
+  // a K whose third row is not 0 0 1 0 (h.z != c.z, cu:176): nothing is proven for such a view, every pair takes the
+  // per-voxel path of the fusion kernel's GENK instantiation
+  if (tr->errz != 0.0) return BRICK_MIXED;
   const BoxFootprint fp = box_footprint<ROT>(a, mr, tr, i0, i1, j0, j1, k0, k1);
   if (!fp.query) return fp.cls;
   return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
@@ -374,10 +377,20 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
     tr_u.qx = cload(&tsrc->qx); tr_u.qy = cload(&tsrc->qy); tr_u.qz = cload(&tsrc->qz); tr_u.q0 = cload(&tsrc->q0);
     tr_u.err = cload(&tsrc->err);
     tr_u.cz_err = cload(&tsrc->cz_err);
+    tr_u.errz = cload(&tsrc->errz);
     mr = &mr_u;
-    if (mine) fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+    if (tr_u.errz != 0.0) {  // general K: unproven, see classify_box
+      fp.cls = BRICK_MIXED;
+    } else if (mine) {
+      fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+    }
   } else {
-    if (mine) fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+    if (mine) {
+      if (a.tile_maps[m].errz != 0.0)
+        fp.cls = BRICK_MIXED;
+      else
+        fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+    }
   }
   const bool query = mine && fp.query;
   uint8_t cls = fp.cls;

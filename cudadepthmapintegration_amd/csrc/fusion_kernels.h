@@ -55,9 +55,12 @@ struct alignas(16) TileMapRec {
   const void *depth;       // same table as MapRec::depth
   double cz_err;           // rotated grids: bound on |computed c.z - real c.z| (0 for axis-aligned grids, where the
                            // computed c.z is monotone in every index and needs no margin)
-  double errk;             // what the fusion kernel multiplies by 1/c.z in its acceptance test: err plus 2^-22 times a
-                           // bound on c.z over the grid, so that errk/c.z >= err/c.z + 2^-22 and the test compares with 1/2
-  double pad[7];
+  double errk;             // what the fusion kernel multiplies by 1/h.z in its acceptance test: err, 2^16 * errz and 2^-22
+                           // times a bound on h.z over the grid, so that the test compares with the constant 1/2
+  // general K (third row not 0 0 1 0, cu:176): h.z ~ sx*wx + sy*wy + sz*wz + s0 (row 2 of K*[R|T]) and its step per
+  // voxel along k; errz bounds |h.z_ref - h.z_affine|.  For a pinhole K these restate RT row 2 and errz is 0.
+  double sx, sy, sz, s0, dhz, errz;
+  double pad;
 };
 static_assert(sizeof(TileMapRec) == 192, "TileMapRec layout");
 
@@ -157,6 +160,7 @@ struct FuseConfig {
   int count_hits;
   int variant;   // tuning variant bits, see launch_fuse / launch_fuse_tiled
   int use_tile;  // host decision: the tiled kernel's preconditions hold
+  int general_k; // tiled kernel: some view of the fused range has a K whose third row is not 0 0 1 0 (GENK instantiation)
 };
 
 // tuning-variant bits (dmi_options::kernel_variant)
@@ -178,7 +182,7 @@ enum VariantBits : int {
 struct TileShape {
   int tk, wx, wy;  // column height; waves per workgroup along x and y (a wave is 8 x 8 lanes)
 };
-TileShape tile_shape(int variant, bool depth_is_f64, bool rotated);
+TileShape tile_shape(int variant, bool depth_is_f64, bool rotated_or_general_k);  // those run the two default shapes only
 
 // Enqueues the general fusion kernel on `stream`.  Returns hipSuccess or the launch error.
 hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t stream);

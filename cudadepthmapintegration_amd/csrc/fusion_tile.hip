@@ -205,7 +205,12 @@ constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw
 // w = ((g_r0*gx + g_r1*gy) + g_r2*gz) + g_r3 from a per-lane part and the per-k products of the wk table, then
 // c.z = ((r20*wx + r21*wy) + r22*wz) + r23, every operation the reference's (cu:90-92, cu:168, cu:172): 12 VALU
 // operations per voxel-projection instead of 2.  Everything else is shared with the axis-aligned path.
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false>
+// GENK: some view of the launch has a K whose third row is not 0 0 1 0 (cu:176 in full): h.z is then an affine function
+// of the world position like h.x and h.y (TileMapRec::sx..s0, bound errz), the reciprocal is h.z's, "behind the camera"
+// (cu:177) is proven from h.z -+ errz, and whatever is not proven goes through the exact expression as before.  c.z
+// -- what enters the ray potential -- is exact in every instantiation.  Pinhole views run through the same code: for
+// them h.z restates c.z and errz is 0.
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false, bool GENK = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
   // The argument block is read where it is needed, straight from the kernarg segment (scalar loads), instead of through
@@ -417,6 +422,15 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                          __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
     }
     const double dhx = cload(&rec->dhx), dhy = cload(&rec->dhy), errk = cload(&rec->errk);
+    [[maybe_unused]] double hz = 0, dhz = 0, errz = 0;
+    if constexpr (GENK) {
+      dhz = cload(&rec->dhz);
+      errz = cload(&rec->errz);
+      if constexpr (!ROT) {
+        hz = __builtin_fma(cload(&rec->sx), wx, __builtin_fma(cload(&rec->sy), wy, __builtin_fma(cload(&rec->sz), wz0, cload(&rec->s0))));
+        if (!lane_ok) hz = -__builtin_inf();  // lanes outside the grid: behind the camera (cu:177) at no cost per voxel
+      }
+    }
 
     uint32_t undecided = 0;  // per lane: bit kk set = redo voxel kk of this map exactly
     uint32_t map_hits = 0;   // wave-uniform
@@ -458,21 +472,33 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                                  __builtin_fma(cload(&rec->py), wyk, __builtin_fma(cload(&rec->pz), wzk, cload(&rec->p0))));
               hy = __builtin_fma(cload(&rec->qx), wxk,
                                  __builtin_fma(cload(&rec->qy), wyk, __builtin_fma(cload(&rec->qz), wzk, cload(&rec->q0))));
+              if constexpr (GENK) {
+                hz = __builtin_fma(cload(&rec->sx), wxk,
+                                   __builtin_fma(cload(&rec->sy), wyk, __builtin_fma(cload(&rec->sz), wzk, cload(&rec->s0))));
+                if (!lane_ok) hz = -__builtin_inf();
+              }
             } else {
               hx += dhx;
               hy += dhy;
+              if constexpr (GENK) hz += dhz;
             }
           } else {
+            if constexpr (GENK) {
+              if (kk >= kcount) continue;  // wave-uniform: a voxel above the grid (h.z does not come through the cz table)
+            }
             if (kk > 0) {
               hx += dhx;
               hy += dhy;
+              if constexpr (GENK) hz += dhz;
             }
             if constexpr (!DMI_EXP_CZPRE) czg[q] = (sz + ctq[q]) + rz3;
           }
           const double cz = czg[q];
+          // the divisor of cu:183-184: h.z, which for a pinhole K is c.z itself
+          const double hdiv = GENK ? hz : cz;
           // reciprocal: hardware seed + one Newton step; e0 is the seed's residual, checked below
-          const double r0 = __builtin_amdgcn_rcp(cz);
-          const double e0 = __builtin_fma(-cz, r0, 1.0);
+          const double r0 = __builtin_amdgcn_rcp(hdiv);
+          const double e0 = __builtin_fma(-hdiv, r0, 1.0);
           const double r = __builtin_fma(r0, e0, r0);
           const double ua = hx * r, va = hy * r;
           // nearest integers (ties never accepted, so RNE vs the reference's half-away does not matter)
@@ -506,6 +532,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot is one v_cmp, all the logic
           // between them runs on the scalar unit.
           mask_t m_in, m_und;
+          [[maybe_unused]] mask_t m_proven_front = ~0ull;
           if constexpr (INTERIOR) {
             // The classification has proven, for EVERY voxel of this brick and this view, that the reference's c.z is
             // positive and its rounded pixel inside the depth map (box_footprint: fp.query).  A proven lane's
@@ -514,10 +541,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             m_in = m_proven & m_lane_ok;
             m_und = m_lane_ok & ~m_proven;
           } else {
-            const mask_t m_front = ballot(!(cz < 0.0));  // cu:177: not behind the camera
+            // cu:177.  Pinhole: c.z is the reference's own h.z, the test is exact.  General K: h.z is within errz of the
+            // reference's; beyond -errz the voxel is behind the camera, above +errz in front (then the reciprocal is
+            // positive and the acceptance test above means what it says), in between undecided.
+            const mask_t m_front = GENK ? ballot(!(hz < -errz)) : ballot(!(cz < 0.0));
+            if constexpr (GENK) m_proven_front = ballot(hz > errz);
 #if DMI_EXP_ROUND
             // cu:192-197 on the integers: a saturated conversion (|ru| >= 2^31) is >= 2^31 as unsigned, outside any map
-            m_in = m_front & m_proven & ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
+            m_in = m_front & m_proven & m_proven_front & ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
 #else
             // 0 <= r < W for an integer-valued double r, on its high dword alone: the high dword is monotone in r, W's low
             // dword is zero (W <= 2^20), and negative values have the sign bit set
@@ -526,7 +557,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             asm("" : "+v"(hv));
             m_in = m_front & m_proven & ballot(hu < hiW) & ballot(hv < hiH);
 #endif
-            m_und = m_front & ~m_proven;
+            m_und = m_front & ~(m_proven & m_proven_front);
           }
           if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
           if (__builtin_amdgcn_inverse_ballot_w64(m_in))
@@ -601,7 +632,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         }
       }
     };
-    if (!ROT && kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR))
+    if (!ROT && !GENK && kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR))
       column(std::true_type{});
     else
       column(std::false_type{});
@@ -677,29 +708,37 @@ __global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double 
   table[4 * k + 3] = 0.0;
 }
 
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false>
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   // super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
   const int per_round = 8 * a.xcd_run_wg;
   const unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + per_round - 1) / per_round * per_round);
   const dim3 block(64 * WX * WY);
   if (cfg.count_hits)
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>), dim3(blocks), block, 0, s, a);
   else
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>), dim3(blocks), block, 0, s, a);
   return hipGetLastError();
 }
 
 // Shapes 0 and 7 (the two that dmi_fuse picks by grid size) are built for every storage type; the other (tuning)
 // shapes only for f32 depth tables.
-int effective_shape(int variant, bool depth_is_f64, bool rotated) {
+int effective_shape(int variant, bool depth_is_f64, bool rotated, bool general_k = false) {
   const int shape = tile_shape_index(variant);
-  return ((depth_is_f64 || rotated) && shape != 7) ? 0 : shape;
+  return ((depth_is_f64 || rotated || general_k) && shape != 7) ? 0 : shape;
 }
 
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0);
+  const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0, cfg.general_k != 0);
+  if (cfg.general_k) {  // a general K among the views: the two default shapes, either kind of grid
+    if (a.rotated) {
+      if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true, true>(a, cfg, s);
+      return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true, true>(a, cfg, s);
+    }
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, false, true>(a, cfg, s);
+    return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, true>(a, cfg, s);
+  }
   if (a.rotated) {  // rotated grid: the two default shapes
     if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true>(a, cfg, s);
@@ -760,7 +799,7 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (!(cfg.variant & VAR_NO_BRICK_CLASSES)) {
-    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0);
+    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0 || cfg.general_k != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, stream);
     if (e != hipSuccess) return e;
 #ifdef DMI_TUNING

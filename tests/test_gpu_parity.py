@@ -217,9 +217,10 @@ def test_near_half_pixel_stress_fast_path_equals_exact():
 
 
 def test_tiled_kernel_is_selected_only_when_its_preconditions_hold():
-    """Pinhole K (axis-aligned or rotated grid) -> tiled kernel; general K -> general kernel."""
+    """Pinhole or general K, axis-aligned or rotated grid -> every view through the tiled kernel (the GENK instantiation
+    for a K whose third row is not 0 0 1 0); VARIANT_FORCE_GENERAL -> the general kernel."""
     from conftest import load_golden
-    expect = {"generic_sphere_32": 1, "noncubic_70x33x17": 1, "anisotropic_rotated": 1, "general_k_f64_depth": 0}
+    expect = {"generic_sphere_32": 1, "noncubic_70x33x17": 1, "anisotropic_rotated": 1, "general_k_f64_depth": 1}
     for name, want in expect.items():
         grid, rp, views, thr = _golden_inputs(load_golden(name))
         with capi.FusionContext(grid, rp) as ctx:
@@ -228,6 +229,52 @@ def test_tiled_kernel_is_selected_only_when_its_preconditions_hold():
         with capi.FusionContext(grid, rp, kernel_variant=G) as ctx:
             ctx.add_views(views, thr)
             assert ctx.info().tiled_kernel == 0
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+@pytest.mark.parametrize("count_hits", [True, False])
+def test_views_of_every_kind_in_one_fusion(rotated, count_hits):
+    """The reference takes any 4x4 K at one speed (cu:176).  Here: pinhole, skewed, scaled third row (K[2][2] != 1), a
+    third row that depends on x and y, a fourth column, and one view no fast path can take (a focal length of 1e14: its
+    error bound exceeds the tiled kernel's limit) -- fused in view order by runs (tiled, general kernel, tiled GENK ...),
+    bit-identical to the oracle with exact hit counters, from a zero grid and onto an uploaded one."""
+    grid = scene.default_grid((40, 36, 44), rotated=rotated)
+    rp = scene.default_ray_potential(grid)
+    v = scene.make_views(10, 96, 72, seed=29, dense=True)
+    v.K4[1, 0, 1] = 0.7                      # skew: still a pinhole for the tiled kernel
+    v.K4[2, 2, 2] = 1.25                     # non-unit homogeneous scale
+    v.K4[3, 0, 3] = 3.0                      # 4th column (cu:90-92)
+    v.K4[3, 1, 3] = -2.0
+    v.K4[4, 2, 0] = 0.01                     # h.z depends on x and y
+    v.K4[4, 2, 1] = -0.02
+    v.K4[5, 2, 3] = 0.5                      # h.z offset
+    v.K4[6, 0, 0] = 1e14                     # no fast path: the general kernel takes this view alone
+    v.K4[8, 1, 0] = 0.3                      # h.y depends on c.x
+    init = np.random.default_rng(3).standard_normal(grid.n_voxels)
+    p = oracle_params_from_scene(grid, rp, v)
+    for start in (None, init):
+        want, vh_w, mh_w = oracle.fuse(p, v.depth, v.K4, v.RT4, init_grid=start, n_threads=oracle.max_threads())
+        with capi.FusionContext(grid, rp, count_hits=count_hits) as ctx:
+            if start is not None:
+                ctx.upload_grid(start)
+            ctx.add_views(v)
+            assert ctx.info().tiled_kernel == 0 and ctx.info().k_mode == 0   # one view needs the general kernel
+            ctx.fuse()
+            out = ctx.download_grid()
+            assert bits_equal(out, want)
+            if count_hits:
+                vh, mh = ctx.download_hits()
+                assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w)
+        assert mh_w[2] > 0 and mh_w[4] > 0 and np.abs(want).max() > 0.5
+    # the same views without the one that needs the general kernel: one tiled (GENK) launch; f32 grid = one rounding
+    keep = [m for m in range(10) if m != 6]
+    sub = scene.Views(v.depth[keep], v.K4[keep], v.RT4[keep])
+    want, _, _ = oracle.fuse(oracle_params_from_scene(grid, rp, sub), sub.depth, sub.K4, sub.RT4, n_threads=oracle.max_threads())
+    with capi.FusionContext(grid, rp, grid_dtype="f32") as ctx:
+        ctx.add_views(sub)
+        assert ctx.info().tiled_kernel == 1
+        ctx.fuse()
+        assert np.array_equal(ctx.download_grid(np.float32), want.astype(np.float32))
 
 
 @pytest.mark.parametrize("shape", TILE_SHAPES)
