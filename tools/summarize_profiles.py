@@ -91,7 +91,9 @@ def main():
     sel = [k for k in merged if args.kernel in k]
     for k in sel:
         c = merged[k]
-        lines += [f"## PMC, mean per dispatch: `{k[:100]}`", "", f"resources: {c['_meta']}", ""]
+        lines += [f"## PMC, mean per dispatch: `{k[:100]}`", "", f"resources as rocprofv3 prints them: {c['_meta']}",
+                  "(on gfx950 its VGPR_Count is half of what the kernel descriptor allocates: the build's register audit, "
+                  "build/obj/acc_audit.json, and llvm-readelf give the number of 32-bit registers)", ""]
         g = c.get("GRBM_GUI_ACTIVE")
         if g and kern_ms:
             lines.append(f"* effective clock = GRBM_GUI_ACTIVE / 8 / t = {g / 8 / (kern_ms * 1e-3) / 1e9:.2f} GHz")
@@ -102,8 +104,12 @@ def main():
             if kern_ms:
                 lines.append(f"* VALU issue floor at 4 cycles per fp64-rate wave-instruction on 1024 SIMDs, 2.4 GHz: "
                              f"{v * 4 / 1024 / 2.4e9 * 1e3:.2f} ms of {kern_ms:.2f} ms")
+        if "SQ_INSTS_SALU" in c and kern_ms:
+            sa = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_BRANCH", 0.0) + c.get("SQ_INSTS_SMEM", 0.0)
+            lines.append(f"* scalar-issue floor: SALU + branch + SMEM wave-instructions at one per cycle per CU (the four SIMDs of "
+                         f"a CU share one scalar unit), 256 CUs, 2.4 GHz: {sa / 256 / 2.4e9 * 1e3:.2f} ms of {kern_ms:.2f} ms")
         for name in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
-                     "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                     "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
                      "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "TA_BUSY_avr", "TA_TA_BUSY_sum",
                      "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
             if name in c:
