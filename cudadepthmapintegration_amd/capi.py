@@ -687,7 +687,7 @@ HOST_ABI_SYMBOLS = [
     "dmi_filter_set_ray_potential_eta", "dmi_filter_set_ray_potential_delta", "dmi_filter_set_threshold_best_cost",
     "dmi_filter_set_file_path_krtd", "dmi_filter_set_file_path_vti", "dmi_filter_set_grid_matrix",
     "dmi_filter_set_input_data", "dmi_filter_add_view", "dmi_filter_clear_views", "dmi_filter_set_device",
-    "dmi_filter_set_kernel_variant", "dmi_filter_set_devices", "dmi_filter_set_partition", "dmi_filter_set_host_chunk_bytes", "dmi_filter_update", "dmi_filter_get_execution_time",
+    "dmi_filter_set_kernel_variant", "dmi_filter_set_devices", "dmi_filter_set_partition", "dmi_filter_set_host_chunk_bytes", "dmi_filter_set_fill_on_calling_thread", "dmi_filter_update", "dmi_filter_get_execution_time",
     "dmi_filter_get_fuse_kernel_ms", "dmi_filter_get_number_of_cells", "dmi_filter_get_output",
     "dmi_filter_last_error", "dmi_read_krtd_file", "dmi_extract_all_file_path", "dmi_k3_to_k4",
     "dmi_apply_depth_threshold", "dmi_read_depth_map", "dmi_read_depth_map_color", "dmi_mesh_coloration_from_lists",
@@ -724,6 +724,7 @@ def load_host() -> ctypes.CDLL:
     L.dmi_filter_set_devices.restype, L.dmi_filter_set_devices.argtypes = None, [vp, ip, i32]
     L.dmi_filter_set_partition.restype, L.dmi_filter_set_partition.argtypes = None, [vp, i32]
     L.dmi_filter_set_host_chunk_bytes.restype, L.dmi_filter_set_host_chunk_bytes.argtypes = None, [vp, ctypes.c_uint64]
+    L.dmi_filter_set_fill_on_calling_thread.restype, L.dmi_filter_set_fill_on_calling_thread.argtypes = None, [vp, i32]
     L.dmi_filter_update.restype, L.dmi_filter_update.argtypes = ctypes.c_int, [vp]
     L.dmi_filter_get_execution_time.restype, L.dmi_filter_get_execution_time.argtypes = dbl, [vp]
     L.dmi_filter_get_fuse_kernel_ms.restype, L.dmi_filter_get_fuse_kernel_ms.argtypes = dbl, [vp]
@@ -819,6 +820,7 @@ class ReconstructionFilter:
         self._lib.dmi_filter_set_partition(self._h, {"views": DMI_PARTITION_VIEWS, "z_slabs": DMI_PARTITION_Z_SLABS}[partition])
 
     def SetHostChunkBytes(self, n): self._lib.dmi_filter_set_host_chunk_bytes(self._h, int(n))
+    def SetFillOnCallingThread(self, yes): self._lib.dmi_filter_set_fill_on_calling_thread(self._h, 1 if yes else 0)
     def Update(self) -> int: return int(self._lib.dmi_filter_update(self._h))
     def GetExecutionTime(self) -> float: return float(self._lib.dmi_filter_get_execution_time(self._h))
     def GetFuseKernelMs(self) -> float: return float(self._lib.dmi_filter_get_fuse_kernel_ms(self._h))

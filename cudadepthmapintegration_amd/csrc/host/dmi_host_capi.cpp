@@ -92,6 +92,7 @@ void dmi_filter_set_devices(dmi_filter *f, const int32_t *devices, int32_t n) {
 }
 void dmi_filter_set_partition(dmi_filter *f, int32_t partition) { if (f) f->filter.SetPartition(partition); }
 void dmi_filter_set_host_chunk_bytes(dmi_filter *f, uint64_t bytes) { if (f) f->filter.SetHostChunkBytes((size_t)bytes); }
+void dmi_filter_set_fill_on_calling_thread(dmi_filter *f, int32_t yes) { if (f) f->filter.SetFillOnCallingThread(yes != 0); }
 double dmi_filter_get_execution_time(const dmi_filter *f) { return f ? f->filter.GetExecutionTime() : -1.0; }
 double dmi_filter_get_fuse_kernel_ms(const dmi_filter *f) { return f ? f->filter.GetFuseKernelMs() : 0.0; }
 int64_t dmi_filter_get_number_of_cells(const dmi_filter *f) { return f ? f->filter.GetNumberOfCells() : 0; }

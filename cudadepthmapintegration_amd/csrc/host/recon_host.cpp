@@ -324,13 +324,9 @@ struct Feed {
 
 }  // namespace
 
-// Fills slot `c` of a chunk from view `index`: depth (and best cost when the view has one) in vtk point order, the
-// identity-padded 4x4 K (cu:352) and [R|T] (cu:353).
-using ViewFill = std::function<bool(size_t index, double *depth, double *cost, bool *has_cost, double K4[16], double RT[16],
-                                    std::string *error)>;
+using ViewFill = ViewSource;
 
-bool FusionDriver::Run(size_t n_views, const void *fill_ptr, double thresholdBestCost, double *io_scalar) {
-  const ViewFill &fill = *static_cast<const ViewFill *>(fill_ptr);
+bool FusionDriver::ProcessDepthMap(size_t n_views, const ViewSource &fill, double thresholdBestCost, double *io_scalar) {
   Error.clear();
   if (!Initialized) {
     Error = "ProcessDepthMap: CudaInitialize has not been called";
@@ -445,14 +441,9 @@ bool FusionDriver::Run(size_t n_views, const void *fill_ptr, double thresholdBes
   }
 
   const size_t n_chunks = (n_views + chunk - 1) / chunk;
-  std::thread filler([&]() {
-    for (size_t q = 0; q < n_chunks; ++q) {
+  // fills chunk q (on the filler thread, or on this one just before the chunk is needed)
+  auto fill_chunk = [&](size_t q) {
       Chunk &c = feed.slot[q & 1];
-      {
-        std::unique_lock<std::mutex> hold(feed.lock);
-        feed.changed.wait(hold, [&] { return !c.filled || feed.abandon; });
-        if (feed.abandon) return;
-      }
       c.first = q * chunk;
       c.count = std::min(chunk, n_views - c.first);
       c.failed = false;
@@ -466,18 +457,32 @@ bool FusionDriver::Run(size_t n_views, const void *fill_ptr, double thresholdBes
         }
         c.has_cost[v] = has_cost ? 1 : 0;
       }
-      {
-        std::lock_guard<std::mutex> hold(feed.lock);
-        c.filled = true;
+  };
+  std::thread filler;
+  if (!FillOnCallingThread)
+    filler = std::thread([&]() {
+      for (size_t q = 0; q < n_chunks; ++q) {
+        Chunk &c = feed.slot[q & 1];
+        {
+          std::unique_lock<std::mutex> hold(feed.lock);
+          feed.changed.wait(hold, [&] { return !c.filled || feed.abandon; });
+          if (feed.abandon) return;
+        }
+        fill_chunk(q);
+        {
+          std::lock_guard<std::mutex> hold(feed.lock);
+          c.filled = true;
+        }
+        feed.changed.notify_all();
+        if (c.failed) return;
       }
-      feed.changed.notify_all();
-      if (c.failed) return;
-    }
-  });
+    });
 
   for (size_t q = 0; ok && q < n_chunks; ++q) {
     Chunk &c = feed.slot[q & 1];
-    {
+    if (FillOnCallingThread) {
+      fill_chunk(q);  // the previous chunk's fusion is still running on the device meanwhile
+    } else {
       std::unique_lock<std::mutex> hold(feed.lock);
       feed.changed.wait(hold, [&] { return c.filled; });
     }
@@ -520,7 +525,7 @@ bool FusionDriver::Run(size_t n_views, const void *fill_ptr, double thresholdBes
     feed.abandon = !ok;
   }
   feed.changed.notify_all();
-  filler.join();
+  if (filler.joinable()) filler.join();
   free_chunks();
   if (!ok) {
     destroy();
@@ -570,7 +575,7 @@ bool FusionDriver::ProcessDepthMap(const std::vector<ReconstructionData *> &view
     std::memcpy(RT, d->GetMatrixTR(), 16 * 8);  // cu:353
     return true;
   };
-  return Run(views.size(), &fill, thresholdBestCost, io_scalar);
+  return ProcessDepthMap(views.size(), fill, thresholdBestCost, io_scalar);
 }
 
 bool FusionDriver::ProcessDepthMap(const std::vector<std::string> &vtiList, const std::vector<std::string> &krtdList,
@@ -608,7 +613,7 @@ bool FusionDriver::ProcessDepthMap(const std::vector<std::string> &vtiList, cons
     std::memcpy(RT, data.GetMatrixTR(), 16 * 8);
     return true;
   };
-  return Run(n, &fill, thresholdBestCost, io_scalar);
+  return ProcessDepthMap(n, fill, thresholdBestCost, io_scalar);
 }
 
 // ====================================================================================================
@@ -700,6 +705,7 @@ int ReconstructionFilter::Compute(int gridDims[3], double gridOrig[3], double gr
   driver.SetPartition(Partition);
   driver.SetKernelVariant(KernelVariant);
   driver.SetHostChunkBytes(HostChunkBytes);
+  driver.SetFillOnCallingThread(FillOnCallingThread);
   driver.SetInitialGridIsZero(true);  // RequestData zero-filled outScalar just before (filt.cxx:133)
   bool result;
   if (!Views.empty()) {

@@ -11,6 +11,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,14 @@ class ReconstructionData {
   double MatrixTR[16];
 };
 
+// Where ProcessDepthMap gets view `index` from: fills depth (and best cost when the view has one; *has_cost says so) as
+// W*H doubles in vtk point order, the identity-padded 4x4 K (cu:352) and [R|T] (cu:353); false + *error to abort.
+// Lets a caller keep its own way of reading views -- the VTK binding reads them with the reference's own
+// ReconstructionData / vtkXMLImageDataReader (vtk/vtkCudaReconstructionFilter.cxx) -- and still get the chunked,
+// pinned, overlapped upload.
+using ViewSource = std::function<bool(size_t index, double *depth, double *best_cost, bool *has_cost, double K4[16],
+                                      double RT[16], std::string *error)>;
+
 // ---- Reconstruction/CudaReconstruction.cu host driver -------------------------------------------------
 // The reference keeps the grid description in global __constant__ state between the two calls (cu:55-64);
 // here it lives in an object.  One FusionDriver = one CudaInitialize + ProcessDepthMap pair.
@@ -109,6 +118,13 @@ class FusionDriver {
   bool ProcessDepthMap(const std::vector<std::string> &vtiList, const std::vector<std::string> &krtdList,
                        double thresholdBestCost, double *io_scalar);
 
+  // the general form behind both: n_views views, each produced by `source` when its chunk is being filled
+  bool ProcessDepthMap(size_t n_views, const ViewSource &source, double thresholdBestCost, double *io_scalar);
+  // true: views are produced on the thread that called ProcessDepthMap (for sources that must not run on another
+  // thread; the fusion of a chunk still overlaps the filling of the next, only its host-to-device copy does not).
+  // Default false: a second thread fills chunk i+1 while chunk i is copied and fused.
+  void SetFillOnCallingThread(bool yes) { FillOnCallingThread = yes; }
+
   void SetDevice(int device) { Device = device; }
   // Several GPUs of the node for ONE fusion (none in the reference; north star: depth maps shard across the GPUs, one
   // RCCL all-reduce of the float TSDF grid).  Empty = single GPU (SetDevice).  Non-empty: ProcessDepthMap runs through
@@ -133,8 +149,7 @@ class FusionDriver {
   int DepthDims[2];
   bool Initialized = false;
   bool InitialGridIsZero = false;
-  // the driver loop behind both ProcessDepthMap forms: n_views views produced by *fill (a ViewFill, recon_host.cpp)
-  bool Run(size_t n_views, const void *fill, double thresholdBestCost, double *io_scalar);
+  bool FillOnCallingThread = false;
 
   int Device = 0;
   std::vector<int> Devices;
@@ -186,6 +201,7 @@ class ReconstructionFilter {
   void SetDevices(const std::vector<int> &devices) { Devices = devices; }
   void SetPartition(int partition) { Partition = partition; }
   void SetHostChunkBytes(size_t bytes) { HostChunkBytes = bytes < 1 ? 1 : bytes; }  // FusionDriver::SetHostChunkBytes
+  void SetFillOnCallingThread(bool yes) { FillOnCallingThread = yes; }               // FusionDriver::SetFillOnCallingThread
   void SetKernelVariant(int v) { KernelVariant = v; }
   double GetFuseKernelMs() const { return FuseKernelMs; }
 
@@ -211,6 +227,7 @@ class ReconstructionFilter {
   std::vector<int> Devices;
   int Partition = DMI_PARTITION_VIEWS;
   size_t HostChunkBytes = size_t(256) << 20;
+  bool FillOnCallingThread = false;
   double FuseKernelMs = 0.0;
 };
 

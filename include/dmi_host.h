@@ -47,6 +47,10 @@ void dmi_filter_set_partition(dmi_filter *f, int32_t partition);
  * whatever the number of views -- the list files are read chunk by chunk, as the reference reads them view by view
  * inside its loop (cu:343-353). */
 void dmi_filter_set_host_chunk_bytes(dmi_filter *f, uint64_t bytes);
+/* != 0: views are read / copied into the staging chunks on the thread that calls Update() (what the VTK binding uses,
+ * vtk/vtkCudaReconstructionFilter.cxx: its view source creates VTK readers); 0 (default): on a second thread, while the
+ * previous chunk is copied to the device. */
+void dmi_filter_set_fill_on_calling_thread(dmi_filter *f, int32_t yes);
 /* Update() -> RequestData (filt.cxx:96-151): 1 on success, 0 on error */
 int dmi_filter_update(dmi_filter *f);
 double dmi_filter_get_execution_time(const dmi_filter *f);            /* filt.h:81 */

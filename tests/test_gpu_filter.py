@@ -47,17 +47,21 @@ def test_filter_in_memory_views_bit_exact(rotated):
     assert bits_equal(out, _oracle(grid, rp, views, thr))
 
 
-def test_filter_from_list_files_bit_exact(tmp_path):
-    """The reference's own input form: vtiList.txt + krtdList.txt next to the files they name."""
+@pytest.mark.parametrize("fill_on_calling_thread", [False, True])
+def test_filter_from_list_files_bit_exact(tmp_path, fill_on_calling_thread):
+    """The reference's own input form: vtiList.txt + krtdList.txt next to the files they name; chunks of two views,
+    filled by the second thread (default) or on the calling thread (what the VTK binding uses)."""
     grid = scene.default_grid((24, 20, 16))
     rp = scene.default_ray_potential(grid)
-    views = scene.make_views(3, 48, 36, seed=4, dense=True, with_best_cost=True)
+    views = scene.make_views(5, 48, 36, seed=4, dense=True, with_best_cost=True)
     lv, lk = scene.write_view_files(str(tmp_path), views)
     thr = 0.7
     with capi.ReconstructionFilter() as f:
         _configure(f, grid, rp, thr)
         f.SetFilePathVTI(lv)
         f.SetFilePathKRTD(lk)
+        f.SetHostChunkBytes(2 * 48 * 36 * 16)
+        f.SetFillOnCallingThread(fill_on_calling_thread)
         assert f.Update() == 1, f.LastError()
         out = f.GetOutputScalars()
     assert bits_equal(out, _oracle(grid, rp, views, thr))
