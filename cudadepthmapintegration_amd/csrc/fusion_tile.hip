@@ -45,28 +45,6 @@ namespace {
 constexpr int kLX = 8, kLY = 8;                   // lanes of a wave over (i, j)
 typedef unsigned long long mask_t;
 
-// Experiment switches of the column (tools/gpu_exp.sh builds one library per combination; the defaults are what ships)
-#ifndef DMI_EXP_ARGS
-#define DMI_EXP_ARGS 1    // 1: argument block read through the kernarg pointer, hot values pinned; 0: by-value parameter
-#endif
-#ifndef DMI_EXP_ROUND
-#define DMI_EXP_ROUND 1   // 1: v_rndne + v_cvt_i32, integer range tests; 0: magic-number adds, high-dword range tests
-#endif
-#ifndef DMI_EXP_CHK
-#define DMI_EXP_CHK 1     // 1: reciprocal residual folded into the acceptance value, one compare with 0.5; 0: two compares
-#endif
-#ifndef DMI_EXP_PHASEB
-#define DMI_EXP_PHASEB 1  // 1: class adds under possibly empty masks; 0: a test and a branch per class
-#endif
-#ifndef DMI_EXP_PB2
-#define DMI_EXP_PB2 1     // 1: phase B compares diff with -delta and +delta; 0: |diff| with delta, then the sign
-#endif
-#ifndef DMI_EXP_PINPTR
-#define DMI_EXP_PINPTR 0  // 1: the two per-view table pointers and the cz row pitch stay in SGPRs; 0: re-read per view
-#endif
-#ifndef DMI_EXP_CZPRE
-#define DMI_EXP_CZPRE 1   // 1: the group's exact c.z first; 0: inside each projection
-#endif
 
 // EXEC-masked accumulates with the running sums pinned to fixed VGPR pairs (generated; see the script for why)
 #include "fusion_tile_acc.inc"
@@ -217,20 +195,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // the by-value parameter: the view loop below has no scalar registers to spare, and what it does not use must not stay
   // live across it.  KA(f): a plain load (the compiler may keep it); KC(f): a load the compiler cannot hoist or merge
   // (the pointer goes through an opaque asm), for fields used once per view, after the loop or on rare paths.
-#if DMI_EXP_ARGS
   typedef const TileArgs __attribute__((address_space(4))) *kernarg_t;
   const kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   (void)a;
 #define KA(f) (ka->f)
 #define KC(f) (launder(ka)->f)
 #define KFRESH() launder(ka)
-#else
-  typedef const TileArgs *kernarg_t;
-  const kernarg_t ka = &a;
-#define KA(f) (a.f)
-#define KC(f) (a.f)
-#define KFRESH() ka
-#endif
   constexpr int BASE = acc_base(MINW);
   constexpr int kGroup = GROUP;
   typedef double czvec __attribute__((ext_vector_type(GROUP)));
@@ -309,31 +279,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   int keep_zero_adds = KA(behind_mask) == 0 ? 1 : 0;
   // Values, not loads: without this the compiler re-reads them from the argument block (a scalar load and a wait) next
   // to every use.  The two thresholds and the slope only ever meet per-lane operands: they live in VGPRs.
-#if DMI_EXP_ARGS
   free_space = pinned(free_space), rho_pos = pinned(rho_pos);
   keep_zero_adds = pinned_word(keep_zero_adds);
   asm volatile("" : "+v"(delta), "+v"(thick), "+v"(slope));
-#endif
-  [[maybe_unused]] double resid_limit = 0x1p-20;  // |1 - cz*r0| below this => |1 - cz*r| < 2^-39
-#if DMI_EXP_CHK == 2
-  resid_limit = pinned(resid_limit);
-#endif
-#if DMI_EXP_ARGS && DMI_EXP_PINPTR
-  // where a view's record and its row of the cz table are: in SGPRs, so that both loads of a view go out at once (read
-  // per view from the argument block they would be a second, dependent round trip to the scalar cache at the head of
-  // every view)
-  const TileMapRec *const tile_maps = pinned_ptr(KA(tile_maps));
-  const double *const cz_table = pinned_ptr(KA(cz_table));
-  const int kpad = pinned_word(KA(kpad));
-#endif
   unsigned vW = (unsigned)KA(W), vH = (unsigned)KA(H);
   asm("" : "+v"(vW));
   asm("" : "+v"(vH));
-  [[maybe_unused]] uint32_t hiW = (uint32_t)__double2hiint((double)KA(W)), hiH = (uint32_t)__double2hiint((double)KA(H));
-#if !DMI_EXP_ROUND
-  asm("" : "+v"(hiW));
-  asm("" : "+v"(hiH));
-#endif
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
   // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
@@ -389,13 +340,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       continue;
     }
     const kernarg_t kv = KFRESH();                              // this view's reads of the argument block
-#if DMI_EXP_ARGS && DMI_EXP_PINPTR
-    const TileMapRec *rec = tile_maps + m;                      // wave-uniform -> scalar loads
-    const double *ct = cz_table + (int64_t)m * kpad + k0;       // r22*wz(k), wave-uniform
-#else
     const TileMapRec *rec = kv->tile_maps + m;                  // wave-uniform -> scalar loads
     const double *ct = kv->cz_table + (int64_t)m * kv->kpad + k0;  // r22*wz(k), wave-uniform
-#endif
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&rec->depth)), (short)0, kv->depth_bytes, 0x00020000);
 
@@ -446,9 +392,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // Every lane starts from the "no depth" sentinel and only the lanes that are in the map load over it: phase B then
         // needs no mask from phase A (eight lane masks = sixteen SGPRs the loop does not have), cu:202 covers both.
         typename DL::raw_t dg[kGroup];
-        [[maybe_unused]] czvec ctq = {};
-        if constexpr (!ROT && !DMI_EXP_CZPRE) ctq = cload(reinterpret_cast<const czvec *>(ct + g0));
-        if constexpr (!ROT && DMI_EXP_CZPRE) {
+                if constexpr (!ROT) {
           // exact c.z of the group's voxels first (cu:92, cu:172; h.z == c.z for a pinhole K): r22*wz(k) comes as one
           // scalar load for the group and its sixteen SGPRs are free again before the projections start
           const czvec ctg = cload(reinterpret_cast<const czvec *>(ct + g0));
@@ -491,7 +435,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               hy += dhy;
               if constexpr (GENK) hz += dhz;
             }
-            if constexpr (!DMI_EXP_CZPRE) czg[q] = (sz + ctq[q]) + rz3;
           }
           const double cz = czg[q];
           // the divisor of cu:183-184: h.z, which for a pinhole K is c.z itself
@@ -502,17 +445,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const double r = __builtin_fma(r0, e0, r0);
           const double ua = hx * r, va = hy * r;
           // nearest integers (ties never accepted, so RNE vs the reference's half-away does not matter)
-#if DMI_EXP_ROUND
           const double ru = __builtin_rint(ua), rv = __builtin_rint(va);
           const int px = cvt_saturating(ru), py = cvt_saturating(rv);
-#else
-          constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: x + kMagic rounds x to an integer (RNE)
-          const double tu = ua + kMagic, tv = va + kMagic;
-          const double ru = tu - kMagic, rv = tv - kMagic;
-          const int px = __double2loint(tu), py = __double2loint(tv);  // two's complement below 2^31
-#endif
           const double fu = ua - ru, fv = va - rv;  // exact: signed distance to the chosen integer
-#if DMI_EXP_CHK == 1
           // Accepted iff |frac| + (bound on |u_ref - ua|) < 1/2, a bound that holds only with a good reciprocal: the seed's
           // residual |e0| must be below 2^-20, i.e. |e0| * 2^19 below 1/2 -- it joins the maximum, so ONE compare against an
           // inline constant decides (errk includes the 2^-22 of DESIGN.md 4.4, scaled so that errk * r covers it).  A NaN
@@ -520,15 +455,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const double resid = __builtin_ldexp(__builtin_fabs(e0), 19);
           const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)), resid));
           const mask_t m_proven = ballot(chk < 0.5);
-#elif DMI_EXP_CHK == 2
-          // one VALU instruction fewer than folding the residual in: its own compare against 2^-20 (a pinned SGPR pair),
-          // the acceptance value against the inline constant 0.5 (errk carries the 2^-22 of DESIGN.md 4.4)
-          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
-          const mask_t m_proven = ballot(__builtin_fabs(e0) < resid_limit) & ballot(chk < 0.5);
-#else
-          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
-          const mask_t m_proven = ballot(__builtin_fabs(e0) < 0x1p-20) & ballot(chk < 0.5 - 0x1p-22);
-#endif
           // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot is one v_cmp, all the logic
           // between them runs on the scalar unit.
           mask_t m_in, m_und;
@@ -546,17 +472,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             // positive and the acceptance test above means what it says), in between undecided.
             const mask_t m_front = GENK ? ballot(!(hz < -errz)) : ballot(!(cz < 0.0));
             if constexpr (GENK) m_proven_front = ballot(hz > errz);
-#if DMI_EXP_ROUND
             // cu:192-197 on the integers: a saturated conversion (|ru| >= 2^31) is >= 2^31 as unsigned, outside any map
             m_in = m_front & m_proven & m_proven_front & ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
-#else
-            // 0 <= r < W for an integer-valued double r, on its high dword alone: the high dword is monotone in r, W's low
-            // dword is zero (W <= 2^20), and negative values have the sign bit set
-            uint32_t hu = (uint32_t)__double2hiint(ru), hv = (uint32_t)__double2hiint(rv);
-            asm("" : "+v"(hu));
-            asm("" : "+v"(hv));
-            m_in = m_front & m_proven & ballot(hu < hiW) & ballot(hv < hiH);
-#endif
             m_und = m_front & ~(m_proven & m_proven_front);
           }
           if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
@@ -575,7 +492,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const mask_t m_hit = ballot(!DL::is_sentinel(d));  // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike
           if (m_hit) {  // wave-uniform: skip the potential when no lane accumulates
             const double diff = czg[q] - DL::widen(d);  // cu:108
-#if DMI_EXP_PHASEB && DMI_EXP_PB2
             // cu:114-115 as two signed compares: diff < -delta is "far in front" (-eta*rho), diff > delta "far behind" (+0);
             // a NaN diff fails both and ends, as in the reference, in the last else branch (cu:119)
             const mask_t m_front_far = ballot(diff < -delta);  // (also set on lanes that did not hit: masked below)
@@ -592,38 +508,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               // the rest, a NaN diff included, is the reference's else branch: (rho/thick)*diff (cu:119)
               acc_add_v<BASE, TK>(kk, m_near & ~m_plat, slope * diff);
             }
-#elif DMI_EXP_PHASEB
-            const mask_t m_farv = ballot(__builtin_fabs(diff) > delta);  // cu:114 (also set on lanes that did not hit)
-            const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
-            acc_add_s<BASE, TK>(kk, m_hit & m_farv & ~m_pos, free_space);  // -eta*rho (cu:115)
-            // + 0 (cu:115) matters only where a sum can be -0.0: never, when the grid started at +0.0 (behind_mask set)
-            if (keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_farv & m_pos);
-            const mask_t m_near = m_hit & ~m_farv;
-            if (m_near) {
-              const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
-              acc_add_s<BASE, TK>(kk, m_plat & m_pos, rho_pos);                       // rho * +1 (cu:117)
-              acc_sub_s<BASE, TK>(kk, m_plat & ~m_pos, rho_pos);                      // rho * -1
-              // the rest, a NaN diff included, is the reference's else branch: (rho/thick)*diff (cu:119)
-              acc_add_v<BASE, TK>(kk, m_near & ~m_plat, slope * diff);
-            }
-#else
-            const mask_t m_far = m_hit & ballot(__builtin_fabs(diff) > delta);  // cu:114
-            const mask_t m_pos = ballot(diff > 0);  // cu:115, and the sign of cu:112
-            if (m_far) {
-              const mask_t m_free = m_far & ~m_pos, m_zero = m_far & m_pos;
-              if (m_free) acc_add_s<BASE, TK>(kk, m_free, free_space);              // -eta*rho (cu:115)
-              if (keep_zero_adds && m_zero) acc_add_zero<BASE, TK>(kk, m_zero);      // + 0 (cu:115): -0.0 + 0.0 = +0.0
-            }
-            const mask_t m_near = m_hit & ~m_far;
-            if (m_near) {
-              const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
-              const mask_t m_ramp = m_near & ~m_plat;  // includes a NaN diff, as the reference's else branch
-              const mask_t m_pp = m_plat & m_pos, m_pn = m_plat & ~m_pos;
-              if (m_pp) acc_add_s<BASE, TK>(kk, m_pp, rho_pos);           // rho * +1 (cu:117)
-              if (m_pn) acc_sub_s<BASE, TK>(kk, m_pn, rho_pos);           // rho * -1
-              if (m_ramp) acc_add_v<BASE, TK>(kk, m_ramp, slope * diff);  // (rho/thick)*diff (cu:119)
-            }
-#endif
             if (COUNT) {
               nh[kk] += __builtin_amdgcn_inverse_ballot_w64(m_hit) ? 1u : 0u;
               map_hits += (uint32_t)__popcll(m_hit);

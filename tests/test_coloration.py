@@ -150,3 +150,34 @@ def test_gpu_matches_committed_coloration_fixture():
     mean, median, count = capi.color_mesh(g["points"], g["colors"], g["K4"], g["RT4"])
     assert np.array_equal(mean, g["expected_mean"]) and np.array_equal(median, g["expected_median"])
     assert np.array_equal(count, g["expected_count"])
+
+
+@pytest.mark.gpu
+def test_gpu_coloration_at_config5_scale():
+    """BASELINE configs[4]'s coloration pass at one GPU's share: 64 views of 1920x1080 resident, 1 M mesh vertices (several
+    chunks of the 1 GiB scratch budget would be needed at 512 views; here one).  All three outputs of a 12 000-vertex
+    sample -- spread over the whole vertex range, so every part of every chunk is probed -- match the oracle exactly, and
+    the whole result obeys what the arithmetic implies (count <= views; mean and median 0 where count is 0)."""
+    n, W, H, nv = 64, 1920, 1080, 1_000_000
+    views = scene.make_views(n, 8, 8, seed=41)                 # cameras only
+    K4 = views.K4.copy()
+    K4[:, 0, 0] = K4[:, 1, 1] = 0.9 * W
+    K4[:, 0, 2], K4[:, 1, 2] = W / 2.0, H / 2.0
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([(xx * 3 + yy * 7) % 256, (xx * 5 + yy * 11 + 80) % 256, (xx ^ yy) % 256], axis=-1).astype(np.uint8)
+    colors = np.empty((n, H, W, 3), dtype=np.uint8)
+    for m in range(n):                                         # a different image per view, cheap to make
+        colors[m] = np.roll(base, shift=(13 * m, 29 * m), axis=(0, 1)) + np.uint8(3 * m)
+    pts = scene.make_mesh_points(nv, seed=42)
+    with capi.ColorContext() as c:
+        c.add_views(colors, K4, views.RT4)
+        mean, median, count = c.process(pts)
+        assert c.kernel_ms() > 0
+    assert count.max() <= n and count.min() >= 0 and count.mean() > n / 4
+    none = count == 0
+    assert not mean[none].any() and not median[none].any()
+    ids = np.unique(np.concatenate([np.arange(0, nv, 83), np.array([0, nv - 1])]))
+    assert len(ids) >= 12000
+    want = oracle.color_mesh(pts[ids], colors, K4, views.RT4)
+    for got, w in zip((mean[ids], median[ids], count[ids]), want):
+        assert np.array_equal(got, w)
