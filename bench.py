@@ -131,7 +131,8 @@ def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int 
     with capi.ColorContext() as c:
         c.add_views(colors, K4, views.RT4)
         c.process(pts[:1000])   # warm-up
-        for name, p in (("random_vertices", pts), ("mesh_ordered_vertices", ordered)):
+        for name, p in (("random_vertices", pts), ("mesh_ordered_vertices", ordered), ("random_vertices_reordered_on_device", pts)):
+            c.set_vertex_reorder(name.endswith("on_device"))   # dmi_color_set_vertex_reorder: Z-order processing inside the library
             t0 = time.perf_counter()
             mean, median, count = c.process(p)
             dt = time.perf_counter() - t0
@@ -206,9 +207,20 @@ def self_launch(n: int) -> int:
                    MASTER_PORT=str(port), DMI_BENCH_LAUNCHED_BY="bench.py")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies takes the others with it (they would wait in the rendezvous for ever): poll, do not just wait
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = max(rc, abs(code))
+                for q in alive:
+                    q.terminate()       # the exact processes this launcher started
+        time.sleep(0.2)
     return rc
 
 
@@ -273,7 +285,7 @@ def main():
     if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the fusion path has no CPU fallback")
     n_ranks = args.gpus  # ranks of the fusion = GPUs, however they are spread over processes
-    if (args.one_process and n_dev < args.gpus) or local_rank >= n_dev:
+    if n_dev < args.gpus or local_rank >= n_dev:   # one node: every rank sees every GPU, so every rank decides alike
         raise SystemExit(f"bench.py: {args.gpus} GPUs asked for, {n_dev} visible")
     have_torch_gpu = torch.cuda.is_available()
     if have_torch_gpu:

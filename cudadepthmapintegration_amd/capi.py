@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
     "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram",
-    "dmi_color_set_scratch_budget",
+    "dmi_color_set_scratch_budget", "dmi_color_set_vertex_reorder",
     "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_create",
     "dmi_multi_get_unique_id", "dmi_multi_create_rank", "dmi_multi_destroy", "dmi_multi_last_error", "dmi_multi_add_views",
     "dmi_multi_add_views_f32", "dmi_multi_add_local_views", "dmi_multi_add_local_views_f32", "dmi_multi_clear_views", "dmi_multi_fuse", "dmi_multi_synchronize",
@@ -173,6 +173,7 @@ def load() -> ctypes.CDLL:
     L.dmi_color_process.argtypes = [vp, dp, ctypes.c_int64, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
     L.dmi_color_get_kernel_ms.argtypes = [vp, dp]
     L.dmi_color_set_scratch_budget.argtypes = [vp, ctypes.c_uint64]
+    L.dmi_color_set_vertex_reorder.argtypes = [vp, i32]
     L.dmi_color_last_error.argtypes = []
     L.dmi_color_last_error.restype = ctypes.c_char_p
     i64, i64p, i32p = ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
@@ -661,6 +662,10 @@ class ColorContext:
     def set_scratch_budget(self, n_bytes: int):
         """Bound the device scratch of one vertex chunk (more, smaller chunks; same result)."""
         self._check(self._lib.dmi_color_set_scratch_budget(self._h, int(n_bytes)))
+
+    def set_vertex_reorder(self, enable: bool):
+        """Work through each chunk's vertices along a Z-order curve (same results, better gathers for unordered vertices)."""
+        self._check(self._lib.dmi_color_set_vertex_reorder(self._h, 1 if enable else 0))
 
     def kernel_ms(self) -> float:
         v = ctypes.c_double(0)

@@ -203,21 +203,36 @@ int ensure_stage(dmi_context *ctx, size_t elems, bool need_cost) {
   return DMI_OK;
 }
 
-// Converts the whole store to f64 (AUTO promotion).  f32 -> f64 is exact.
+// Converts the whole store to f64 (AUTO promotion).  f32 -> f64 is exact.  All or nothing: every batch is widened into
+// a new buffer first; only when every allocation and kernel has succeeded are the pointers swapped, the old buffers
+// freed and the storage type changed.  On failure the new buffers are freed and the f32 store is untouched.
 int promote_to_f64(dmi_context *ctx) {
   const size_t npix = (size_t)ctx->W * ctx->H;
+  std::vector<double *> wide(ctx->batches.size(), nullptr);
+  hipError_t e = hipSuccess;
+  for (size_t q = 0; e == hipSuccess && q < ctx->batches.size(); ++q) {
+    const Batch &b = ctx->batches[q];
+    e = hipMalloc(&wide[q], npix * b.n * 8);
+    if (e == hipSuccess)
+      e = dmi::launch_widen_depth(static_cast<const float *>(b.d_depth), wide[q], (int64_t)npix * b.n, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (double *p : wide)
+      if (p) (void)hipFree(p);
+    return fail(ctx, e == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_DEVICE,
+                std::string("promotion of the depth store to f64: ") + hipGetErrorString(e));
+  }
   size_t map_index = 0;
-  for (Batch &b : ctx->batches) {
-    double *wide = nullptr;
-    DMI_HIP(ctx, hipMalloc(&wide, npix * b.n * 8));
-    DMI_HIP(ctx, dmi::launch_widen_depth(static_cast<const float *>(b.d_depth), wide, (int64_t)npix * b.n, ctx->stream));
-    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t q = 0; q < ctx->batches.size(); ++q) {
+    Batch &b = ctx->batches[q];
     (void)hipFree(b.d_depth);
     ctx->device_bytes += npix * b.n * 4;
-    b.d_depth = wide;
+    b.d_depth = wide[q];
     for (int i = 0; i < b.n; ++i) {
-      ctx->h_maps[map_index + i].depth = wide + npix * i;
-      ctx->h_tile_maps[map_index + i].depth = wide + npix * i;
+      ctx->h_maps[map_index + i].depth = wide[q] + npix * i;
+      ctx->h_tile_maps[map_index + i].depth = wide[q] + npix * i;
     }
     map_index += b.n;
   }

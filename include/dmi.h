@@ -251,6 +251,11 @@ int dmi_color_process(dmi_color_context *ctx, const double *points, int64_t n_po
 /* Upper bound, in bytes, of the device scratch one chunk of vertices may use (default 1 GiB, at least 1024): a smaller
  * budget means more, smaller chunks, never a different result. */
 int dmi_color_set_scratch_budget(dmi_color_context *ctx, uint64_t bytes);
+/* enable != 0: the vertices of a chunk are worked through along a Z-order curve of their bounding box (device-side key +
+ * radix sort), whatever order the caller has them in; inputs and outputs keep the caller's order and no result bit
+ * changes.  Worth it for vertices in no particular order (scattered colour gathers become neighbouring ones); a mesh
+ * whose vertices already come in a spatially coherent order is faster without.  Default off. */
+int dmi_color_set_vertex_reorder(dmi_color_context *ctx, int32_t enable);
 /* hipEvent time of the kernels (projection + median) of the last dmi_color_process, summed over its chunks */
 int dmi_color_get_kernel_ms(dmi_color_context *ctx, double *out);
 

@@ -116,7 +116,17 @@ def test_gpu_color_context_resident_views_chunks_and_batches():
         got = c.process(pts)
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
-        c.set_scratch_budget(1 << 30)
+        c.set_vertex_reorder(True)                   # Z-order processing per chunk: same bits, with and without chunks
+        weird = pts.copy()
+        weird[5] = np.nan                            # a NaN vertex takes no part in the bounding box and colours to 0
+        for budget in (9 * 4 * 1024, 1 << 30):
+            c.set_scratch_budget(budget)
+            got = c.process(pts)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w)
+        gw = c.process(weird)
+        assert gw[2][5] == 0 and all(np.array_equal(np.delete(g, 5, axis=0), np.delete(w, 5, axis=0)) for g, w in zip(gw, want))
+        c.set_vertex_reorder(False)
         sub = c.process(pts[100:1100])               # another vertex set, same resident views
         for g, w in zip(sub, want):
             assert np.array_equal(g, w[100:1100])

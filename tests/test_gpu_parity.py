@@ -565,3 +565,11 @@ def test_diagnostics_and_layer_tracking():
     with pytest.raises(ValueError):
         with capi.FusionContext(grid, rp) as ctx:
             ctx.download_grid(np.float64, out=np.zeros(5))
+
+
+def test_pcie_probe_reports_plausible_rates():
+    """dmi_pcie_probe: the pinned copy rates bench.py uses as the floor of its PCIe-inclusive figures."""
+    h2d, d2h = capi.pcie_probe(0, 64 << 20)
+    assert 1.0 < h2d < 500.0 and 1.0 < d2h < 500.0
+    with pytest.raises(capi.DmiError):
+        capi.pcie_probe(0, 1024)

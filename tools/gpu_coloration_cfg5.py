@@ -31,12 +31,21 @@ with capi.ColorContext() as c:
     mean, median, count = c.process(pts)
     dt = time.perf_counter() - t0
     kms = c.kernel_ms()
+    ordered = pts[scene.morton_order(pts)]          # the same vertices in mesh order (neighbours in neighbouring lanes)
+    c.process(ordered)
+    kms_ordered = c.kernel_ms()
+    c.set_vertex_reorder(True)                      # Z-order processing inside the library, for the random vertices
+    m2, md2, c2 = c.process(pts)
+    kms_reordered = c.kernel_ms()
+    same = bool(np.array_equal(m2, mean) and np.array_equal(md2, median) and np.array_equal(c2, count))
 colors = np.concatenate([base] * (n_views // 8))
 sample = rng.choice(n_vert, size=300, replace=False)
 want = oracle.color_mesh(pts[sample], colors, K4, views.RT4)
 ok = all(np.array_equal(g[sample], w) for g, w in zip((mean, median, count), want))
 rec = {"views": n_views, "image": f"{W}x{H}", "vertices": n_vert, "upload_s": t_up, "process_s": dt, "kernel_ms": kms,
-       "gvertex_projections_per_s_kernels": n_vert * n_views / kms / 1e6, "mean_views_per_vertex": float(count.mean()),
+       "gvertex_projections_per_s_kernels": n_vert * n_views / kms / 1e6,
+       "kernel_ms_mesh_ordered_vertices": kms_ordered, "kernel_ms_random_vertices_reordered_on_device": kms_reordered,
+       "reordered_result_identical": same, "mean_views_per_vertex": float(count.mean()),
        "sample_of_300_matches_oracle": bool(ok)}
 print(json.dumps(rec))
 json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "coloration_cfg5.json"), "w"), indent=1)
