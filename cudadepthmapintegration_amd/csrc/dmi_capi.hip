@@ -956,7 +956,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // spatial order: one z-layer of super-bricks per XCD and round (long runs keep an XCD on one region of every
     // depth map); heaviest-first order: one super-brick's worth, so that the heavy bricks spread over all XCDs
     t.xcd_run_wg = 32 * std::max(1, t.super_x * t.super_y);
-    if (((int64_t)t.super_x * t.super_y * t.super_z * 32 + 8 * (int64_t)t.xcd_run_wg) > (int64_t)0x7fffffff)
+    if (((int64_t)t.super_x * t.super_y * t.super_z * 32 + 16 * (int64_t)t.xcd_run_wg + 64) > (int64_t)0x7fffffff)
       return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: grid too large for one launch");
     t.depth_bytes = (int32_t)((int64_t)a.W * a.H * (ctx->depth_f64 ? 8 : 4));
     t.kz0 = a.kz0;
@@ -972,7 +972,8 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     t.grid = a.grid; t.voxel_hits = a.voxel_hits; t.map_hits = a.map_hits;
     // r22*wz(k) table, one row of kpad doubles per resident view
     t.rotated = grid_axis_aligned(ctx->grid) ? 0 : 1;
-    t.flags = (cfg.variant & dmi::VAR_NO_INTERIOR) ? dmi::TILE_FLAG_NO_INTERIOR : 0;
+    t.flags = ((cfg.variant & dmi::VAR_NO_INTERIOR) ? dmi::TILE_FLAG_NO_INTERIOR : 0) |
+              ((cfg.variant & dmi::VAR_XCD_RUNS) ? dmi::TILE_FLAG_XCD_RUNS : 0);
     t.maps = ctx->d_maps;
     const size_t need = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;  // rotated: [kpad][4]
     if (ctx->cz_table_capacity < need) {
@@ -1050,6 +1051,9 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
         }
         t.order = ctx->d_order + 1;  // [0] holds the count
         t.n_order = ctx->d_order;
+        // the ordering kernels leave the first position of every (level, chunk) behind the level bytes of their scratch
+        // (launch_order_bricks): chunk 0's four entries are where the levels start
+        t.order_levels = reinterpret_cast<const int32_t *>(ctx->d_order_level + (n_slots + 15) / 16 * 16);
         t.xcd_run_wg = 32 * (4 / (sh.wx * sh.wy));  // 32 workgroups of four waves, 128 of one (profiles: 7.73 vs 7.78 ms)
       }
     }

@@ -128,10 +128,16 @@ struct TileArgs {
   // be split into a per-lane part and a per-(view, k) table; cz_table then holds [kpad][4] = the k-dependent products
   // (g02, g12, g22) * gz(k) of cu:168, and the kernel forms w and c.z per voxel in the reference's order
   int32_t rotated;
-  int32_t flags;                         // TileFlags2 bits
+  int32_t flags;                         // TileKernelFlags bits
   const MapRec *maps;                    // RT row 2 in full for the rotated path
+  // first entry of each of the four work levels within `order` (device; written by the ordering kernels): with them an
+  // XCD takes ONE contiguous eighth of every level instead of runs dealt round-robin (fusion_tile.hip, workgroup -> brick)
+  const int32_t *order_levels;
 };
-enum TileKernelFlags : int32_t { TILE_FLAG_NO_INTERIOR = 1 };  // tuning / tests: never take the INTERIOR column variant
+enum TileKernelFlags : int32_t {
+  TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
+  TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
+};
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
 // corner voxels and the depth table's min/max pyramid (fusion_classify.hip):
@@ -175,7 +181,8 @@ enum VariantBits : int {
   VAR_SPATIAL_ORDER = 512,     // tiled kernel: workgroups in spatial order, not heaviest bricks first
   VAR_FIXED_TILE_SHAPE = 4096,  // tiled kernel: tile-shape bits 0 mean shape 0 whatever the grid size (no automatic choice)
   VAR_KEEP_BEHIND_ADDS = 1024,  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
-  VAR_NO_INTERIOR = 2048        // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
+  VAR_NO_INTERIOR = 2048,       // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
+  VAR_XCD_RUNS = 8192           // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

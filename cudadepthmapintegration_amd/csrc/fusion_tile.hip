@@ -214,16 +214,41 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // the grid (the work per brick depends on how close it is to a surface).
   const int b = blockIdx.x;
   const int q = b >> 3;                         // q-th workgroup of this block's XCD
-  const int run = KA(xcd_run_wg);                 // workgroups dealt to one XCD in a row
-  const int p = (q / run) * (8 * run) + (b & 7) * run + q % run;
-  // heaviest bricks first when the classification has ordered them (fusion_classify.hip), else spatial order
   // slots are absolute (whole grid); a slab fuse (dmi_fuse_slab) covers slots [slot_base, slot_base + slot_count)
-  int slot = p + KA(slot_base);
-  if (KA(order)) {
-    if (p >= cload(KA(n_order))) return;
-    slot = cload(KA(order) + p);
-  } else if (p >= KA(slot_count)) {
-    return;
+  int slot;
+  if (KA(order) && !(KA(flags) & TILE_FLAG_XCD_RUNS)) {
+    // Bricks ordered heaviest level first, spatial order inside a level (fusion_classify.hip).  Every XCD takes ONE
+    // contiguous eighth of every level, heaviest level first: all XCDs start on heavy bricks, and what an XCD works on
+    // is a compact region of the grid per level, so its L2 is asked for a band of every depth table instead of all of
+    // it (dealt in runs, every XCD fetched nearly every table: 8 x the tables' size in fabric traffic).
+    const int xcd = b & 7;
+    int rest = q, found = -1;
+    int lo = cload(KA(order_levels));
+#pragma unroll
+    for (int level = 0; level < 4; ++level) {
+      const int hi = level < 3 ? cload(KA(order_levels) + level + 1) : cload(KA(n_order));
+      const int n = hi - lo;
+      const int s0 = (int)(((long long)xcd * n) >> 3), s1 = (int)(((long long)(xcd + 1) * n) >> 3);
+      if (found < 0) {
+        if (rest < s1 - s0)
+          found = lo + s0 + rest;
+        else
+          rest -= s1 - s0;
+      }
+      lo = hi;
+    }
+    if (found < 0) return;
+    slot = cload(KA(order) + found);
+  } else {
+    const int run = KA(xcd_run_wg);             // workgroups dealt to one XCD in a row
+    const int p = (q / run) * (8 * run) + (b & 7) * run + q % run;
+    slot = p + KA(slot_base);
+    if (KA(order)) {
+      if (p >= cload(KA(n_order))) return;
+      slot = cload(KA(order) + p);
+    } else if (p >= KA(slot_count)) {
+      return;
+    }
   }
   const int sb = slot >> 5, within = slot & 31;
   const int sbx = sb % KA(super_x);
@@ -595,8 +620,9 @@ __global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double 
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   // super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
+  // (+ 32: an XCD's eighths of the four levels can add up to four workgroups more than an eighth of the total)
   const int per_round = 8 * a.xcd_run_wg;
-  const unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + per_round - 1) / per_round * per_round);
+  const unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + 32 + per_round - 1) / per_round * per_round);
   const dim3 block(64 * WX * WY);
   if (cfg.count_hits)
     hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>), dim3(blocks), block, 0, s, a);
