@@ -1,4 +1,5 @@
-"""Randomised GPU parity: random axis-aligned and rotated grids, pinhole / skewed / general K, random poses (cameras
+"""Randomised GPU parity: random axis-aligned and rotated grids, pinhole / skewed / general K (also mixed view by view,
+with a view no fast path takes), random poses (cameras
 inside and outside the grid), depth tables with sentinels, NaNs and f32-inexact values, ray-potential parameters
 including the degenerate ones the reference accepts (thickness 0, delta 0, negative eta).  Every case runs the default
 path (tiled kernel with brick classes when eligible), the tiled kernel without classes and the general kernel, and
@@ -37,11 +38,25 @@ def _random_case(seed):
     radius = float(rng.choice([0.3, 1.2, 3.0, 6.0]))
     views = scene.make_views(n, W, H, seed=int(rng.integers(1 << 30)), dense=bool(rng.integers(0, 2)), radius=radius,
                              focal_scale=float(rng.uniform(0.4, 1.5)))
-    kk = rng.integers(0, 4)
+    kk = rng.integers(0, 7)
     if kk == 1:
         views.K4[:, 0, 1] = rng.uniform(-0.5, 0.5)  # skew
     elif kk == 2:
         views.K4[:, 2, 0] = 1e-3                    # general K (h.z != c.z)
+    elif kk == 3:                                   # every kind in one fusion, view by view: runs of tiled (pinhole or
+        for m in range(n):                          # GENK) launches and, for the huge focal, the general kernel
+            what = rng.integers(0, 5)
+            if what == 1:
+                views.K4[m, 2, 2] = rng.uniform(0.5, 2.0)
+            elif what == 2:
+                views.K4[m, 2, :] = [rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.uniform(0.8, 1.2), rng.uniform(-0.3, 0.3)]
+            elif what == 3:
+                views.K4[m, 0, 3], views.K4[m, 1, 3], views.K4[m, 1, 0] = rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-0.2, 0.2)
+            elif what == 4:
+                views.K4[m, 0, 0] = 1e14
+    elif kk == 4:                                   # scaled third row and a fourth column on every view
+        views.K4[:, 2, 2] = rng.uniform(0.5, 2.0)
+        views.K4[:, 0, 3] = rng.uniform(-3, 3)
     depth = views.depth
     m = rng.random(depth.shape)
     depth[m < 0.05] = -1.0
@@ -68,7 +83,8 @@ def test_random_scenes_bit_exact(seed):
     with np.errstate(all="ignore"):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        init_grid=init, n_threads=oracle.max_threads())
-    for variant in (0, capi.VARIANT_FIXED_TILE_SHAPE, capi.VARIANT_NO_BRICK_CLASSES, 96, capi.VARIANT_FORCE_GENERAL):
+    for variant in (0, capi.VARIANT_FIXED_TILE_SHAPE, capi.VARIANT_NO_BRICK_CLASSES, 96, capi.VARIANT_FORCE_GENERAL,
+                    capi.VARIANT_NO_INTERIOR | capi.VARIANT_XCD_RUNS):
         out, vh, mh = capi.fuse_once(grid, rp, views, init_grid=init, kernel_variant=variant)
         assert np.array_equal(mh, mh_w), (seed, variant)
         assert np.array_equal(vh, vh_w), (seed, variant)

@@ -31,7 +31,8 @@ def main():
     args = ap.parse_args()
     fx = capi.VARIANT_FIXED_TILE_SHAPE
     variants = [(0, True), (0, False), (fx, True), (fx, False), (fx | capi.VARIANT_NO_BRICK_CLASSES, True), (96, True),
-                (capi.VARIANT_FORCE_GENERAL, True)]
+                (capi.VARIANT_FORCE_GENERAL, True), (capi.VARIANT_NO_INTERIOR, False), (capi.VARIANT_XCD_RUNS, False)]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     t0 = time.time()
     done = 0
     voxel_projections = 0
@@ -76,6 +77,8 @@ def main():
         voxel_projections += grid.n_voxels * views.n
         if done % 50 == 0:
             print(f"{done} cases bit-exact, {time.time() - t0:.0f} s", flush=True)
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_campaign_progress.txt"), "a") as f:  # survives a cut-off call
+                f.write(f"{done} cases bit-exact from seed {args.first}, {time.time() - t0:.0f} s\n")
     res = {"first_seed": args.first, "cases": done, "kernel_paths_per_case": len(variants), "voxel_projections_per_path": voxel_projections,
            "default_path_ran": paths, "failure": failure, "seconds": time.time() - t0}
     print(json.dumps(res))
