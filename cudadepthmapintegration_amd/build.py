@@ -104,6 +104,7 @@ def audit_accumulator_registers(asm_text: str) -> tuple[int, list[str]]:
         base = ACC_BASES.get(minw, 128)
         code = body[: body.find("s_endpgm")]
         in_asm = False
+        scc_from_asm = False  # SCC currently holds what an asm statement's s_and_saveexec_b64 left there
         for line in code.splitlines():
             if "#ASMSTART" in line:
                 in_asm = True
@@ -111,6 +112,19 @@ def audit_accumulator_registers(asm_text: str) -> tuple[int, list[str]]:
             if "#ASMEND" in line:
                 in_asm = False
                 continue
+            # The EXEC-masked statements write SCC (s_and_saveexec_b64) and say so in their clobber lists; a compiler
+            # instruction that READS SCC right after one would mean a clobber list lost it (results silently wrong).
+            op = line.split()[0] if line.split() else ""
+            if in_asm:
+                if op.startswith("s_and_saveexec"):
+                    scc_from_asm = True
+            elif op.startswith("s_"):
+                if scc_from_asm and re.match(r"s_(cbranch_scc|cselect|cmov|addc|subb)", op):
+                    bad.append(f"{name}: {op} reads the SCC an asm statement's s_and_saveexec_b64 wrote: {line.strip()}")
+                if not re.match(r"s_(mov|movk|load|buffer_load|waitcnt|nop|branch|cbranch|cselect|cmov|getpc|setpc|swappc|sleep|barrier|endpgm)", op):
+                    scc_from_asm = False  # scalar ALU and compare instructions define SCC anew
+            elif line.rstrip().endswith(":") and not line.startswith((" ", "\t")):
+                scc_from_asm = False  # a label: control flow joins here, the compiler's own bookkeeping applies
             if in_asm or not re.match(r"\s+(v_|global_|buffer_|ds_|scratch_|flat_)", line):
                 continue
             regs = [int(x) for x in re.findall(r"\bv(\d+)\b", line)]

@@ -52,7 +52,7 @@ typedef unsigned long long mask_t;
 // bits |= bit on the lanes of m only
 __device__ __forceinline__ void or_where(uint32_t &bits, mask_t m, uint32_t bit /* wave-uniform */) {
   mask_t saved;
-  asm("s_and_saveexec_b64 %1, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(bits), "=&s"(saved) : "s"(m), "s"(bit));
+  asm("s_and_saveexec_b64 %1, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(bits), "=&s"(saved) : "s"(m), "s"(bit) : "scc");
 }
 
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -108,6 +108,7 @@ struct DepthLoad<float> {
   static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
   static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0f; }  // cu:202; f32 holds the f64 exactly
   static __device__ __forceinline__ raw_t sentinel() { return -1.0f; }
+  static __device__ __forceinline__ raw_t minus_inf() { return -__builtin_inff(); }
   static __device__ __forceinline__ double widen(raw_t d) { return (double)d; }
 };
 template <>
@@ -121,6 +122,7 @@ struct DepthLoad<double> {
   static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
   static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0; }
   static __device__ __forceinline__ raw_t sentinel() { return -1.0; }
+  static __device__ __forceinline__ raw_t minus_inf() { return -__builtin_inf(); }
   static __device__ __forceinline__ double widen(raw_t d) { return d; }
 };
 
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   unsigned vW = (unsigned)KA(W), vH = (unsigned)KA(H);
   asm("" : "+v"(vW));
   asm("" : "+v"(vH));
+  [[maybe_unused]] const double Wd = pinned((double)KA(W));  // the row pitch as the interior column multiplies it
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
   // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
@@ -409,8 +412,15 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // The column, in two instantiations chosen per (brick, view): INTERIOR when the classification has proven every
     // voxel of the brick in front of the camera and inside the depth map for this view (the mixed pairs that are mixed
     // because a surface is near: MIXED_NAN_DEPTH and above), the full tests otherwise.
-    auto column = [&](auto interior_tag) __attribute__((always_inline)) {
+    auto column = [&](auto interior_tag, auto surface_tag) __attribute__((always_inline)) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
+      // SURFACE (a refinement of INTERIOR): every pixel of the brick's footprint holds a depth (no "no depth" pixel, no
+      // NaN: MIXED_NEAR_SURFACE), the sums cannot be -0.0 and hits are not counted
+      constexpr bool SURFACE = decltype(surface_tag)::value;
+      // INTERIOR without hit counters loads under no lane mask at all: every proven lane's pixel is inside the map, and
+      // what the other lanes fetch (range-checked by the buffer descriptor) is never used: an unproven voxel's value is
+      // replaced below by one that adds nothing, and a lane outside the grid owns no voxel (its sums are never stored)
+      constexpr bool UNMASKED = INTERIOR && !COUNT;
   #pragma unroll
       for (int g0 = 0; g0 < TK; g0 += kGroup) {
         double czg[kGroup];
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   #pragma unroll
         for (int q = 0; q < kGroup; ++q) {
           const int kk = g0 + q;
-          dg[q] = DL::sentinel();
+          if constexpr (!UNMASKED) dg[q] = DL::sentinel();
           if constexpr (ROT) {
             if (kk >= kcount) continue;  // wave-uniform: a voxel above the grid (the table has no -inf trick here)
             // the k-dependent products g_r2*gz(k) of cu:168 (wk table, scalar load), then w and c.z in the reference's order
@@ -471,15 +481,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const double ua = hx * r, va = hy * r;
           // nearest integers (ties never accepted, so RNE vs the reference's half-away does not matter)
           const double ru = __builtin_rint(ua), rv = __builtin_rint(va);
-          const int px = cvt_saturating(ru), py = cvt_saturating(rv);
           const double fu = ua - ru, fv = va - rv;  // exact: signed distance to the chosen integer
           // Accepted iff |frac| + (bound on |u_ref - ua|) < 1/2, a bound that holds only with a good reciprocal: the seed's
-          // residual |e0| must be below 2^-20, i.e. |e0| * 2^19 below 1/2 -- it joins the maximum, so ONE compare against an
-          // inline constant decides (errk includes the 2^-22 of DESIGN.md 4.4, scaled so that errk * r covers it).  A NaN
-          // anywhere makes r, and with it chk, a NaN: not accepted.
-          const double resid = __builtin_ldexp(__builtin_fabs(e0), 19);
-          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)), resid));
-          const mask_t m_proven = ballot(chk < 0.5);
+          // residual |e0| must be below 2^-20 (errk includes the 2^-22 of DESIGN.md 4.4, scaled so that errk * r covers
+          // it).  A NaN anywhere makes r, and with it chk, a NaN: not accepted.
+          const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
+          const mask_t m_proven = ballot(chk < 0.5) & ballot(__builtin_fabs(e0) < 0x1p-20);
           // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot is one v_cmp, all the logic
           // between them runs on the scalar unit.
           mask_t m_in, m_und;
@@ -497,13 +504,26 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             // positive and the acceptance test above means what it says), in between undecided.
             const mask_t m_front = GENK ? ballot(!(hz < -errz)) : ballot(!(cz < 0.0));
             if constexpr (GENK) m_proven_front = ballot(hz > errz);
-            // cu:192-197 on the integers: a saturated conversion (|ru| >= 2^31) is >= 2^31 as unsigned, outside any map
-            m_in = m_front & m_proven & m_proven_front & ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
+            m_in = m_front & m_proven & m_proven_front;  // and inside the map: below, on the integers
             m_und = m_front & ~(m_proven & m_proven_front);
           }
-          if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
-          if (__builtin_amdgcn_inverse_ballot_w64(m_in))
-            dg[q] = DL::load(rsrc, __umul24((unsigned)py, vW) + (unsigned)px);  // cu:201
+          if constexpr (UNMASKED) {
+            // W*py + px (cu:201) in one fp64 operation: exact, both are integers below 2^31 on every lane that counts
+            dg[q] = DL::load(rsrc, (unsigned)cvt_saturating(__builtin_fma(rv, Wd, ru)));
+            if (m_und) {  // wave-uniform branch, rarely taken
+              or_where(undecided, m_und, 1u << kk);
+              // the exact redo below adds this voxel's value; here it must add nothing: "no depth" (cu:202), or, where
+              // that is not looked for, a depth of -inf: diff = +inf > delta adds the +0 (cu:115) no sum can notice
+              if (__builtin_amdgcn_inverse_ballot_w64(m_und)) dg[q] = SURFACE ? DL::minus_inf() : DL::sentinel();
+            }
+          } else {
+            const int px = cvt_saturating(ru), py = cvt_saturating(rv);
+            if constexpr (!INTERIOR)  // cu:192-197 on the integers: a saturated conversion is >= 2^31 as unsigned, outside any map
+              m_in &= ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
+            if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
+            if (__builtin_amdgcn_inverse_ballot_w64(m_in))
+              dg[q] = DL::load(rsrc, __umul24((unsigned)py, vW) + (unsigned)px);  // cu:201
+          }
           // keep the voxels' instruction streams apart: interleaving them buys nothing (other waves fill the
           // gaps) and costs the registers that decide the occupancy
           __builtin_amdgcn_sched_barrier(0);
@@ -514,8 +534,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         for (int q = 0; q < kGroup; ++q) {
           const int kk = g0 + q;
           const typename DL::raw_t d = dg[q];  // lanes that did not load still hold the sentinel
-          const mask_t m_hit = ballot(!DL::is_sentinel(d));  // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike
-          if (m_hit) {  // wave-uniform: skip the potential when no lane accumulates
+          // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike; SURFACE: every lane has a depth
+          const mask_t m_hit = SURFACE ? ~0ull : ballot(!DL::is_sentinel(d));
+          if (SURFACE || m_hit) {  // wave-uniform: skip the potential when no lane accumulates
             const double diff = czg[q] - DL::widen(d);  // cu:108
             // cu:114-115 as two signed compares: diff < -delta is "far in front" (-eta*rho), diff > delta "far behind" (+0);
             // a NaN diff fails both and ends, as in the reference, in the last else branch (cu:119)
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             const mask_t m_behind_far = ballot(diff > delta);
             acc_add_s<BASE, TK>(kk, m_hit & m_front_far, free_space);  // -eta*rho (cu:115)
             // + 0 (cu:115) matters only where a sum can be -0.0: never, when the grid started at +0.0 (behind_mask set)
-            if (keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_behind_far);
+            if (!SURFACE && keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_behind_far);
             const mask_t m_near = m_hit & ~(m_front_far | m_behind_far);
             if (m_near) {
               const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
@@ -541,10 +562,22 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         }
       }
     };
-    if (!ROT && !GENK && kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR))
-      column(std::true_type{});
-    else
-      column(std::false_type{});
+    bool interior = false;
+    if constexpr (!ROT && !GENK)
+      interior = kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
+    if constexpr (!ROT && !GENK) {
+      if (interior) {
+        if constexpr (!COUNT) {
+          if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
+            column(std::true_type{}, std::true_type{});
+          else
+            column(std::true_type{}, std::false_type{});
+        } else {
+          column(std::true_type{}, std::false_type{});
+        }
+      }
+    }
+    if (!interior) column(std::false_type{}, std::false_type{});
 
     // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so
     // doing them after the column keeps every voxel's accumulation in map order, cu:211)

@@ -94,3 +94,11 @@ def test_accumulator_register_audit_flags_a_violation():
     assert n == 1 and len(bad) == 1 and "v81" in bad[0]
     short = ok.replace("next_free_vgpr 96", "next_free_vgpr 88")
     assert len(build.audit_accumulator_registers(short)[1]) == 1
+    # a compare whose SCC is read only after an EXEC-masked asm statement (s_and_saveexec_b64 writes SCC): flagged;
+    # with a scalar instruction that defines SCC anew in between: clean
+    masked = "\t;;#ASMSTART\n\ts_and_saveexec_b64 s[8:9], s[6:7]\n\tv_add_f64 v[80:81], v[80:81], s[2:3]\n\ts_mov_b64 exec, s[8:9]\n\t;;#ASMEND\n"
+    carried = ok.replace("\ts_endpgm", "\ts_cmp_eq_u64 s[0:1], -1\n" + masked + "\ts_cbranch_scc1 .LBB0_1\n.LBB0_1:\n\ts_endpgm")
+    n, bad = build.audit_accumulator_registers(carried)
+    assert n == 1 and len(bad) == 1 and "SCC" in bad[0]
+    fine = ok.replace("\ts_endpgm", masked + "\ts_cmp_eq_u64 s[0:1], -1\n\ts_cbranch_scc1 .LBB0_1\n.LBB0_1:\n\ts_endpgm")
+    assert build.audit_accumulator_registers(fine) == (1, [])

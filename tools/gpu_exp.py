@@ -74,15 +74,22 @@ def main():
                     fuse[k].append((t.total_fuse_kernel_ms - t0.total_fuse_kernel_ms) / args.steps)
                     main_ms[k].append((t.total_fuse_main_kernel_ms - t0.total_fuse_main_kernel_ms) / args.steps)
         ref = None
+        ref_grid = None
+        same = {}
+        for k, c in ctxs.items():                     # every build must leave the same bits in the grid as the first one
+            g = np.ascontiguousarray(c.download_grid(np.float32)).view(np.uint8)
+            if ref_grid is None:
+                ref_grid = g
+            same[k] = bool(np.array_equal(g, ref_grid))
         for k in ctxs:
             rec = {"scene": sc, "lib": k[0], "variant": k[1], "fuse_ms": float(np.median(fuse[k])), "main_ms": float(np.median(main_ms[k])),
-                   "main_min_ms": float(np.min(main_ms[k]))}
+                   "main_min_ms": float(np.min(main_ms[k])), "grid_bits_equal_first": same[k]}
             if ref is None:
                 ref = rec["main_ms"]
             rec["main_vs_first"] = rec["main_ms"] / ref
             out.append(rec)
             print(sc, k[0], k[1], "fuse", round(rec["fuse_ms"], 3), "main", round(rec["main_ms"], 3), "min", round(rec["main_min_ms"], 3),
-                  "x%.3f" % rec["main_vs_first"], flush=True)
+                  "x%.3f" % rec["main_vs_first"], "" if same[k] else "GRID DIFFERS", flush=True)
         for c in ctxs.values():
             c.close()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
