@@ -975,7 +975,9 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     t.flags = ((cfg.variant & dmi::VAR_NO_INTERIOR) ? dmi::TILE_FLAG_NO_INTERIOR : 0) |
               ((cfg.variant & dmi::VAR_XCD_RUNS) ? dmi::TILE_FLAG_XCD_RUNS : 0);
     t.maps = ctx->d_maps;
-    const size_t need = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;  // rotated: [kpad][4]
+    // rotated: [kpad][4]; behind the table, the sums of n free-space constants (TileArgs::free_sums)
+    const size_t table_doubles = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;
+    const size_t need = table_doubles + (size_t)dmi::kFreeSumsMax + 1;
     if (ctx->cz_table_capacity < need) {
       if (ctx->d_cz_table) {
         DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -990,6 +992,8 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       ctx->device_bytes += grown * 8;
     }
     t.cz_table = ctx->d_cz_table;
+    // valid while every sum of the launch starts at +0.0 and hits are not counted (counted views are taken one by one)
+    if (!a.init_from_grid && !ctx->opt.count_hits && count <= dmi::kFreeSumsMax) t.free_sums = ctx->d_cz_table + table_doubles;
     // brick classes: one byte per (8 x 8 x column wave brick, resident view)
     t.wbricks_x = (a.nx + 7) / 8;
     t.wbricks_y = (a.ny + 7) / 8;

@@ -133,7 +133,13 @@ struct TileArgs {
   // first entry of each of the four work levels within `order` (device; written by the ordering kernels): with them an
   // XCD takes ONE contiguous eighth of every level instead of runs dealt round-robin (fusion_tile.hip, workgroup -> brick)
   const int32_t *order_levels;
+  // free_sums[n] = ((0 + f) + f ...) + f, n times, f = free_space, in fp64: what EVERY voxel of a brick holds after n
+  // BRICK_FREE views when nothing else has touched the brick yet (the sums start at +0.0).  The kernel counts such views
+  // and fetches the sum when the first view with per-voxel work arrives, instead of adding per view and voxel.
+  // nullptr: not available (the grid does not start from zeros, or more views than kFreeSumsMax)
+  const double *free_sums;
 };
+constexpr int kFreeSumsMax = 4096;
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
   TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)

@@ -324,6 +324,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // skipped views cost none (one bit per view that needs work, found with s_ff1), and a run of BRICK_FREE views before
   // the next view that needs its own treatment is counted (s_bcnt1) and executed as that many blocks of adds.  The only
   // state carried across the per-voxel body below is (cword, cnext, m): the body has no scalar registers to spare.
+  // While nothing but BRICK_FREE views has touched this brick, all its sums are equal and depend on the number of such
+  // views alone: they are counted here and fetched from the free_sums table when the first other view arrives (or at the
+  // end).  n_uniform < 0: the sums have diverged (or there is no table), FREE views are added one by one.
+  int n_uniform = (!COUNT && KA(free_sums) != nullptr) ? 0 : -1;
   unsigned long long cword = 0ull;
   unsigned long long cnext = cload(crow + (first_map >> 3));
   for (int m = first_map; m < m_end; ++m) {
@@ -343,13 +347,23 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     const unsigned long long fr = COUNT ? 0ull : (todo & ((cword & ~(cword >> 1) & 0x0101010101010101ull) >> shift));
     const unsigned long long other = todo ^ fr;             // BRICK_MIXED views (and BEHIND / counted FREE ones)
     const unsigned long long below = (other - 1) & ~other;  // the bits below the next such view (all bits, if none)
-    for (int n_free = __builtin_popcountll(fr & below); n_free > 0; --n_free) {
+    if (n_uniform >= 0) {
+      n_uniform += __builtin_popcountll(fr & below);
+    } else {
+      for (int n_free = __builtin_popcountll(fr & below); n_free > 0; --n_free) {
 #pragma unroll
-      for (int q = 0; q < TK; q += 8) acc_add8_all<BASE, TK>(q, free_space);
+        for (int q = 0; q < TK; q += 8) acc_add8_all<BASE, TK>(q, free_space);
+      }
     }
     if (other == 0) {  // nothing else in this word
       m |= 7;
       continue;
+    }
+    if (n_uniform >= 0) {  // the first view of this brick with work of its own: from here on the sums differ
+      const double v = cload(KC(free_sums) + n_uniform);
+#pragma unroll
+      for (int q = 0; q < TK; ++q) acc_set<BASE, TK>(q, v);
+      n_uniform = -1;
     }
     m += __builtin_ctzll(other) >> 3;
     const unsigned cbyte = (unsigned)(cword >> ((m & 7) * 8)) & 0x1fu;  // class in bits 0..1, MixedReason above it
@@ -604,6 +618,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     }
   }
 
+  if (n_uniform > 0) {  // no view had work of its own: every voxel of the brick holds the same sum
+    const double v = cload(KC(free_sums) + n_uniform);
+#pragma unroll
+    for (int q = 0; q < TK; ++q) acc_set<BASE, TK>(q, v);
+  }
   if (lane_ok) {
     // The store addresses are formed here, from a fresh read of the argument block: nothing of them (TK addresses of 2
     // VGPRs each, the grid pointer, the row and plane pitches) stays live across the view loop.
@@ -625,11 +644,25 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #undef KC
 #undef KFRESH
 
+// TileArgs::free_sums: the running sum of n free-space constants (cu:115, cu:211), n = 0 .. n_maps, added one at a time
+// exactly as a voxel's sum receives them.  One thread; the chain of n_maps dependent adds is a few microseconds.
+__device__ __forceinline__ void fill_free_sums(const TileArgs &a) {
+  if (!a.free_sums) return;
+  double *out = const_cast<double *>(a.free_sums);
+  double sum = 0.0;
+  out[0] = sum;
+  for (int n = 1; n <= a.n_maps; ++n) {
+    sum += a.free_space;
+    out[n] = sum;
+  }
+}
+
 // r22[m] * wz(k): the one product of c.z that depends on (map, k) only.  Exact fp64 multiply.
 __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        double *__restrict__ table) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int m = a.first_map + blockIdx.y;
+  if (k == 0 && blockIdx.y == 0) fill_free_sums(a);
   if (k >= a.kpad) return;
   const double gx = a.ox + (0 + 0.5) * a.sx;
   const double gy = a.oy + (0 + 0.5) * a.sy;
@@ -642,6 +675,7 @@ __global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const M
 // rotated grids: table[k][0..2] = (g02, g12, g22) * gz(k), the k-dependent products of cu:168 (exact fp64 multiplies)
 __global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double *__restrict__ table) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) fill_free_sums(a);
   if (k >= a.kpad) return;
   const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;  // cu:82
   table[4 * k + 0] = a.g[2] * gz;

@@ -86,10 +86,20 @@ def main():
                    "main_min_ms": float(np.min(main_ms[k])), "grid_bits_equal_first": same[k]}
             if ref is None:
                 ref = rec["main_ms"]
+                ref_rounds = np.array(main_ms[k])
             rec["main_vs_first"] = rec["main_ms"] / ref
+            # round by round against the first build (measured back to back: the box's drift mostly cancels)
+            ratios = np.array(main_ms[k]) / ref_rounds
+            rec["paired_ratio_median"] = float(np.median(ratios))
+            rec["paired_ratio_quartiles"] = [float(np.percentile(ratios, 25)), float(np.percentile(ratios, 75))]
+            rec["main_rounds_ms"] = [round(float(x), 3) for x in main_ms[k]]
+            # the rounds are a base level plus spikes of a millisecond or two (the box, not the build): the lower quartile
+            # is the steadier figure
+            rec["main_p25_ms"] = float(np.percentile(main_ms[k], 25))
             out.append(rec)
             print(sc, k[0], k[1], "fuse", round(rec["fuse_ms"], 3), "main", round(rec["main_ms"], 3), "min", round(rec["main_min_ms"], 3),
-                  "x%.3f" % rec["main_vs_first"], "" if same[k] else "GRID DIFFERS", flush=True)
+                  "x%.3f" % rec["main_vs_first"], "p25", round(rec["main_p25_ms"], 3), "paired x%.3f [%.3f, %.3f]" % (rec["paired_ratio_median"], *rec["paired_ratio_quartiles"]),
+                  "" if same[k] else "GRID DIFFERS", flush=True)
         for c in ctxs.values():
             c.close()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
