@@ -66,12 +66,10 @@ struct TileAcc {
       dmax = fmaxf(dmax, float_above(d));
     }
   }
-  __device__ __forceinline__ void add_tile(const DepthTile &t) {
+  __device__ __forceinline__ void add_tile(const DepthTile &t) {  // a tile without a valid depth holds +inf / -inf (tile())
     flags |= t.flags;
-    if (t.flags & TILE_HAS_VALID) {
-      dmin = fminf(dmin, t.dmin);
-      dmax = fmaxf(dmax, t.dmax);
-    }
+    dmin = fminf(dmin, t.dmin);
+    dmax = fmaxf(dmax, t.dmax);
   }
   __device__ __forceinline__ DepthTile tile() const { return DepthTile{dmin, dmax, flags, 0u}; }
 };
@@ -327,10 +325,10 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   }
 }
 
-// Fine pass: one wave per (unproven box, view): the lanes are the box's wave bricks (4 x 4 x 4 of 8 voxels in z; with
-// 16-voxel columns 4 x 4 x 2, and the wave's upper half takes the next view), so a wave either has nothing to do or
-// works with all its lanes.  A block is four waves = four (eight) consecutive views of one box: their byte stores
-// land in the same cache lines.
+// Fine pass: one workgroup per (box, 64 consecutive views); its four waves share out the views the coarse pass left
+// unproven (one ballot over the box's coarse row finds them: a box proven for all 64 costs one load), one view at a
+// time per wave.  The lanes are the box's wave bricks (4 x 4 x 4 of 8 voxels in z; with 16-voxel columns 4 x 4 x 2, and
+// the wave's upper half takes the next view), so a wave that works does so with all its lanes.
 // The footprints of a box's bricks tile the box's footprint: the lanes of a view stage that window of the view's
 // min/max pyramid in LDS once (coalesced rows of tiles) and every lane reduces its own tiles from there, instead of
 // every lane gathering 4 to 25 tiles from global memory.
@@ -348,96 +346,112 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
   const int cx_n = (a.wbricks_x + 3) / 4, cy_n = (a.wbricks_y + 3) / 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mm = (blockIdx.y * 4 + wave) * views_per_wave + lane / children;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int local = blockIdx.x;  // box within the slab
   const int cbx = local % cx_n;
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
+  // the views of this workgroup that the coarse pass left to it: bit v = view chunk0 + v
+  const int chunk0 = blockIdx.y * 64;
+  const uint8_t *__restrict__ crow = coarse + (int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + a.first_map + chunk0;
+  const unsigned long long unproven = __builtin_amdgcn_ballot_w64(chunk0 + lane < a.n_maps && (crow[lane] & 3) == BRICK_MIXED);
+  if (unproven == 0) return;
+  // a wave's work items are runs of views_per_wave views; wave w takes the items w, w + 4, w + 8 ...
+  unsigned long long items = views_per_wave == 1 ? unproven & (0x1111111111111111ull << wave)
+                                                 : (unproven | (unproven >> 1)) & (0x0101010101010101ull << (2 * wave));
   const int child = lane % children;
   const int bx = cbx * 4 + (child & 3), by = cby * 4 + ((child >> 2) & 3), bz = cbz * per_z + (child >> 4);
-  const int m = a.first_map + min(mm, a.n_maps - 1);
-  const bool mine = mm < a.n_maps && bx < a.wbricks_x && by < a.wbricks_y && bz < bz_first + bz_count &&
-                    (coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] & 3) == BRICK_MIXED;
-  if (__builtin_amdgcn_ballot_w64(mine) == 0) return;  // the whole wave: proven by the coarse pass, or no such view
-  const MapRec *__restrict__ mr = maps + m;
-  BoxFootprint fp;
-  fp.query = false;
-  fp.cls = BRICK_SKIP;
-  MapRec mr_u;      // one view per wave: the camera records arrive through scalar loads, once, instead of ~35 vector
-  TileMapRec tr_u;  // loads of the same address per lane
-  if constexpr (views_per_wave == 1) {
-    const int mu = __builtin_amdgcn_readfirstlane(m);
-    const MapRec *src = maps + mu;
-    const TileMapRec *tsrc = a.tile_maps + mu;
+  const bool in_grid = bx < a.wbricks_x && by < a.wbricks_y && bz < bz_first + bz_count;
+  uint8_t *__restrict__ out = classes + (int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch;
+  while (items) {
+    const int first = __builtin_ctzll(items);  // first view of the item, relative to chunk0
+    items &= items - 1;
+    const int rel = first + lane / children;
+    const int mm = chunk0 + rel;
+    const int m = a.first_map + min(mm, a.n_maps - 1);
+    const bool mine = in_grid && ((unproven >> rel) & 1ull);
+    const MapRec *__restrict__ mr = maps + m;
+    BoxFootprint fp;
+    fp.query = false;
+    fp.cls = BRICK_SKIP;
+    MapRec mr_u;      // one view per wave: the camera records arrive through scalar loads, once, instead of ~35 vector
+    TileMapRec tr_u;  // loads of the same address per lane
+    if constexpr (views_per_wave == 1) {
+      const int mu = __builtin_amdgcn_readfirstlane(m);
+      const MapRec *src = maps + mu;
+      const TileMapRec *tsrc = a.tile_maps + mu;
 #pragma unroll
-    for (int q = 8; q < 12; ++q) mr_u.rt[q] = cload(&src->rt[q]);
-    mr_u.pyramid = cload(&src->pyramid);
-    tr_u.px = cload(&tsrc->px); tr_u.py = cload(&tsrc->py); tr_u.pz = cload(&tsrc->pz); tr_u.p0 = cload(&tsrc->p0);
-    tr_u.qx = cload(&tsrc->qx); tr_u.qy = cload(&tsrc->qy); tr_u.qz = cload(&tsrc->qz); tr_u.q0 = cload(&tsrc->q0);
-    tr_u.err = cload(&tsrc->err);
-    tr_u.cz_err = cload(&tsrc->cz_err);
-    tr_u.errz = cload(&tsrc->errz);
-    mr = &mr_u;
-    if (tr_u.errz != 0.0) {  // general K: unproven, see classify_box
-      fp.cls = BRICK_MIXED;
-    } else if (mine) {
-      fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
-    }
-  } else {
-    if (mine) {
-      if (a.tile_maps[m].errz != 0.0)
+      for (int q = 8; q < 12; ++q) mr_u.rt[q] = cload(&src->rt[q]);
+      mr_u.pyramid = cload(&src->pyramid);
+      tr_u.px = cload(&tsrc->px); tr_u.py = cload(&tsrc->py); tr_u.pz = cload(&tsrc->pz); tr_u.p0 = cload(&tsrc->p0);
+      tr_u.qx = cload(&tsrc->qx); tr_u.qy = cload(&tsrc->qy); tr_u.qz = cload(&tsrc->qz); tr_u.q0 = cload(&tsrc->q0);
+      tr_u.err = cload(&tsrc->err);
+      tr_u.cz_err = cload(&tsrc->cz_err);
+      tr_u.errz = cload(&tsrc->errz);
+      mr = &mr_u;
+      if (tr_u.errz != 0.0) {  // general K: unproven, see classify_box
         fp.cls = BRICK_MIXED;
-      else
-        fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
-    }
-  }
-  const bool query = mine && fp.query;
-  uint8_t cls = fp.cls;
-  const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
-  bool from_window = false;
-  {
-    // per view of the wave (its 64 or 32 lanes): the finest level any lane asks for, and the window of that level's
-    // tiles that covers those lanes' rectangles
-    DepthTile *__restrict__ win = window[wave * views_per_wave + lane / children];
-    int li_w = li;
-    for (int off = children >> 1; off > 0; off >>= 1) li_w = min(li_w, __shfl_xor(li_w, off, 64));
-    if (li_w != 0x7fff) {
-      const int L = kPyramidMinLevel + li_w;
-      const bool at_level = query && li == li_w;
-      int tx0 = at_level ? fp.x0 >> L : 0x7fffffff, ty0 = at_level ? fp.y0 >> L : 0x7fffffff;
-      int tx1 = at_level ? fp.x1 >> L : -1, ty1 = at_level ? fp.y1 >> L : -1;
-      int wx0 = tx0, wy0 = ty0, wx1 = tx1, wy1 = ty1;
-      for (int off = children >> 1; off > 0; off >>= 1) {
-        wx0 = min(wx0, __shfl_xor(wx0, off, 64));
-        wy0 = min(wy0, __shfl_xor(wy0, off, 64));
-        wx1 = max(wx1, __shfl_xor(wx1, off, 64));
-        wy1 = max(wy1, __shfl_xor(wy1, off, 64));
+      } else if (mine) {
+        fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
       }
-      if (wx1 - wx0 < kWindow && wy1 - wy0 < kWindow) {  // uniform over the view's lanes
-        const DepthTile *__restrict__ level = mr->pyramid + P.offset[li_w];
-        const int pitch = P.width[li_w];
-        const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
-        for (int t = child; t < ww * wh; t += children) {
-          const int ty = t / ww, tx = t - ty * ww;
-          win[ty * kWindow + tx] = level[(wy0 + ty) * pitch + wx0 + tx];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (at_level) {
-          TileAcc d;
-          for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) d.add_tile(win[(ty - wy0) * kWindow + (tx - wx0)]);
-          cls = class_from_bounds(a, d, fp.czmin, fp.czmax);
-          from_window = true;
-        }
+    } else {
+      if (mine) {
+        if (a.tile_maps[m].errz != 0.0)
+          fp.cls = BRICK_MIXED;
+        else
+          fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
       }
     }
+    const bool query = mine && fp.query;
+    uint8_t cls = fp.cls;
+    const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
+    bool from_window = false;
+    {
+      // per view of the wave (its 64 or 32 lanes): the finest level any lane asks for, and the window of that level's
+      // tiles that covers those lanes' rectangles
+      DepthTile *__restrict__ win = window[wave * views_per_wave + lane / children];
+      int li_w = li;
+      for (int off = children >> 1; off > 0; off >>= 1) li_w = min(li_w, __shfl_xor(li_w, off, 64));
+      if (li_w != 0x7fff) {
+        const int L = kPyramidMinLevel + li_w;
+        const bool at_level = query && li == li_w;
+        int tx0 = at_level ? fp.x0 >> L : 0x7fffffff, ty0 = at_level ? fp.y0 >> L : 0x7fffffff;
+        int tx1 = at_level ? fp.x1 >> L : -1, ty1 = at_level ? fp.y1 >> L : -1;
+        int wx0 = tx0, wy0 = ty0, wx1 = tx1, wy1 = ty1;
+        for (int off = children >> 1; off > 0; off >>= 1) {
+          wx0 = min(wx0, __shfl_xor(wx0, off, 64));
+          wy0 = min(wy0, __shfl_xor(wy0, off, 64));
+          wx1 = max(wx1, __shfl_xor(wx1, off, 64));
+          wy1 = max(wy1, __shfl_xor(wy1, off, 64));
+        }
+        if (wx1 - wx0 < kWindow && wy1 - wy0 < kWindow) {  // uniform over the view's lanes
+          const DepthTile *__restrict__ level = mr->pyramid + P.offset[li_w];
+          const int pitch = P.width[li_w];
+          const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+          // the view's lanes as 16 columns x children / 16 rows of the window at a time
+          const int tx = child & 15;
+          for (int ty = child >> 4; ty < wh; ty += children / 16)
+            if (tx < ww) win[ty * kWindow + tx] = level[(wy0 + ty) * pitch + wx0 + tx];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (at_level) {
+            TileAcc d;
+            for (int ty = ty0; ty <= ty1; ++ty)
+              for (int tx = tx0; tx <= tx1; ++tx) d.add_tile(win[(ty - wy0) * kWindow + (tx - wx0)]);
+            cls = class_from_bounds(a, d, fp.czmin, fp.czmax);
+            from_window = true;
+          }
+          // the next view of this wave stages into the same window: every lane's reads above come first
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (query && !from_window)
+      cls = class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
+    if (mine) out[m] = cls;
   }
-  if (query && !from_window)
-    cls = class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
-  if (mine) classes[(int64_t)((bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m] = cls;
 }
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
@@ -610,8 +624,7 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
     hipLaunchKernelGGL(classify_coarse_kernel<false>, coarse_grid, dim3(64, 4), 0, stream, a, maps_dev, P, tk, classes, coarse);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const int views_per_block = 4 * (64 / (16 * per_z));
-  const dim3 fine_grid((unsigned)n_boxes, (unsigned)((a.n_maps + views_per_block - 1) / views_per_block));
+  const dim3 fine_grid((unsigned)n_boxes, (unsigned)((a.n_maps + 63) / 64));
   // tiles per axis the fine pass may read for its depth bounds: 2 -> 3 -> 5 took the mixed pairs of cfg 3 from 10.1 M to
   // 8.4 M to 7.6 M and the fusion from 10.8 to 10.0 to 9.8 ms; more gains nothing at 8-pixel tiles, and 4-pixel tiles
   // cost more in this pass than they save in the next (profiles/r01zm_*)

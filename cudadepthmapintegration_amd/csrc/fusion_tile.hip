@@ -313,6 +313,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   asm("" : "+v"(vW));
   asm("" : "+v"(vH));
   [[maybe_unused]] const double Wd = pinned((double)KA(W));  // the row pitch as the interior column multiplies it
+  double tiny = 0x1p-20;  // the reciprocal seed's residual must stay below this; a value in registers, not a literal
+  asm volatile("" : "+v"(tiny));  // rebuilt with two scalar moves next to every voxel's compare
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
   // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           // residual |e0| must be below 2^-20 (errk includes the 2^-22 of DESIGN.md 4.4, scaled so that errk * r covers
           // it).  A NaN anywhere makes r, and with it chk, a NaN: not accepted.
           const double chk = __builtin_fma(errk, r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
-          const mask_t m_proven = ballot(chk < 0.5) & ballot(__builtin_fabs(e0) < 0x1p-20);
+          const mask_t m_proven = ballot(chk < 0.5) & ballot(__builtin_fabs(e0) < tiny);
           // Lane masks are kept as 64-bit wave-uniform values (SGPR pairs): every ballot is one v_cmp, all the logic
           // between them runs on the scalar unit.
           mask_t m_in, m_und;
@@ -560,7 +562,15 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             // + 0 (cu:115) matters only where a sum can be -0.0: never, when the grid started at +0.0 (behind_mask set)
             if (!SURFACE && keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_behind_far);
             const mask_t m_near = m_hit & ~(m_front_far | m_behind_far);
-            if (m_near) {
+            if (SURFACE) {
+              // one add of a per-lane value instead of three masked adds of the class values: rho * sign(diff) on the
+              // plateau (cu:117: |diff| > thick >= 0 there, so diff != 0 and its sign bit is the sign), else cu:119
+              if (m_near) {
+                const int rh = __double2hiint(rho_pos) ^ (__double2hiint(diff) & (int)0x80000000);
+                const double near = __builtin_fabs(diff) > thick ? __hiloint2double(rh, __double2loint(rho_pos)) : slope * diff;
+                acc_add_v<BASE, TK>(kk, m_near, near);
+              }
+            } else if (m_near) {
               const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
               const mask_t m_pos = ballot(diff > 0);                                 // the sign of cu:112
               acc_add_s<BASE, TK>(kk, m_plat & m_pos, rho_pos);                       // rho * +1 (cu:117)
