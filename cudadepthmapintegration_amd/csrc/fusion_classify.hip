@@ -569,6 +569,38 @@ __global__ __launch_bounds__(kOrderChunk) void order_scatter_kernel(const uint8_
   }
 }
 
+// The same for one-wave workgroups (slot = wave brick), four slots per wave: 16 lanes read a slot's class row 16 bytes
+// per lane (256 views per pass), so a wave issues one load where the kernel above issues four per slot.
+__global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, int n_slots, uint8_t *__restrict__ level) {
+  const int lane = threadIdx.x & 63;
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);  // slot within the slab being fused
+  const int part = lane & 15;
+  int bx = 0, by = 0, bz = 0;
+  const bool exists = slot < n_slots;
+  const bool in_grid = exists && slot_to_brick(a, slot + a.slot_base, bx, by, bz);
+  int mixed = 0;
+  if (in_grid) {
+    const uint8_t *row = a.classes + (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * (int64_t)a.class_pitch + a.first_map;
+    for (int v0 = part * 16; v0 < a.n_maps; v0 += 256) {
+      if (((a.first_map | a.class_pitch) & 15) == 0 && v0 + 16 <= a.n_maps) {  // rows and the run start on 16-byte boundaries
+        const uint4 w = *reinterpret_cast<const uint4 *>(row + v0);
+        const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t c = words[q];
+          const uint32_t nz = (c | (c >> 1)) & 0x01010101u;  // a byte whose low two bits are not 00 (BRICK_MIXED)
+          mixed += 4 - __builtin_popcount(nz);
+        }
+      } else {
+        for (int v = v0; v < min(v0 + 16, a.n_maps); ++v) mixed += (row[v] & 3) == BRICK_MIXED ? 1 : 0;
+      }
+    }
+  }
+  for (int off = 8; off > 0; off >>= 1) mixed += __shfl_xor(mixed, off, 64);
+  if (exists && part == 0)
+    level[slot] = !in_grid ? 255 : (mixed * 2 >= a.n_maps ? 0 : (mixed * 8 >= a.n_maps ? 1 : (mixed > 0 ? 2 : 3)));
+}
+
 inline unsigned blocks_of(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -665,7 +697,10 @@ int64_t coarse_class_bytes(const TileArgs &a, int tk) {
 hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level, int *order, int *n_valid,
                                hipStream_t stream) {
   const int n_slots = a.super_x * a.super_y * a.super_z * 32;
-  hipLaunchKernelGGL(brick_work_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, stream, a, wx, wy, n_slots, level);
+  if (wx == 1 && wy == 1)
+    hipLaunchKernelGGL(brick_work_kernel_1x1, dim3((unsigned)((n_slots + 15) / 16)), dim3(256), 0, stream, a, n_slots, level);
+  else
+    hipLaunchKernelGGL(brick_work_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, stream, a, wx, wy, n_slots, level);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // per-chunk counts live behind the levels in the same scratch buffer (order_scratch_bytes)
