@@ -91,6 +91,13 @@ struct dmi_context {
   uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch], then the coarse table [boxes][class_pitch]
   size_t coarse_offset = 0;      // byte offset of the coarse table within d_classes (last fuse)
   size_t classes_capacity = 0;   // bytes
+  // slot enumeration of the tiled kernel (TileArgs::sb_perm), one table per slab geometry seen (the z-slabs of a
+  // multi-GPU fusion come round again every step)
+  struct SlotPerm {
+    int32_t super_x, super_y, super_z, zmajor;
+    int32_t *d_perm;
+  };
+  std::vector<SlotPerm> slot_perms;
   uint8_t *d_order_level = nullptr;  // workgroup order: scratch levels, order[], count
   int32_t *d_order = nullptr;
   size_t order_capacity = 0;     // slots
@@ -722,6 +729,7 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_maps) (void)hipFree(ctx->d_maps);
   if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
   if (ctx->d_cz_table) (void)hipFree(ctx->d_cz_table);
+  for (auto &sp : ctx->slot_perms) (void)hipFree(sp.d_perm);
   if (ctx->d_fuse_args) (void)hipFree(ctx->d_fuse_args);
   if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
   if (ctx->d_stage_cost) (void)hipFree(ctx->d_stage_cost);
@@ -867,6 +875,56 @@ int fuse_impl(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, i
   return DMI_OK;
 }
 
+// TileArgs::sb_perm for a slab of super_x x super_y x super_z super-bricks: the super-bricks sorted by the Morton code of
+// their coordinates (z-major order when asked for: the enumeration until r03h).  Built on the host once per geometry.
+int slot_permutation(dmi_context *ctx, int32_t super_x, int32_t super_y, int32_t super_z, bool zmajor, const int32_t **out) {
+  for (const auto &sp : ctx->slot_perms)
+    if (sp.super_x == super_x && sp.super_y == super_y && sp.super_z == super_z && sp.zmajor == (zmajor ? 1 : 0)) {
+      *out = sp.d_perm;
+      return DMI_OK;
+    }
+  if (super_x > 1023 || super_y > 1023 || super_z > 1023)
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: more than 1023 super-bricks along an axis");
+  const size_t n = (size_t)super_x * super_y * super_z;
+  auto spread = [](uint64_t v) {  // bit i -> bit 3i (10 bits)
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000ffull;
+    v = (v | (v << 8)) & 0x0300f00full;
+    v = (v | (v << 4)) & 0x030c30c3ull;
+    v = (v | (v << 2)) & 0x09249249ull;
+    return v;
+  };
+  std::vector<std::pair<uint64_t, int32_t>> keyed(n);
+  size_t q = 0;
+  for (int32_t z = 0; z < super_z; ++z)
+    for (int32_t y = 0; y < super_y; ++y)
+      for (int32_t x = 0; x < super_x; ++x, ++q)
+        keyed[q] = {zmajor ? (uint64_t)q : (spread(x) | (spread(y) << 1) | (spread(z) << 2)), x | (y << 10) | (z << 20)};
+  if (!zmajor) std::sort(keyed.begin(), keyed.end());
+  std::vector<int32_t> perm(n);
+  for (size_t i = 0; i < n; ++i) perm[i] = keyed[i].second;
+  int32_t *d = nullptr;
+  DMI_HIP(ctx, hipMalloc(&d, n * sizeof(int32_t)));
+  // pageable source: the copy has left the host buffer when the call returns
+  hipError_t e = hipMemcpyAsync(d, perm.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return fail(ctx, DMI_ERR_DEVICE, std::string("slot permutation upload: ") + hipGetErrorString(e));
+  }
+  if (ctx->slot_perms.size() >= 64) {  // a caller cycling through more slab geometries than that: start over
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sp : ctx->slot_perms) {
+      (void)hipFree(sp.d_perm);
+      ctx->device_bytes -= (uint64_t)sp.super_x * sp.super_y * sp.super_z * sizeof(int32_t);
+    }
+    ctx->slot_perms.clear();
+  }
+  ctx->slot_perms.push_back({super_x, super_y, super_z, zmajor ? 1 : 0, d});
+  ctx->device_bytes += n * sizeof(int32_t);
+  *out = d;
+  return DMI_OK;
+}
+
 int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, int32_t z_count, bool tiled, int run_k_mode,
              bool general_k) {
   const int32_t n_views = (int32_t)ctx->h_maps.size();
@@ -951,8 +1009,12 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       t.sbz_first = z_first / (2 * sh.tk);
       t.super_z = (z_first + z_count + 2 * sh.tk - 1) / (2 * sh.tk) - t.sbz_first;
     }
+    if (t.bricks_x > 2047 || t.bricks_y > 2047 || t.bricks_z > 1023)  // pack_brick (fusion_kernels.h)
+      return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse: more bricks along an axis than the tiled kernel's order entries hold");
     t.slot_base = t.sbz_first * t.super_x * t.super_y * 32;
     t.slot_count = t.super_x * t.super_y * t.super_z * 32;
+    rc = slot_permutation(ctx, t.super_x, t.super_y, t.super_z, (cfg.variant & dmi::VAR_ZMAJOR_SLOTS) != 0, &t.sb_perm);
+    if (rc != DMI_OK) return rc;
     // spatial order: one z-layer of super-bricks per XCD and round (long runs keep an XCD on one region of every
     // depth map); heaviest-first order: one super-brick's worth, so that the heavy bricks spread over all XCDs
     t.xcd_run_wg = 32 * std::max(1, t.super_x * t.super_y);

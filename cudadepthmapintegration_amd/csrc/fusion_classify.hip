@@ -460,12 +460,12 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
 // (23 % of the wave slots idle at cfg 3).  So workgroup bricks are partitioned by their share of BRICK_MIXED
 // pairs, heaviest level first, each level kept in spatial (super-brick) order for L2 locality.
 
-// slot = super_brick * 32 + brick within the 4 x 4 x 2 super-brick, over the whole grid (absolute)
+// slot = slot_base + 32 * n + brick within the 4 x 4 x 2 super-brick, n = position of the super-brick in the slab's
+// enumeration (TileArgs::sb_perm: Z-order)
 __device__ __forceinline__ bool slot_to_brick(const TileArgs &a, int slot, int &bx, int &by, int &bz) {
-  const int sb = slot >> 5, within = slot & 31;
-  const int sbx = sb % a.super_x;
-  const int sbt = sb / a.super_x;
-  const int sby = sbt % a.super_y, sbz = sbt / a.super_y;
+  const int within = slot & 31;
+  const int code = a.sb_perm[(slot - a.slot_base) >> 5];
+  const int sbx = code & 1023, sby = (code >> 10) & 1023, sbz = (code >> 20) + a.sbz_first;
   bx = sbx * 4 + (within & 3);
   by = sby * 4 + ((within >> 2) & 3);
   bz = sbz * 2 + (within >> 4);
@@ -544,9 +544,9 @@ __global__ __launch_bounds__(1024) void order_base_kernel(int *__restrict__ coun
   if (threadIdx.x == 0) *n_valid = carry;
 }
 
-// order[base(level, chunk) + rank of the slot among its chunk's slots of that level] = absolute slot
-__global__ __launch_bounds__(kOrderChunk) void order_scatter_kernel(const uint8_t *__restrict__ level, int n_slots,
-                                                                    int slot_base, const int *__restrict__ bases,
+// order[base(level, chunk) + rank of the slot among its chunk's slots of that level] = the slot's brick
+__global__ __launch_bounds__(kOrderChunk) void order_scatter_kernel(const TileArgs a, const uint8_t *__restrict__ level,
+                                                                    int n_slots, const int *__restrict__ bases,
                                                                     int *__restrict__ order) {
   __shared__ unsigned long long wave_totals[16];
   const int s = blockIdx.x * kOrderChunk + threadIdx.x;
@@ -565,7 +565,10 @@ __global__ __launch_bounds__(kOrderChunk) void order_scatter_kernel(const uint8_
   for (int w = 0; w < wave; ++w) before += wave_totals[w];
   if (l < kWorkLevels) {
     const int rank = (int)(((before + incl - one) >> (16 * l)) & 0xffffull);
-    order[bases[blockIdx.x * kWorkLevels + l] + rank] = s + slot_base;
+    // the entry is the brick itself (pack_brick): the fusion kernel's workgroups start from one scalar load
+    int bx = 0, by = 0, bz = 0;
+    slot_to_brick(a, s + a.slot_base, bx, by, bz);
+    order[bases[blockIdx.x * kWorkLevels + l] + rank] = pack_brick(bx, by, bz);
   }
 }
 
@@ -708,8 +711,7 @@ hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level
   const int n_chunks = (n_slots + kOrderChunk - 1) / kOrderChunk;
   hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, level, n_slots, counts);
   hipLaunchKernelGGL(order_base_kernel, dim3(1), dim3(1024), 0, stream, counts, n_chunks, n_valid);
-  hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, level, n_slots, a.slot_base,
-                     counts, order);
+  hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, a, level, n_slots, counts, order);
   return hipGetLastError();
 }
 

@@ -118,7 +118,8 @@ struct TileArgs {
   int32_t class_pitch;
   int32_t wbricks_x, wbricks_y;          // wave bricks (8 x 8 x column) per axis, x fastest
   int32_t xcd_run_wg;                    // workgroups dealt to one XCD in a row
-  // workgroup order (fusion_classify.hip): slot of the p-th workgroup, heaviest bricks first; nullptr = spatial order
+  // workgroup order (fusion_classify.hip): brick of the p-th workgroup (pack_brick), heaviest bricks first; nullptr =
+  // the enumeration's own order
   const int32_t *order;
   const int32_t *n_order;                // number of entries of `order` (device)
   // 0x0101010101010101 when adding +0.0 cannot change any running sum (the grid starts at +0.0 and there are no hit
@@ -138,8 +139,14 @@ struct TileArgs {
   // and fetches the sum when the first view with per-voxel work arrives, instead of adding per view and voxel.
   // nullptr: not available (the grid does not start from zeros, or more views than kFreeSumsMax)
   const double *free_sums;
+  // super-brick of the n-th entry of the slot enumeration, n = (slot - slot_base) / 32: sbx | sby << 10 | (sbz - sbz_first)
+  // << 20.  Z-order (Morton) over the slab being fused, so that a contiguous share of the enumeration -- an XCD's eighth of
+  // a work level -- is a compact region in all three axes and projects onto a small part of every depth map.
+  const int32_t *sb_perm;
 };
 constexpr int kFreeSumsMax = 4096;
+// an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)
+__host__ __device__ inline int32_t pack_brick(int bx, int by, int bz) { return (int32_t)((uint32_t)bx | ((uint32_t)by << 11) | ((uint32_t)bz << 22)); }
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
   TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
@@ -188,7 +195,8 @@ enum VariantBits : int {
   VAR_FIXED_TILE_SHAPE = 4096,  // tiled kernel: tile-shape bits 0 mean shape 0 whatever the grid size (no automatic choice)
   VAR_KEEP_BEHIND_ADDS = 1024,  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
   VAR_NO_INTERIOR = 2048,       // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
-  VAR_XCD_RUNS = 8192           // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
+  VAR_XCD_RUNS = 8192,          // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
+  VAR_ZMAJOR_SLOTS = 16384      // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

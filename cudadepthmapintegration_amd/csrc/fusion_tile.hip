@@ -216,13 +216,13 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // the grid (the work per brick depends on how close it is to a surface).
   const int b = blockIdx.x;
   const int q = b >> 3;                         // q-th workgroup of this block's XCD
-  // slots are absolute (whole grid); a slab fuse (dmi_fuse_slab) covers slots [slot_base, slot_base + slot_count)
-  int slot;
+  int entry = -1;  // the brick as the ordering kernels pack it (pack_brick), when there is an order
+  int p = -1;      // else: position in the slab's own enumeration
   if (KA(order) && !(KA(flags) & TILE_FLAG_XCD_RUNS)) {
-    // Bricks ordered heaviest level first, spatial order inside a level (fusion_classify.hip).  Every XCD takes ONE
-    // contiguous eighth of every level, heaviest level first: all XCDs start on heavy bricks, and what an XCD works on
-    // is a compact region of the grid per level, so its L2 is asked for a band of every depth table instead of all of
-    // it (dealt in runs, every XCD fetched nearly every table: 8 x the tables' size in fabric traffic).
+    // Bricks ordered heaviest level first, the enumeration's (Z-)order inside a level (fusion_classify.hip).  Every XCD
+    // takes ONE contiguous eighth of every level, heaviest level first: all XCDs start on heavy bricks, and what an XCD
+    // works on is a compact region of the grid per level, so its L2 is asked for a part of every depth table instead of all
+    // of it (dealt in runs, every XCD fetched nearly every table: 8 x the tables' size in fabric traffic).
     const int xcd = b & 7;
     int rest = q, found = -1;
     int lo = cload(KA(order_levels));
@@ -240,23 +240,26 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       lo = hi;
     }
     if (found < 0) return;
-    slot = cload(KA(order) + found);
+    entry = cload(KA(order) + found);
   } else {
     const int run = KA(xcd_run_wg);             // workgroups dealt to one XCD in a row
-    const int p = (q / run) * (8 * run) + (b & 7) * run + q % run;
-    slot = p + KA(slot_base);
+    p = (q / run) * (8 * run) + (b & 7) * run + q % run;
     if (KA(order)) {
       if (p >= cload(KA(n_order))) return;
-      slot = cload(KA(order) + p);
+      entry = cload(KA(order) + p);
     } else if (p >= KA(slot_count)) {
       return;
     }
   }
-  const int sb = slot >> 5, within = slot & 31;
-  const int sbx = sb % KA(super_x);
-  const int sbt = sb / KA(super_x);
-  const int sby = sbt % KA(super_y), sbz = sbt / KA(super_y);
-  const int bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
+  int bx, by, bz;
+  if (KA(order)) {
+    bx = entry & 2047, by = (entry >> 11) & 2047, bz = (int)((unsigned)entry >> 22);
+  } else {
+    const int within = p & 31;
+    const int code = cload(KA(sb_perm) + (p >> 5));  // the slab's super-bricks in Z-order (fusion_kernels.h)
+    const int sbx = code & 1023, sby = (code >> 10) & 1023, sbz = (code >> 20) + KA(sbz_first);
+    bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
+  }
   if (bx >= KA(bricks_x) || by >= KA(bricks_y) || bz >= KA(bricks_z)) return;  // padding of the super-brick grid
 
   const int lane = threadIdx.x & 63;
