@@ -94,9 +94,6 @@ def main():
         lines += [f"## PMC, mean per dispatch: `{k[:100]}`", "", f"resources as rocprofv3 prints them: {c['_meta']}",
                   "(on gfx950 its VGPR_Count is half of what the kernel descriptor allocates: the build's register audit, "
                   "build/obj/acc_audit.json, and llvm-readelf give the number of 32-bit registers)", ""]
-        g = c.get("GRBM_GUI_ACTIVE")
-        if g and kern_ms:
-            lines.append(f"* effective clock = GRBM_GUI_ACTIVE / 8 / t = {g / 8 / (kern_ms * 1e-3) / 1e9:.2f} GHz")
         if "SQ_INSTS_VALU" in c:
             v = c["SQ_INSTS_VALU"]
             lines.append(f"* SQ_INSTS_VALU = {v:.4g} wave-instructions" +
