@@ -365,6 +365,9 @@ def main():
 
     dt, kern_ms = timed(args.steps, args.warmup)
     main_ms = timed.main_ms  # the fusion kernel proper (what rocprofv3 lists as fuse_tile_kernel / fuse_kernel)
+    # what this box's vector units sustain right now on bare fp64 FMAs: boxes of the same model differ (the same library
+    # has measured 5.0 and 7.1 ms per fusion kernel within the hour), and the fusion kernel is bound by fp64 vector issue
+    fp64_now = capi.fp64_probe(local_rank, 20.0)
     ms_per_step = dt / args.steps * 1e3
     value = n_vox * maps_per_gpu * args.steps / dt / 1e9
 
@@ -489,6 +492,8 @@ def main():
                     "the default path proves most (brick, view) pairs uniform and skips their projections",
         },
         "brick_classes": hist,
+        "box_state": {"fp64_vector_tflops_now": fp64_now, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                      "note": "dmi_fp64_probe right after the timed steps: independent v_fma_f64 chains on every SIMD for 20 ms"},
     }
     if ablation:
         out["ablation"] = ablation

@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "dmi_default_options", "dmi_create", "dmi_destroy", "dmi_last_error", "dmi_add_views", "dmi_add_views_f32",
     "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_fuse_slab", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
-    "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_abi_version", "dmi_device_count",
+    "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_fp64_probe", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
     "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram",
@@ -165,6 +165,7 @@ def load() -> ctypes.CDLL:
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.dmi_free_pinned.argtypes = [vp]
     L.dmi_pcie_probe.argtypes = [i32, ctypes.c_size_t, dp, dp]
+    L.dmi_fp64_probe.argtypes = [i32, ctypes.c_double, dp]
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.dmi_color_mesh.argtypes = [dp, ctypes.c_int64, u8p, dp, dp, i32, i32, i32, i32, u8p, u8p, ctypes.POINTER(ctypes.c_int32)]
     L.dmi_color_create.argtypes = [i32, ctypes.POINTER(vp)]
@@ -234,6 +235,16 @@ def pcie_probe(device: int = 0, n_bytes: int = 256 << 20) -> tuple[float, float]
     if rc != DMI_OK:
         raise DmiError(rc, L.dmi_last_error(None).decode())
     return float(a.value), float(b.value)
+
+
+def fp64_probe(device: int = 0, milliseconds: float = 20.0) -> float:
+    """fp64 vector TFLOP/s the device sustains right now on independent v_fma_f64 chains (dmi_fp64_probe)."""
+    L = load()
+    a = ctypes.c_double()
+    rc = L.dmi_fp64_probe(int(device), float(milliseconds), ctypes.byref(a))
+    if rc != DMI_OK:
+        raise DmiError(rc, L.dmi_last_error(None).decode())
+    return float(a.value)
 
 
 def device_count() -> int:

@@ -1457,6 +1457,49 @@ int dmi_pcie_probe(int32_t device, size_t bytes, double *h2d_GBps, double *d2h_G
   });
 }
 
+int dmi_fp64_probe(int32_t device, double milliseconds, double *tflops) {
+  return guarded(nullptr, "dmi_fp64_probe", [&]() -> int {
+    if (!tflops || !(milliseconds > 0.0) || milliseconds > 1000.0)
+      return fail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_fp64_probe: an output and 0 < milliseconds <= 1000");
+    dmi_context *none = nullptr;
+    DMI_HIP(none, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    DMI_HIP(none, hipGetDeviceProperties(&prop, device));
+    const int blocks = std::max(1, prop.multiProcessorCount) * 8;  // eight workgroups of four waves per CU
+    double *out = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&out, (size_t)blocks * 256 * sizeof(double));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    int iters = 4096;  // the first pass sizes the others
+    for (int rep = 0; e == hipSuccess && rep < 4; ++rep) {
+      e = hipEventRecord(e0, s);
+      if (e == hipSuccess) e = dmi::launch_fp64_probe(out, blocks, iters, s);
+      if (e == hipSuccess) e = hipEventRecord(e1, s);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e != hipSuccess || !(ms > 0.f)) break;
+      const double flops = 2.0 * 8.0 * (double)iters * (double)blocks * 256.0;
+      if (rep > 0) best = std::max(best, flops / (ms * 1e-3) / 1e12);
+      if (rep == 0) iters = (int)std::min(4.0e6, std::max(1024.0, iters * milliseconds / ms));
+    }
+    if (e1) (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (s) (void)hipStreamDestroy(s);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(nullptr, DMI_ERR_DEVICE, std::string("dmi_fp64_probe: ") + hipGetErrorString(e));
+    }
+    *tflops = best;
+    return DMI_OK;
+  });
+}
+
 int dmi_free_pinned(void *ptr) {
   return guarded(nullptr, "dmi_free_pinned", [&]() -> int {
   if (!ptr) return DMI_OK;

@@ -227,6 +227,9 @@ hipError_t launch_widen_depth(const float *in, double *out, int64_t n, hipStream
 // n grid elements f64 -> f32 (in_is_f64) or f32 -> f64, device to device
 hipError_t launch_convert_grid(const void *in, int in_is_f64, void *out, int64_t n, hipStream_t stream);
 
+// dmi_fp64_probe: `iters` rounds of eight independent fp64 FMAs per lane; out[thread] keeps the chains alive
+hipError_t launch_fp64_probe(double *out, int blocks, int iters, hipStream_t stream);
+
 // min/max pyramids of n_maps depth tables (device, top-down rows) into pyramids[n_maps][desc.total_tiles]
 PyramidDesc make_pyramid_desc(int W, int H);
 hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &desc,

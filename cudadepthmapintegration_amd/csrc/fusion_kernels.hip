@@ -238,6 +238,22 @@ hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int
   return hipGetLastError();
 }
 
+// eight independent chains per lane: enough to cover the FMA latency at any occupancy
+__global__ __launch_bounds__(256) void fp64_probe_kernel(double *__restrict__ out, int iters) {
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-12 * blockIdx.x;
+  double v0 = 0.1, v1 = 0.2, v2 = 0.3, v3 = 0.4, v4 = 0.5, v5 = 0.6, v6 = 0.7, v7 = 0.8;
+  for (int n = 0; n < iters; ++n) {
+    v0 = __builtin_fma(v0, a, b); v1 = __builtin_fma(v1, a, b); v2 = __builtin_fma(v2, a, b); v3 = __builtin_fma(v3, a, b);
+    v4 = __builtin_fma(v4, a, b); v5 = __builtin_fma(v5, a, b); v6 = __builtin_fma(v6, a, b); v7 = __builtin_fma(v7, a, b);
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+}
+
+hipError_t launch_fp64_probe(double *out, int blocks, int iters, hipStream_t stream) {
+  hipLaunchKernelGGL(fp64_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, iters);
+  return hipGetLastError();
+}
+
 hipError_t launch_convert_grid(const void *in, int in_is_f64, void *out, int64_t n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   if (in_is_f64)

@@ -222,6 +222,10 @@ int dmi_free_pinned(void *ptr);
 /* Diagnostic: the host <-> device copy rates (GB/s, pinned memory, one hipMemcpyAsync of `bytes` each way, best of two)
  * that bound every PCIe-inclusive figure of this path -- the roof next to which bench.py quotes its end-to-end numbers. */
 int dmi_pcie_probe(int32_t device, size_t bytes, double *h2d_GBps, double *d2h_GBps);
+/* Diagnostic: the fp64 vector rate this device sustains right now (TFLOP/s; a kernel of dependent-free v_fma_f64 chains
+ * on every SIMD for about `milliseconds`, best of three).  The fusion kernel is bound by fp64 vector issue, and boxes of
+ * the same model differ and drift: bench.py quotes this next to its figures so that runs on different boxes compare. */
+int dmi_fp64_probe(int32_t device, double milliseconds, double *tflops);
 
 /* ---- MeshColoration pass (Coloration/MeshColoration.cxx:98-199; the reference runs it on the CPU) ----
  * For every mesh vertex: the views whose projection of the vertex (RD.cxx:169-182: no z-sign test, no depth

@@ -573,3 +573,11 @@ def test_pcie_probe_reports_plausible_rates():
     assert 1.0 < h2d < 500.0 and 1.0 < d2h < 500.0
     with pytest.raises(capi.DmiError):
         capi.pcie_probe(0, 1024)
+
+
+def test_fp64_probe_reports_a_plausible_rate():
+    """dmi_fp64_probe: the fp64 vector rate of the box, quoted by bench.py next to its figures (peak 78.6 TFLOP/s)."""
+    rate = capi.fp64_probe(0, 5.0)
+    assert 5.0 < rate < 100.0
+    with pytest.raises(capi.DmiError):
+        capi.fp64_probe(0, -1.0)
