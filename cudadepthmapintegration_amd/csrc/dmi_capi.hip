@@ -91,6 +91,9 @@ struct dmi_context {
   uint8_t *d_classes = nullptr;  // brick classes [wave bricks][class_pitch], then the coarse table [boxes][class_pitch]
   size_t coarse_offset = 0;      // byte offset of the coarse table within d_classes (last fuse)
   size_t classes_capacity = 0;   // bytes
+  int32_t *d_queue_heads = nullptr;          // TileArgs::queue_heads (128 ints)
+  unsigned long long *d_wg_times = nullptr;  // tuning builds: TileArgs::wg_times of the last tiled fuse
+  size_t wg_times_blocks = 0;
   // slot enumeration of the tiled kernel (TileArgs::sb_perm), one table per slab geometry seen (the z-slabs of a
   // multi-GPU fusion come round again every step)
   struct SlotPerm {
@@ -729,6 +732,8 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_maps) (void)hipFree(ctx->d_maps);
   if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
   if (ctx->d_cz_table) (void)hipFree(ctx->d_cz_table);
+  if (ctx->d_wg_times) (void)hipFree(ctx->d_wg_times);
+  if (ctx->d_queue_heads) (void)hipFree(ctx->d_queue_heads);
   for (auto &sp : ctx->slot_perms) (void)hipFree(sp.d_perm);
   if (ctx->d_fuse_args) (void)hipFree(ctx->d_fuse_args);
   if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
@@ -1054,6 +1059,8 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       ctx->device_bytes += grown * 8;
     }
     t.cz_table = ctx->d_cz_table;
+    if (!ctx->d_queue_heads) DMI_HIP(ctx, hipMalloc(&ctx->d_queue_heads, 128 * sizeof(int32_t)));
+    t.queue_heads = ctx->d_queue_heads;
     // valid while every sum of the launch starts at +0.0 and hits are not counted (counted views are taken one by one)
     if (!a.init_from_grid && !ctx->opt.count_hits && count <= dmi::kFreeSumsMax) t.free_sums = ctx->d_cz_table + table_doubles;
     // brick classes: one byte per (8 x 8 x column wave brick, resident view)
@@ -1127,6 +1134,21 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     if (!a.init_from_grid && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS))
       t.behind_mask = 0x0101010101010101ull;
 #ifdef DMI_TUNING
+    if (std::getenv("DMI_DEBUG_WG_TIMES")) {  // per-workgroup start / end / XCC (tools/gpu_wg_timeline.py)
+      const size_t per_round = 8 * (size_t)t.xcd_run_wg;
+      const size_t blocks = ((size_t)t.super_x * t.super_y * t.super_z * 32 + 32 + per_round - 1) / per_round * per_round;  // launch_shape
+      if (ctx->wg_times_blocks < blocks) {
+        if (ctx->d_wg_times) {
+          DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          (void)hipFree(ctx->d_wg_times);
+        }
+        DMI_HIP(ctx, hipMalloc(&ctx->d_wg_times, blocks * 3 * sizeof(unsigned long long)));
+        ctx->wg_times_blocks = blocks;
+      }
+      DMI_HIP(ctx, hipMemsetAsync(ctx->d_wg_times, 0, blocks * 3 * sizeof(unsigned long long), ctx->stream));
+      t.wg_times = ctx->d_wg_times;
+      t.wg_times_n = (int64_t)blocks;
+    }
     if (const char *e = std::getenv("DMI_XCD_RUN_WG")) {  // launch-geometry experiments
       t.xcd_run_wg = std::max(1, std::atoi(e));
       if (((int64_t)t.super_x * t.super_y * t.super_z * 32 + 8 * (int64_t)t.xcd_run_wg) > (int64_t)0x7fffffff)
@@ -1456,6 +1478,19 @@ int dmi_pcie_probe(int32_t device, size_t bytes, double *h2d_GBps, double *d2h_G
     return DMI_OK;
   });
 }
+
+#ifdef DMI_TUNING
+// tuning builds only (not part of the ABI): the TileArgs::wg_times record of the last tiled fuse, 3 * blocks values
+extern "C" int dmi_debug_wg_times(dmi_context *ctx, unsigned long long *out, int64_t capacity, int64_t *blocks) {
+  if (!ctx || !blocks) return DMI_ERR_INVALID_ARGUMENT;
+  *blocks = (int64_t)ctx->wg_times_blocks;
+  if (!ctx->d_wg_times || !out || capacity < 3 * (int64_t)ctx->wg_times_blocks) return DMI_OK;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return DMI_ERR_DEVICE;
+  if (hipMemcpy(out, ctx->d_wg_times, ctx->wg_times_blocks * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return DMI_ERR_DEVICE;
+  return DMI_OK;
+}
+#endif
 
 int dmi_fp64_probe(int32_t device, double milliseconds, double *tflops) {
   return guarded(nullptr, "dmi_fp64_probe", [&]() -> int {

@@ -143,6 +143,13 @@ struct TileArgs {
   // << 20.  Z-order (Morton) over the slab being fused, so that a contiguous share of the enumeration -- an XCD's eighth of
   // a work level -- is a compact region in all three axes and projects onto a small part of every depth map.
   const int32_t *sb_perm;
+  // tuning builds (DMI_TUNING) with DMI_DEBUG_WG_TIMES set, u = the brick's position in the order: [2u] = s_memrealtime
+  // (100 MHz) when its workgroup has found it, [2u + 1] = just before the sums are stored, [2 * wg_times_n + u] = the
+  // XCC_ID it ran on | blockIdx.x << 8; nullptr otherwise (tools/gpu_wg_timeline.py)
+  unsigned long long *wg_times;
+  int64_t wg_times_n;
+  // brick counters of the persistent workgroups, one per XCD at [16 * xcd]; zeroed by the table kernel of every launch
+  int32_t *queue_heads;
 };
 constexpr int kFreeSumsMax = 4096;
 // an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)

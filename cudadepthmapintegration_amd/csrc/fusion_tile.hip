@@ -31,6 +31,7 @@
 // Results are bit-identical to the general kernel and to oracle/tsdf_oracle.c (tests/test_gpu_parity.py).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "fusion_kernels.h"
@@ -207,104 +208,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   constexpr int kGroup = GROUP;
   typedef double czvec __attribute__((ext_vector_type(GROUP)));
   typedef double czvec4 __attribute__((ext_vector_type(4)));
-  // ---- workgroup -> brick.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD), and
-  // an XCD runs about 32 of these workgroups at a time.  So consecutive blocks OF ONE XCD enumerate one
-  // super-brick of 4 x 4 x 2 bricks: the workgroups an XCD runs together are neighbours in space and their
-  // depth-map footprints overlap in that XCD's L2.  Super-bricks are dealt to the XCDs in runs of KA(xcd_run)
-  // (one z-layer of super-bricks): long enough that an XCD keeps working on one region of every depth map
-  // (dealing single super-bricks round-robin cost 12 %), short enough that every XCD gets layers from all over
-  // the grid (the work per brick depends on how close it is to a surface).
-  const int b = blockIdx.x;
-  const int q = b >> 3;                         // q-th workgroup of this block's XCD
-  int entry = -1;  // the brick as the ordering kernels pack it (pack_brick), when there is an order
-  int p = -1;      // else: position in the slab's own enumeration
-  if (KA(order) && !(KA(flags) & TILE_FLAG_XCD_RUNS)) {
-    // Bricks ordered heaviest level first, the enumeration's (Z-)order inside a level (fusion_classify.hip).  Every XCD
-    // takes ONE contiguous eighth of every level, heaviest level first: all XCDs start on heavy bricks, and what an XCD
-    // works on is a compact region of the grid per level, so its L2 is asked for a part of every depth table instead of all
-    // of it (dealt in runs, every XCD fetched nearly every table: 8 x the tables' size in fabric traffic).
-    const int xcd = b & 7;
-    int rest = q, found = -1;
-    int lo = cload(KA(order_levels));
-#pragma unroll
-    for (int level = 0; level < 4; ++level) {
-      const int hi = level < 3 ? cload(KA(order_levels) + level + 1) : cload(KA(n_order));
-      const int n = hi - lo;
-      const int s0 = (int)(((long long)xcd * n) >> 3), s1 = (int)(((long long)(xcd + 1) * n) >> 3);
-      if (found < 0) {
-        if (rest < s1 - s0)
-          found = lo + s0 + rest;
-        else
-          rest -= s1 - s0;
-      }
-      lo = hi;
-    }
-    if (found < 0) return;
-    entry = cload(KA(order) + found);
-  } else {
-    const int run = KA(xcd_run_wg);             // workgroups dealt to one XCD in a row
-    p = (q / run) * (8 * run) + (b & 7) * run + q % run;
-    if (KA(order)) {
-      if (p >= cload(KA(n_order))) return;
-      entry = cload(KA(order) + p);
-    } else if (p >= KA(slot_count)) {
-      return;
-    }
-  }
-  int bx, by, bz;
-  if (KA(order)) {
-    bx = entry & 2047, by = (entry >> 11) & 2047, bz = (int)((unsigned)entry >> 22);
-  } else {
-    const int within = p & 31;
-    const int code = cload(KA(sb_perm) + (p >> 5));  // the slab's super-bricks in Z-order (fusion_kernels.h)
-    const int sbx = code & 1023, sby = (code >> 10) & 1023, sbz = (code >> 20) + KA(sbz_first);
-    bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
-  }
-  if (bx >= KA(bricks_x) || by >= KA(bricks_y) || bz >= KA(bricks_z)) return;  // padding of the super-brick grid
-
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and provably so
-  const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
-  if (wbx >= KA(wbricks_x) || wby >= KA(wbricks_y)) return;            // wave entirely outside the grid
-  const int i = wbx * kLX + (lane % kLX);
-  const int j = wby * kLY + (lane / kLX);
-  const int k0 = bz * TK;
-  const int kcount = KA(nz) - k0 < TK ? KA(nz) - k0 : TK;  // wave-uniform, >= 1
-  const bool lane_ok = i < KA(nx) && j < KA(ny);
-
-  // cu:78-83 + cu:168 once per lane.  With a diagonal 3x3 grid matrix wx depends on i only, wy on j
-  // only, wz on k only (the off-diagonal products are exact zeros; only the sign of a zero result can
-  // depend on the other indices, and no later step observes it: DESIGN.md).
-  const double gx = KA(ox) + (i + 0.5) * KA(sx);
-  const double gy = KA(oy) + (j + 0.5) * KA(sy);
-  const double gz0 = KA(oz) + ((k0 + KA(kz0)) + 0.5) * KA(sz);
-  // axis-aligned: the lane's world x, y and the column's first z.  Rotated: the (i, j)-dependent part of each world
-  // coordinate, fl(fl(g_r0*gx) + fl(g_r1*gy)) -- the first sum of cu:90-92, which does not depend on k.
-  double gm[12];  // rows 0..2 of the grid matrix
-#pragma unroll
-  for (int q = 0; q < 12; ++q) gm[q] = KA(g)[q];
-  const double wx = ROT ? gm[0] * gx + gm[1] * gy : row4(gm + 0, gx, gy, gz0);
-  const double wy = ROT ? gm[4] * gx + gm[5] * gy : row4(gm + 4, gx, gy, gz0);
-  const double wz0 = ROT ? gm[8] * gx + gm[9] * gy : row4(gm + 8, gx, gy, gz0);
-
-
-  // the TK running sums live in v[BASE ...], outside the compiler's register budget (fusion_tile_acc.inc)
-  uint32_t nh[COUNT ? TK : 1];
-#pragma unroll
-  for (int kk = 0; kk < TK; ++kk) {
-    double v0 = 0.0;
-    if (COUNT) nh[kk] = 0;
-    if (KA(init_from_grid) && lane_ok && kk < kcount)  // cu:211 accumulates onto what the grid holds
-      v0 = (double)static_cast<const GridT *>(KA(grid))[(((int64_t)(k0 + kk)) * KA(ny) + j) * KA(nx) + i];
-    acc_set<BASE, TK>(kk, v0);
-  }
-
-  const mask_t m_lane_ok = ballot(lane_ok);
-  const int first_map = KA(first_map);
-  const int m_end = first_map + KA(n_maps);
   // what every voxel-projection needs: the ray potential's constants (cu:60-63 as FuseArgs holds them) in SGPRs, the
   // depth-map size in VGPRs (two registers the vector file can spare more easily than the scalar one)
   // (rho * -1 == -(rho * +1) exactly, cu:117: one register pair serves both plateau values)
+  const int first_map = KA(first_map);
+  const int m_end = first_map + KA(n_maps);
   double delta = KA(delta), thick = KA(thick), free_space = KA(free_space), rho_pos = KA(rho_pos), slope = KA(slope);
   int keep_zero_adds = KA(behind_mask) == 0 ? 1 : 0;
   // Values, not loads: without this the compiler re-reads them from the argument block (a scalar load and a wait) next
@@ -318,6 +226,136 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   [[maybe_unused]] const double Wd = pinned((double)KA(W));  // the row pitch as the interior column multiplies it
   double tiny = 0x1p-20;  // the reciprocal seed's residual must stay below this; a value in registers, not a literal
   asm volatile("" : "+v"(tiny));  // rebuilt with two scalar moves next to every voxel's compare
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and provably so
+
+  // ---- workgroup -> bricks.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD, verified
+  // with HW_REG_XCC_ID: tools/gpu_wg_timeline.py).  The bricks are ordered heaviest level first, the enumeration's
+  // (Z-)order inside a level (fusion_classify.hip), and every XCD owns ONE contiguous eighth of every level: all XCDs
+  // start on heavy bricks, and what an XCD works on is a compact region of the grid per level, so its L2 is asked for a
+  // part of every depth table instead of all of it.
+  // One-wave workgroups are PERSISTENT: the launch has about as many of them as the chip holds, and each takes the next
+  // brick of its XCD's share from a counter (queue_heads, one per XCD, zeroed by the table kernel of the launch) until the
+  // share is used up, then helps the other XCDs finish theirs.  A brick of the light levels lives 80 us: launched one
+  // workgroup per brick, a tenth of the wave slots sat empty between a workgroup's end and its successor's arrival, and
+  // the XCDs finished up to 0.46 ms apart (profiles/r03p_wg_timeline_*.json).  Every wave reaches the exit: the counters
+  // only grow, and a share is used up once its counter passes its size.
+  constexpr bool PERSIST = WX * WY == 1;
+  const int b = blockIdx.x;
+  int q = b >> 3;   // the q-th brick of an XCD's share
+  int helped = 0;   // PERSIST: how many XCDs' shares this workgroup has seen the end of
+#define DMI_NEXT_BRICK \
+  {                    \
+    if (PERSIST)       \
+      continue;        \
+    else               \
+      return;          \
+  }
+  for (;;) {
+  const int xq = (b + helped) & 7;  // whose share
+  if constexpr (PERSIST) {
+    if (helped == 8) break;
+    int taken = 0;
+    if (lane == 0) taken = atomicAdd(KC(queue_heads) + 16 * xq, 1);
+    q = __builtin_amdgcn_readfirstlane(taken);
+  }
+  int entry = -1;  // the brick as the ordering kernels pack it (pack_brick), when there is an order
+  int p = -1;      // else: position in the slab's own enumeration
+  bool used_up = false;
+  if (KC(order) && !(KC(flags) & TILE_FLAG_XCD_RUNS)) {
+    int rest = q, found = -1;
+    const kernarg_t ko = KFRESH();
+    int lo = cload(ko->order_levels);
+#pragma unroll
+    for (int level = 0; level < 4; ++level) {
+      const int hi = level < 3 ? cload(ko->order_levels + level + 1) : cload(ko->n_order);
+      const int n = hi - lo;
+      const int s0 = (int)(((long long)xq * n) >> 3), s1 = (int)(((long long)(xq + 1) * n) >> 3);
+      if (found < 0) {
+        if (rest < s1 - s0)
+          found = lo + s0 + rest;
+        else
+          rest -= s1 - s0;
+      }
+      lo = hi;
+    }
+    if (found < 0)
+      used_up = true;
+    else
+      entry = cload(ko->order + found);
+    p = found;
+  } else {
+    const int run = KC(xcd_run_wg);             // bricks dealt to one XCD in a row
+    p = (q / run) * (8 * run) + xq * run + q % run;
+    if (KC(order)) {
+      if (p >= cload(KC(n_order)))
+        used_up = true;
+      else
+        entry = cload(KC(order) + p);
+    } else if (p >= KC(slot_count)) {
+      used_up = true;
+    }
+  }
+  if (used_up) {
+    if constexpr (PERSIST) {
+      ++helped;
+      continue;
+    } else {
+      return;
+    }
+  }
+  int bx, by, bz;
+  if (KC(order)) {
+    bx = entry & 2047, by = (entry >> 11) & 2047, bz = (int)((unsigned)entry >> 22);
+  } else {
+    const int within = p & 31;
+    const int code = cload(KC(sb_perm) + (p >> 5));  // the slab's super-bricks in Z-order (fusion_kernels.h)
+    const int sbx = code & 1023, sby = (code >> 10) & 1023, sbz = (code >> 20) + KC(sbz_first);
+    bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
+  }
+  if (bx >= KC(bricks_x) || by >= KC(bricks_y) || bz >= KC(bricks_z)) DMI_NEXT_BRICK  // padding of the super-brick grid
+
+#ifdef DMI_TUNING
+  unsigned long long wg_t0 = 0;
+  if (KC(wg_times)) wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
+  if (wbx >= KC(wbricks_x) || wby >= KC(wbricks_y)) DMI_NEXT_BRICK     // wave entirely outside the grid
+  const int i = wbx * kLX + (lane % kLX);
+  const int j = wby * kLY + (lane / kLX);
+  const int k0 = bz * TK;
+  const int kcount = KC(nz) - k0 < TK ? KC(nz) - k0 : TK;  // wave-uniform, >= 1
+  const bool lane_ok = i < KC(nx) && j < KC(ny);
+
+  // cu:78-83 + cu:168 once per lane.  With a diagonal 3x3 grid matrix wx depends on i only, wy on j
+  // only, wz on k only (the off-diagonal products are exact zeros; only the sign of a zero result can
+  // depend on the other indices, and no later step observes it: DESIGN.md).
+  const kernarg_t kg = KFRESH();
+  const double gx = kg->ox + (i + 0.5) * kg->sx;
+  const double gy = kg->oy + (j + 0.5) * kg->sy;
+  const double gz0 = kg->oz + ((k0 + kg->kz0) + 0.5) * kg->sz;
+  // axis-aligned: the lane's world x, y and the column's first z.  Rotated: the (i, j)-dependent part of each world
+  // coordinate, fl(fl(g_r0*gx) + fl(g_r1*gy)) -- the first sum of cu:90-92, which does not depend on k.
+  double gm[12];  // rows 0..2 of the grid matrix
+#pragma unroll
+  for (int q = 0; q < 12; ++q) gm[q] = kg->g[q];
+  const double wx = ROT ? gm[0] * gx + gm[1] * gy : row4(gm + 0, gx, gy, gz0);
+  const double wy = ROT ? gm[4] * gx + gm[5] * gy : row4(gm + 4, gx, gy, gz0);
+  const double wz0 = ROT ? gm[8] * gx + gm[9] * gy : row4(gm + 8, gx, gy, gz0);
+
+
+  // the TK running sums live in v[BASE ...], outside the compiler's register budget (fusion_tile_acc.inc)
+  uint32_t nh[COUNT ? TK : 1];
+#pragma unroll
+  for (int kk = 0; kk < TK; ++kk) {
+    double v0 = 0.0;
+    if (COUNT) nh[kk] = 0;
+    if (kg->init_from_grid && lane_ok && kk < kcount)  // cu:211 accumulates onto what the grid holds
+      v0 = (double)static_cast<const GridT *>(kg->grid)[(((int64_t)(k0 + kk)) * kg->ny + j) * kg->nx + i];
+    acc_set<BASE, TK>(kk, v0);
+  }
+
+  const mask_t m_lane_ok = ballot(lane_ok);
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
   // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
@@ -631,6 +669,19 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     }
   }
 
+#ifdef DMI_TUNING
+  if (KC(wg_times) && threadIdx.x == 0) {
+    unsigned long long *wt = KC(wg_times);
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const size_t uid = (size_t)p, n_uid = (size_t)KC(wg_times_n);  // the brick's position in the order (or enumeration)
+    if (uid < n_uid) {
+      wt[2 * uid] = wg_t0;
+      wt[2 * uid + 1] = __builtin_amdgcn_s_memrealtime();
+      wt[2 * n_uid + uid] = (xcc & 15u) | ((unsigned long long)blockIdx.x << 8);
+    }
+  }
+#endif
   if (n_uniform > 0) {  // no view had work of its own: every voxel of the brick holds the same sum
     const double v = cload(KC(free_sums) + n_uniform);
 #pragma unroll
@@ -652,7 +703,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       gid += plane;
     }
   }
+  if constexpr (!PERSIST) break;
+  }  // the next brick
 }
+#undef DMI_NEXT_BRICK
 #undef KA
 #undef KC
 #undef KFRESH
@@ -660,6 +714,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 // TileArgs::free_sums: the running sum of n free-space constants (cu:115, cu:211), n = 0 .. n_maps, added one at a time
 // exactly as a voxel's sum receives them.  One thread; the chain of n_maps dependent adds is a few microseconds.
 __device__ __forceinline__ void fill_free_sums(const TileArgs &a) {
+  if (a.queue_heads)  // the fusion kernel's brick counters, one per XCD (16 ints apart)
+    for (int x = 0; x < 8; ++x) a.queue_heads[16 * x] = 0;
   if (!a.free_sums) return;
   double *out = const_cast<double *>(a.free_sums);
   double sum = 0.0;
@@ -702,7 +758,10 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   // super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
   // (+ 32: an XCD's eighths of the four levels can add up to four workgroups more than an eighth of the total)
   const int per_round = 8 * a.xcd_run_wg;
-  const unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + 32 + per_round - 1) / per_round * per_round);
+  unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + 32 + per_round - 1) / per_round * per_round);
+  // one-wave workgroups are persistent (they take bricks from their XCD's counter): as many as the chip holds at the
+  // kernel's occupancy and a few more -- 256 CUs x 4 SIMDs x 8 -- all of them equally spread over the XCDs
+  if (WX * WY == 1) blocks = std::min(blocks, 8192u);
   const dim3 block(64 * WX * WY);
   if (cfg.count_hits)
     hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>), dim3(blocks), block, 0, s, a);
