@@ -753,20 +753,38 @@ __global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double 
   table[4 * k + 3] = 0.0;
 }
 
+// workgroups of `kernel` the device holds at once: what the persistent launch asks for (more would only queue up behind
+// the ones that never leave before the work is done; 8192 instead of 5120 cost 1.5 %, profiles/r03_exp_v_blocks.json)
+template <typename Kernel>
+unsigned resident_workgroups(Kernel kernel, int threads) {
+  int device = 0, per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu <= 0 ||
+      prop.multiProcessorCount <= 0) {
+    (void)hipGetLastError();
+    return 8192u;  // 256 CUs x 4 SIMDs x 8: never fewer than the chip holds
+  }
+  return (unsigned)(per_cu * prop.multiProcessorCount + 7) / 8u * 8u;  // the same number for every XCD
+}
+
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  // super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
+  // one workgroup per brick: super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
   // (+ 32: an XCD's eighths of the four levels can add up to four workgroups more than an eighth of the total)
   const int per_round = 8 * a.xcd_run_wg;
   unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + 32 + per_round - 1) / per_round * per_round);
-  // one-wave workgroups are persistent (they take bricks from their XCD's counter): as many as the chip holds at the
-  // kernel's occupancy and a few more -- 256 CUs x 4 SIMDs x 8 -- all of them equally spread over the XCDs
-  if (WX * WY == 1) blocks = std::min(blocks, 8192u);
   const dim3 block(64 * WX * WY);
+  const auto counted = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>;
+  const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>;
+  if (WX * WY == 1) {  // persistent one-wave workgroups: as many as the chip holds (asked once per instantiation)
+    static const unsigned resident[2] = {resident_workgroups(plain, 64), resident_workgroups(counted, 64)};
+    blocks = std::min(blocks, resident[cfg.count_hits ? 1 : 0]);
+  }
   if (cfg.count_hits)
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL(counted, dim3(blocks), block, 0, s, a);
   else
-    hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>), dim3(blocks), block, 0, s, a);
+    hipLaunchKernelGGL(plain, dim3(blocks), block, 0, s, a);
   return hipGetLastError();
 }
 
