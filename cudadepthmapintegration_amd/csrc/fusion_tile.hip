@@ -26,8 +26,9 @@
 //     u, v to the nearest rounding boundary exceeds a bound on everything the shortcut can have
 //     changed (TileMapRec::err / c.z + 2^-22); the reciprocal's own residual is checked too.
 //     Unproven lanes (about 2^-19 of them) are redone with the reference's expression (tile_exact).
-//   * rayPotential is the reference's arithmetic; its three-way select is executed as EXEC-masked
-//     adds of the class constants, so a wave pays only for the classes it contains.
+//   * rayPotential is the reference's arithmetic; "far in front" and "far behind" are EXEC-masked adds of
+//     constants (a wave pays only for the classes it contains), the near-surface value is one per-lane
+//     value (rho with diff's sign, or the slope term) added under one mask.
 // Results are bit-identical to the general kernel and to oracle/tsdf_oracle.c (tests/test_gpu_parity.py).
 #include <stdlib.h>
 
@@ -581,9 +582,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             if (__builtin_amdgcn_inverse_ballot_w64(m_in))
               dg[q] = DL::load(rsrc, __umul24((unsigned)py, vW) + (unsigned)px);  // cu:201
           }
-          // keep the voxels' instruction streams apart: interleaving them buys nothing (other waves fill the
-          // gaps) and costs the registers that decide the occupancy
-          __builtin_amdgcn_sched_barrier(0);
+          // (a scheduling barrier here, keeping the voxels' instruction streams apart, was worth keeping until the
+          // workgroups became persistent; without it the kernel is 0.4 % faster now, profiles/r03_exp_v_x.json)
         }
         // ---- phase B: ray potential of the group (cu:105-120) as EXEC-masked adds.  The scalar unit is what this kernel
         // runs out of, so a class that may be absent is still added (under an empty mask) rather than tested for.
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             // + 0 (cu:115) matters only where a sum can be -0.0: never, when the grid started at +0.0 (behind_mask set)
             if (!SURFACE && keep_zero_adds) acc_add_zero<BASE, TK>(kk, m_hit & m_behind_far);
             const mask_t m_near = m_hit & ~(m_front_far | m_behind_far);
-            if (SURFACE) {
+            {
               // one add of a per-lane value instead of three masked adds of the class values: rho * sign(diff) on the
               // plateau (cu:117: |diff| > thick >= 0 there, so diff != 0 and its sign bit is the sign), else cu:119
               if (m_near) {
@@ -611,13 +611,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                 const double near = __builtin_fabs(diff) > thick ? __hiloint2double(rh, __double2loint(rho_pos)) : slope * diff;
                 acc_add_v<BASE, TK>(kk, m_near, near);
               }
-            } else if (m_near) {
-              const mask_t m_plat = m_near & ballot(__builtin_fabs(diff) > thick);  // cu:116
-              const mask_t m_pos = ballot(diff > 0);                                 // the sign of cu:112
-              acc_add_s<BASE, TK>(kk, m_plat & m_pos, rho_pos);                       // rho * +1 (cu:117)
-              acc_sub_s<BASE, TK>(kk, m_plat & ~m_pos, rho_pos);                      // rho * -1
-              // the rest, a NaN diff included, is the reference's else branch: (rho/thick)*diff (cu:119)
-              acc_add_v<BASE, TK>(kk, m_near & ~m_plat, slope * diff);
             }
             if (COUNT) {
               nh[kk] += __builtin_amdgcn_inverse_ballot_w64(m_hit) ? 1u : 0u;
