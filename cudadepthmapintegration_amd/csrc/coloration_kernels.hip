@@ -8,12 +8,14 @@
 //
 // Here: one lane per vertex, colour planes and camera records resident in HBM (dmi_color_context).  The planes are
 // repacked at upload to RGBA dwords, top image row first, so a vertex-view pair costs one dword gather.  Kernel 1
-// loops over the views (camera records through scalar loads), projects with the reference's expression in fp64
-// (correctly rounded divisions: the pixel decides which colour is read), accumulates count and integer sums and
-// writes the fetched colour of every (view, vertex) pair to a scratch table [view][vertex] (uchar4, alpha = valid).
-// Kernel 2 finds the medians by a bit-by-bit radix selection over that table: 8 coalesced passes, each serving the
-// three channels and both middle elements at once.  Vertices are processed in chunks that bound the scratch table.
-// Everything after the projection is integer arithmetic, so the three outputs are bit-identical to the reference's.
+// loops over the views (camera records through scalar loads), projects with the reference's expression in fp64 -- the
+// two divisions replaced by a checked reciprocal where that provably selects the same pixel (FastQuotient) --
+// accumulates count and integer sums, writes the fetched colour of every (view, vertex) pair to a scratch table
+// [view][vertex] (uchar4, alpha = valid) and, per lane in LDS, 16-bin histograms of the upper nibbles, from which it
+// leaves the upper nibble of each median and the rank inside that bin.  Kernel 2 reads the table once and finds the
+// lower nibbles the same way (more than 65 535 views: a bit-by-bit radix selection, eight reads).  Vertices are
+// processed in chunks that bound the scratch table.  Everything after the pixel selection is integer arithmetic, so the
+// three outputs are bit-identical to the reference's.
 #include "../../include/dmi.h"
 #include "fusion_kernels.h"
 
@@ -45,6 +47,33 @@ __device__ __forceinline__ bool to_pixel(double u, int &p) {  // round half away
   p = (int)r;
   return true;
 }
+
+// std::round(num / den) as an int (RD.cxx:177-181) without the correctly rounded division, when that provably changes
+// nothing: r = 1/den from the hardware seed and two Newton steps, its residual 1 - den*r CHECKED to be below 2^-40, so
+// ua = num*r is within |Q| * 2^-39 of the real quotient Q and within 2^-21 of the reference's q = fl(num/den) as long as
+// |ua| < 2^16; if ua is further than 2^-20 from every half-integer, q lies on the same side of the same half-integers
+// and rounds -- half away from zero or not, no tie is near -- to the integer nearest to ua.  Everything else (a pixel
+// coordinate beyond 65 536, a near-tie, a zero / tiny / NaN denominator) takes the division.  Two quotients share r.
+struct FastQuotient {
+  double r;
+  bool usable;
+  __device__ __forceinline__ explicit FastQuotient(double den) {
+    double x = __builtin_amdgcn_rcp(den);
+    x = __builtin_fma(__builtin_fma(-den, x, 1.0), x, x);
+    x = __builtin_fma(__builtin_fma(-den, x, 1.0), x, x);
+    r = x;
+    usable = __builtin_fabs(__builtin_fma(-den, x, 1.0)) < 0x1p-40;  // NaN: false
+  }
+  __device__ __forceinline__ bool round_to_pixel(double num, double den, int &p) const {
+    const double ua = num * r;
+    const double fl = __builtin_floor(ua), fr = ua - fl;  // fr in [0, 1), exact
+    if (usable && __builtin_fabs(ua) < 65536.0 && __builtin_fabs(fr - 0.5) > 0x1p-20) {
+      p = (int)fl + (fr > 0.5 ? 1 : 0);
+      return true;
+    }
+    return to_pixel(num / den, p);
+  }
+};
 
 // [n][H][W][3] in vtk point order (row 0 = bottom, RD.cxx:106-108) -> [n][H][W] RGBA, top row first
 __global__ __launch_bounds__(256) void pack_color_kernel(const uint8_t *__restrict__ rgb, uchar4 *__restrict__ rgba, int W,
@@ -123,16 +152,37 @@ __global__ __launch_bounds__(256) void morton_key_kernel(const double *__restric
   index[id] = (uint32_t)id;
 }
 
+constexpr int kHistWords = 8;   // 16 bins of 16 bits, two to a 32-bit word
+
+// What the median pass needs from the projection pass when the medians are found by nibble histograms: for each channel
+// and each of the two middle ranks, the upper nibble of the median (4 bits each in .x) and the rank that remains inside
+// that nibble's bin (16 bits each in .y .z .w).
+struct MedianSeed {
+  uint32_t hi, rest01, rest23, rest45;
+};
+
+// HIST: also fill, per lane, 16-bin histograms of the upper nibbles of the three channels in LDS (every lane owns a
+// column of counters: no barrier, no conflict) and leave the MedianSeed of the vertex: the first of the two passes of
+// the histogram medians costs no read of the scratch table.
+template <bool HIST>
 __global__ __launch_bounds__(256) void project_color_kernel(const double *__restrict__ points, int64_t nv,
                                                             const uint32_t *__restrict__ perm,
                                                             const ColorView *__restrict__ views, int n, int W, int H,
                                                             uchar4 *__restrict__ scratch, uint8_t *__restrict__ mean,
-                                                            int32_t *__restrict__ count) {
+                                                            int32_t *__restrict__ count, MedianSeed *__restrict__ seeds) {
+  __shared__ uint32_t hist[HIST ? 3 * kHistWords * 256 : 1];  // [channel][word][lane]: 24 KB
+  const int lane = threadIdx.x;
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // position along the Z-order curve
   if (id >= nv) return;
   const int64_t vtx = perm ? (int64_t)perm[id] : id;                  // the vertex this lane colours
   const double x = points[3 * vtx], y = points[3 * vtx + 1], z = points[3 * vtx + 2];
   int cnt = 0, s0 = 0, s1 = 0, s2 = 0;
+  auto bump = [&](int table, int b) {
+    __hip_atomic_fetch_add(&hist[(table * kHistWords + (b & 7)) * 256 + lane], 1u << (16 * (b >> 3)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if constexpr (HIST)
+    for (int q = 0; q < 3 * kHistWords; ++q) hist[q * 256 + lane] = 0;
   for (int m = 0; m < n; ++m) {
     const ColorView *v = views + m;  // wave-uniform
     // vtkTransform::TransformPoint with MatrixTR (RD.cxx:173): M[i][0]*x + M[i][1]*y + M[i][2]*z + M[i][3], left to right
@@ -145,14 +195,20 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
     const double dz = (cload(&v->k[6]) * cx + cload(&v->k[7]) * cy) + cload(&v->k[8]) * cz;
     uchar4 out = make_uchar4(0, 0, 0, 0);
     int px, py;
-    if (to_pixel(dx / dz, px) && to_pixel(dy / dz, py) &&           // RD.cxx:177-181
-        px >= 0 && py >= 0 && px < W && py < H) {                   // MC.cxx:158-163
+    const FastQuotient by_dz(dz);
+    if (by_dz.round_to_pixel(dx, dz, px) && by_dz.round_to_pixel(dy, dz, py) &&   // RD.cxx:177-181
+        px >= 0 && py >= 0 && px < W && py < H) {                                 // MC.cxx:158-163
       const uchar4 c = cload(&v->color)[(int64_t)py * W + px];      // RD.cxx:106-108 (row flip done at upload)
       out = make_uchar4(c.x, c.y, c.z, 1);
       cnt += 1;
       s0 += c.x;  // std::accumulate(..., 0): integer running sums (MC.cxx:176-178)
       s1 += c.y;
       s2 += c.z;
+      if constexpr (HIST) {
+        bump(0, c.x >> 4);
+        bump(1, c.y >> 4);
+        bump(2, c.z >> 4);
+      }
     }
     scratch[(int64_t)m * nv + id] = out;
   }
@@ -161,6 +217,25 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
   mean[3 * vtx + 0] = cnt ? (uint8_t)(s0 / cnt) : 0;
   mean[3 * vtx + 1] = cnt ? (uint8_t)(s1 / cnt) : 0;
   mean[3 * vtx + 2] = cnt ? (uint8_t)(s2 / cnt) : 0;
+  if constexpr (HIST) {
+    // rank (0-based) of the upper and of the lower middle element (Helper.h:174-187; the same element for an odd count)
+    const int want[2] = {cnt / 2, (cnt & 1) == 0 ? cnt / 2 - 1 : cnt / 2};
+    uint32_t hi = 0, rest[6] = {0, 0, 0, 0, 0, 0};
+    if (cnt > 0) {
+      for (int c = 0; c < 3; ++c)
+        for (int t = 0; t < 2; ++t) {
+          int k = want[t], b = 0;
+          for (; b < 15; ++b) {
+            const int here = (int)((hist[(c * kHistWords + (b & 7)) * 256 + lane] >> (16 * (b >> 3))) & 0xffffu);
+            if (k < here) break;
+            k -= here;
+          }
+          hi |= (uint32_t)b << (4 * (2 * c + t));
+          rest[2 * c + t] = (uint32_t)k;
+        }
+    }
+    seeds[id] = MedianSeed{hi, rest[0] | (rest[1] << 16), rest[2] | (rest[3] << 16), rest[4] | (rest[5] << 16)};
+  }
 }
 
 // Medians of the valid entries of the three channels (Helper.h:174-187: sorted[cnt/2], or the mean of sorted[cnt/2]
@@ -209,53 +284,29 @@ __global__ __launch_bounds__(256) void median_kernel(const uchar4 *__restrict__ 
   for (int c = 0; c < 3; ++c) median[3 * vtx + c] = cnt > 0 ? (uint8_t)((prefix[c][0] + prefix[c][1]) >> 1) : 0;
 }
 
-// The same medians with two passes over the scratch column instead of eight: per lane, 16-bin histograms of the upper
-// nibble of each channel (pass 1), then of the lower nibble among the entries whose upper nibble holds the wanted
-// rank (pass 2), kept in LDS -- every lane owns a column of counters, two 16-bit counters to a word (so at most
-// 65 535 views; more take the bit-by-bit kernel above).  The pass is bound by the reads of the scratch table
-// (n_views x 4 bytes per vertex per pass), so a quarter of the passes is what counts.
-constexpr int kHistWords = 8;   // 16 bins, two to a 32-bit word
-__global__ __launch_bounds__(256) void median_hist_kernel(const uchar4 *__restrict__ scratch, int64_t nv, int n,
-                                                          const uint32_t *__restrict__ perm, const int32_t *__restrict__ count,
-                                                          uint8_t *__restrict__ median) {
-  __shared__ uint32_t hist[6 * kHistWords * 256];  // [table][word][lane]: 48 KB
+// The same medians from nibble histograms: the projection pass has already found, per channel and middle rank, the
+// upper nibble of the median and the rank left inside that nibble's bin (MedianSeed); this pass reads the scratch column
+// ONCE and builds, per lane, 16-bin histograms of the lower nibbles of the entries whose upper nibble is the wanted one,
+// in LDS -- every lane owns a column of counters, two 16-bit counters to a word (so at most 65 535 views; more take the
+// bit-by-bit kernel above, eight reads of the column).
+__global__ __launch_bounds__(256) void median_low_nibble_kernel(const uchar4 *__restrict__ scratch, int64_t nv, int n,
+                                                                const uint32_t *__restrict__ perm, const int32_t *__restrict__ count,
+                                                                const MedianSeed *__restrict__ seeds, uint8_t *__restrict__ median) {
+  __shared__ uint32_t hist[6 * kHistWords * 256];  // [channel x rank][word][lane]: 48 KB
   const int lane = threadIdx.x;
   const int64_t id = (int64_t)blockIdx.x * 256 + lane;  // scratch column = position along the curve
-  const int64_t vtx = id < nv ? (perm ? (int64_t)perm[id] : id) : 0;
-  const int cnt = id < nv ? count[vtx] : 0;
-  // rank (0-based) of the upper and of the lower middle element (the same element for an odd count)
-  const int want[2] = {cnt / 2, (cnt & 1) == 0 ? cnt / 2 - 1 : cnt / 2};
-  int hi[3][2] = {{0, 0}, {0, 0}, {0, 0}}, rest[3][2] = {{0, 0}, {0, 0}, {0, 0}}, lo[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-  auto bin = [&](int table, int b) -> int {
-    return (int)((hist[(table * kHistWords + (b & 7)) * 256 + lane] >> (16 * (b >> 3))) & 0xffffu);
-  };
+  if (id >= nv) return;                                 // (no barrier below)
+  const int64_t vtx = perm ? (int64_t)perm[id] : id;
+  const int cnt = count[vtx];
+  const MedianSeed seed = seeds[id];
+  int hi[6], rest[6] = {(int)(seed.rest01 & 0xffffu), (int)(seed.rest01 >> 16), (int)(seed.rest23 & 0xffffu),
+                        (int)(seed.rest23 >> 16), (int)(seed.rest45 & 0xffffu), (int)(seed.rest45 >> 16)};
+  for (int q = 0; q < 6; ++q) hi[q] = (int)((seed.hi >> (4 * q)) & 15u);
+  int lo[6] = {0, 0, 0, 0, 0, 0};
   auto bump = [&](int table, int b) {
     __hip_atomic_fetch_add(&hist[(table * kHistWords + (b & 7)) * 256 + lane], 1u << (16 * (b >> 3)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  // only this lane touches its columns: no barrier anywhere
-  for (int q = 0; q < 3 * kHistWords; ++q) hist[q * 256 + lane] = 0;
-  if (cnt > 0) {
-    for (int m = 0; m < n; ++m) {
-      const uchar4 e = scratch[(int64_t)m * nv + id];
-      if (e.w != 0) {
-        bump(0, e.x >> 4);
-        bump(1, e.y >> 4);
-        bump(2, e.z >> 4);
-      }
-    }
-    for (int c = 0; c < 3; ++c)
-      for (int t = 0; t < 2; ++t) {
-        int k = want[t], b = 0;
-        for (; b < 15; ++b) {
-          const int here = bin(c, b);
-          if (k < here) break;
-          k -= here;
-        }
-        hi[c][t] = b;
-        rest[c][t] = k;
-      }
-  }
   for (int q = 0; q < 6 * kHistWords; ++q) hist[q * 256 + lane] = 0;
   if (cnt > 0) {
     for (int m = 0; m < n; ++m) {
@@ -265,27 +316,24 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const uchar4 *__restri
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int up = val[c] >> 4, low = val[c] & 15;
-          if (up == hi[c][0]) bump(2 * c, low);
-          if (up == hi[c][1]) bump(2 * c + 1, low);
+          if (up == hi[2 * c]) bump(2 * c, low);
+          if (up == hi[2 * c + 1]) bump(2 * c + 1, low);
         }
       }
     }
-    for (int c = 0; c < 3; ++c)
-      for (int t = 0; t < 2; ++t) {
-        int k = rest[c][t], b = 0;
-        for (; b < 15; ++b) {
-          const int here = bin(2 * c + t, b);
-          if (k < here) break;
-          k -= here;
-        }
-        lo[c][t] = b;
+    for (int q = 0; q < 6; ++q) {
+      int k = rest[q], b = 0;
+      for (; b < 15; ++b) {
+        const int here = (int)((hist[(q * kHistWords + (b & 7)) * 256 + lane] >> (16 * (b >> 3))) & 0xffffu);
+        if (k < here) break;
+        k -= here;
       }
+      lo[q] = b;
+    }
   }
-  if (id < nv) {
-    // (a + b) / 2 in double, then static_cast<unsigned char> (MC.cxx:185): the integer (a + b) >> 1; a == b for odd counts
-    for (int c = 0; c < 3; ++c)
-      median[3 * vtx + c] = cnt > 0 ? (uint8_t)((((hi[c][0] << 4) | lo[c][0]) + ((hi[c][1] << 4) | lo[c][1])) >> 1) : 0;
-  }
+  // (a + b) / 2 in double, then static_cast<unsigned char> (MC.cxx:185): the integer (a + b) >> 1; a == b for odd counts
+  for (int c = 0; c < 3; ++c)
+    median[3 * vtx + c] = cnt > 0 ? (uint8_t)((((hi[2 * c] << 4) | lo[2 * c]) + ((hi[2 * c + 1] << 4) | lo[2 * c + 1])) >> 1) : 0;
 }
 
 thread_local std::string g_color_error;
@@ -311,6 +359,7 @@ struct dmi_color_context {
   uchar4 *d_scratch = nullptr;
   uint8_t *d_mean = nullptr, *d_median = nullptr;
   int32_t *d_count = nullptr;
+  MedianSeed *d_seeds = nullptr;  // per vertex of a chunk: what the projection pass hands the histogram-median pass
   // processing order of a chunk: Z-order keys and vertex indices (in / out of the radix sort), its temporary storage,
   // the chunk's bounding box
   uint32_t *d_keys = nullptr, *d_keys_sorted = nullptr, *d_index = nullptr, *d_perm = nullptr;
@@ -405,7 +454,7 @@ void dmi_color_destroy(dmi_color_context *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (ColorBatch &b : c->batches) (void)hipFree(b.d_rgba);
   for (void *p : {(void *)c->d_views, (void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median,
-                  (void *)c->d_count, (void *)c->d_stage, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index,
+                  (void *)c->d_count, (void *)c->d_seeds, (void *)c->d_stage, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index,
                   (void *)c->d_perm, c->d_sort_temp, (void *)c->d_box})
     if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -519,9 +568,10 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
   chunk = std::min<size_t>(chunk, ((size_t)n_points + 255) / 256 * 256);
   if (c->chunk_capacity < chunk || c->scratch_capacity < chunk * n_views) {
     for (void *p : {(void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median, (void *)c->d_count,
-                    (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index, (void *)c->d_perm, c->d_sort_temp})
+                    (void *)c->d_seeds, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index, (void *)c->d_perm, c->d_sort_temp})
       if (p) (void)hipFree(p);
     c->d_points = nullptr; c->d_scratch = nullptr; c->d_mean = nullptr; c->d_median = nullptr; c->d_count = nullptr;
+    c->d_seeds = nullptr;
     c->d_keys = c->d_keys_sorted = c->d_index = c->d_perm = nullptr;
     c->d_sort_temp = nullptr;
     c->sort_temp_bytes = 0;
@@ -531,6 +581,7 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     DMI_COLOR_HIP(c, hipMalloc(&c->d_mean, chunk * 3));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_median, chunk * 3));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_count, chunk * 4));
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_seeds, chunk * sizeof(MedianSeed)));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_keys, chunk * 4));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_keys_sorted, chunk * 4));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_index, chunk * 4));
@@ -561,19 +612,23 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
                                                 0, 30, c->stream));
       perm = c->d_perm;
     }
-    hipLaunchKernelGGL(project_color_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                       (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count);
-    DMI_COLOR_HIP(c, hipGetLastError());
     bool histogram_medians = n_views <= 65535;
 #ifdef DMI_TUNING
     if (getenv("DMI_COLOR_BITWISE_MEDIAN")) histogram_medians = false;  // A/B of the two median kernels
 #endif
-    if (histogram_medians)
-      hipLaunchKernelGGL(median_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
-                         c->d_count, c->d_median);
-    else
+    if (histogram_medians) {
+      hipLaunchKernelGGL(project_color_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
+                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds);
+      DMI_COLOR_HIP(c, hipGetLastError());
+      hipLaunchKernelGGL(median_low_nibble_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
+                         c->d_count, c->d_seeds, c->d_median);
+    } else {
+      hipLaunchKernelGGL(project_color_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
+                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds);
+      DMI_COLOR_HIP(c, hipGetLastError());
       hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
                          c->d_count, c->d_median);
+    }
     DMI_COLOR_HIP(c, hipGetLastError());
     DMI_COLOR_HIP(c, hipEventRecord(c->ev1, c->stream));
     DMI_COLOR_HIP(c, hipMemcpyAsync(mean + 3 * v0, c->d_mean, (size_t)nv * 3, hipMemcpyDeviceToHost, c->stream));
