@@ -1061,6 +1061,11 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     t.cz_table = ctx->d_cz_table;
     if (!ctx->d_queue_heads) DMI_HIP(ctx, hipMalloc(&ctx->d_queue_heads, 128 * sizeof(int32_t)));
     t.queue_heads = ctx->d_queue_heads;
+    // A slab fuse is one step of a pipeline on several streams (dmi_multi_fuse: the exchange of the slab before runs
+    // meanwhile, and its kernels can only start where wave slots come free: at the boundary between two slab launches,
+    // where both queues are ready, when the workgroups are persistent).  VAR_SLAB_TURNS makes the workgroups of a slab
+    // fuse take turns, four bricks each -- 6 % slower on one GPU with sixteen; for whoever tunes the overlap on a node.
+    t.bricks_per_workgroup = (!whole_grid && (cfg.variant & dmi::VAR_SLAB_TURNS)) ? 4 : 0;
     // valid while every sum of the launch starts at +0.0 and hits are not counted (counted views are taken one by one)
     if (!a.init_from_grid && !ctx->opt.count_hits && count <= dmi::kFreeSumsMax) t.free_sums = ctx->d_cz_table + table_doubles;
     // brick classes: one byte per (8 x 8 x column wave brick, resident view)

@@ -150,6 +150,10 @@ struct TileArgs {
   int64_t wg_times_n;
   // brick counters of the persistent workgroups, one per XCD at [16 * xcd]; zeroed by the table kernel of every launch
   int32_t *queue_heads;
+  // 0: a persistent workgroup stays until every share is used up.  n > 0: it leaves after n bricks and the launch has
+  // correspondingly more workgroups -- wave slots then come free every few hundred microseconds, which is what lets the
+  // kernels of ANOTHER stream (the slab exchange of a multi-GPU fusion, RCCL) start while a slab is being fused
+  int32_t bricks_per_workgroup, pad4;
 };
 constexpr int kFreeSumsMax = 4096;
 // an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)
@@ -203,7 +207,8 @@ enum VariantBits : int {
   VAR_KEEP_BEHIND_ADDS = 1024,  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
   VAR_NO_INTERIOR = 2048,       // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
   VAR_XCD_RUNS = 8192,          // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
-  VAR_ZMAJOR_SLOTS = 16384      // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
+  VAR_ZMAJOR_SLOTS = 16384,     // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
+  VAR_SLAB_TURNS = 65536        // tiled kernel, slab fuses: workgroups leave after four bricks (TileArgs::bricks_per_workgroup)
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.
