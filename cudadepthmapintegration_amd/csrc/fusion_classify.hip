@@ -153,6 +153,11 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   fp.x0 = fp.x1 = fp.y0 = fp.y1 = 0;
   double czmin = __builtin_inf(), czmax = -__builtin_inf();
   double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
+  // General K (third row not 0 0 1 0, cu:176): the divisor of cu:183-184 and the subject of cu:177 is h.z, an affine
+  // function of the world position like h.x and h.y (TileMapRec::sx..s0), known to within errz; for a pinhole K it is c.z
+  // itself and everything below reads as it always did.
+  const bool genk = tr->errz != 0.0;
+  double hzmin = __builtin_inf(), hzmax = -__builtin_inf();
   bool bad = false;
   const double r23 = mr->rt[11];
   if constexpr (ROT) {
@@ -169,10 +174,13 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
       const double cz = row4(mr->rt + 8, wx, wy, wz);
       const double hx = __builtin_fma(tr->px, wx, __builtin_fma(tr->py, wy, __builtin_fma(tr->pz, wz, tr->p0)));
       const double hy = __builtin_fma(tr->qx, wx, __builtin_fma(tr->qy, wy, __builtin_fma(tr->qz, wz, tr->q0)));
-      double r = __builtin_amdgcn_rcp(cz);
-      r = __builtin_fma(r, __builtin_fma(-cz, r, 1.0), r);
+      const double hz = genk ? __builtin_fma(tr->sx, wx, __builtin_fma(tr->sy, wy, __builtin_fma(tr->sz, wz, tr->s0))) : cz;
+      double r = __builtin_amdgcn_rcp(hz);
+      r = __builtin_fma(r, __builtin_fma(-hz, r, 1.0), r);
       const double u = hx * r, v = hy * r;
-      bad = bad || !(cz == cz);
+      bad = bad || !(cz == cz) || !(hz == hz);
+      hzmin = fmin(hzmin, hz);
+      hzmax = fmax(hzmax, hz);
       czmin = fmin(czmin, cz);
       czmax = fmax(czmax, cz);
       umin = fmin(umin, u);
@@ -206,19 +214,27 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   const double vx[2] = {tr->qx * wxs[0], tr->qx * wxs[1]};
   const double vy[2] = {__builtin_fma(tr->qy, wys[0], tr->q0), __builtin_fma(tr->qy, wys[1], tr->q0)};
   const double vz[2] = {tr->qz * wzs[0], tr->qz * wzs[1]};
+  double sxw[2] = {0.0, 0.0}, syw[2] = {0.0, 0.0}, szw[2] = {0.0, 0.0};
+  if (genk) {
+    sxw[0] = tr->sx * wxs[0], sxw[1] = tr->sx * wxs[1];
+    syw[0] = __builtin_fma(tr->sy, wys[0], tr->s0), syw[1] = __builtin_fma(tr->sy, wys[1], tr->s0);
+    szw[0] = tr->sz * wzs[0], szw[1] = tr->sz * wzs[1];
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int cx = c & 1, cy = (c >> 1) & 1, ck = c >> 2;
     const double cz = ((zx[cx] + zy[cy]) + zz[ck]) + r23;
     const double hx = (ux[cx] + uy[cy]) + uz[ck];
     const double hy = (vx[cx] + vy[cy]) + vz[ck];
-    // h.z == c.z (pinhole K is a precondition of the tiled kernel).  The footprint only needs u, v to a small
-    // fraction of the one-pixel dilation: a Newton-refined reciprocal (relative error < 2^-40) instead of two
-    // fp64 divisions.
-    double r = __builtin_amdgcn_rcp(cz);
-    r = __builtin_fma(r, __builtin_fma(-cz, r, 1.0), r);
+    // h.z == c.z for a pinhole K.  The footprint only needs u, v to a small fraction of the one-pixel dilation: a
+    // Newton-refined reciprocal (relative error < 2^-40) instead of two fp64 divisions.
+    const double hz = genk ? (sxw[cx] + syw[cy]) + szw[ck] : cz;
+    double r = __builtin_amdgcn_rcp(hz);
+    r = __builtin_fma(r, __builtin_fma(-hz, r, 1.0), r);
     const double u = hx * r, v = hy * r;
-    bad = bad || !(cz == cz);
+    bad = bad || !(cz == cz) || !(hz == hz);
+    hzmin = fmin(hzmin, hz);
+    hzmax = fmax(hzmax, hz);
     czmin = fmin(czmin, cz);
     czmax = fmax(czmax, cz);
     umin = fmin(umin, u);
@@ -230,19 +246,26 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   // an unproven pair carries, above the two class bits, WHY it is unproven (MixedReason << 2): a diagnostic the
   // fusion kernel never looks at (it reads the class as byte & 3)
   uint8_t cls = BRICK_MIXED | (MIXED_DEGENERATE << 2);
-  const double err = tr->err;
+  // Pinhole: the divisor is c.z, exact at the corners, and |h.x_ref - h.x| <= err.  General K: every voxel's reference h.z
+  // lies within errz of the affine value, whose extremes are at corners: behind the camera for sure
+  // (cu:177) below -errz, and with |u|, |v| < 2^16 the reference's u differs from the real projective value by at most
+  // (err + 2^16 errz) / (h.z - errz).  2 errz instead of errz leaves room for the corner evaluation's own rounding.
+  const double errz2 = 2.0 * tr->errz;
+  const double err = genk ? tr->err + 65536.0 * tr->errz : tr->err;
+  const double dmin = genk ? hzmin - errz2 : czmin, dmax = genk ? hzmax + errz2 : czmax;
+  const double ulimit = genk ? 65536.0 : 0x1p30;
   if (!bad) {
     cls = BRICK_MIXED | (MIXED_CAMERA_PLANE << 2);
-    if (czmax < 0.0) {
+    if (dmax < 0.0) {
       cls = BRICK_SKIP;  // every voxel is behind the camera (cu:177)
-    } else if (czmin > 4.0 * err && czmin > 0.0 && umin == umin && umax == umax && vmin == vmin && vmax == vmax &&
-               fabs(umin) < 0x1p30 && fabs(umax) < 0x1p30 && fabs(vmin) < 0x1p30 && fabs(vmax) < 0x1p30) {
+    } else if (dmin > 4.0 * err && dmin > 0.0 && umin == umin && umax == umax && vmin == vmin && vmax == vmax &&
+               fabs(umin) < ulimit && fabs(umax) < ulimit && fabs(vmin) < ulimit && fabs(vmax) < ulimit) {
       // Every voxel's rounded pixel lies in [x0, x1] x [y0, y1]: its real u lies between the real corner values
       // (projective, monotone along the axes), the corner values above are within err/c.z + 2^-21 of the real ones, the
       // reference's computed u within err/c.z + 2^-21 of the real one, and rounding moves it by at most
       // 1/2: an integer px with umin - 1/2 - e <= px <= umax + 1/2 + e, e = 2*err/czmin + 2^-20 (< 0.51).
-      double rmin = __builtin_amdgcn_rcp(czmin);
-      rmin = __builtin_fma(rmin, __builtin_fma(-czmin, rmin, 1.0), rmin);
+      double rmin = __builtin_amdgcn_rcp(dmin);
+      rmin = __builtin_fma(rmin, __builtin_fma(-dmin, rmin, 1.0), rmin);
       const double e = 2.0 * err * rmin * (1.0 + 0x1p-30) + 0x1p-20;
       const int x0 = (int)ceil(umin - 0.5 - e), x1 = (int)floor(umax + 0.5 + e);
       const int y0 = (int)ceil(vmin - 0.5 - e), y1 = (int)floor(vmax + 0.5 + e);
@@ -278,9 +301,6 @@ template <int kQueryTiles, bool ROT>
 __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
                                                 const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
                                                 int j0, int j1, int k0, int k1) {
-  // a K whose third row is not 0 0 1 0 (h.z != c.z, cu:176): nothing is proven for such a view, every pair takes the
-  // per-voxel path of the fusion kernel's GENK instantiation
-  if (tr->errz != 0.0) return BRICK_MIXED;
   const BoxFootprint fp = box_footprint<ROT>(a, mr, tr, i0, i1, j0, j1, k0, k1);
   if (!fp.query) return fp.cls;
   return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
@@ -388,19 +408,13 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
       tr_u.err = cload(&tsrc->err);
       tr_u.cz_err = cload(&tsrc->cz_err);
       tr_u.errz = cload(&tsrc->errz);
+      tr_u.sx = cload(&tsrc->sx); tr_u.sy = cload(&tsrc->sy); tr_u.sz = cload(&tsrc->sz); tr_u.s0 = cload(&tsrc->s0);
       mr = &mr_u;
-      if (tr_u.errz != 0.0) {  // general K: unproven, see classify_box
-        fp.cls = BRICK_MIXED;
-      } else if (mine) {
+      if (mine) {
         fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
       }
     } else {
-      if (mine) {
-        if (a.tile_maps[m].errz != 0.0)
-          fp.cls = BRICK_MIXED;
-        else
-          fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
-      }
+      if (mine) fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
     }
     const bool query = mine && fp.query;
     uint8_t cls = fp.cls;
