@@ -18,9 +18,9 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libdmi_hip.so")
 
-SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "dmi_multi.hip", "host/recon_host.cpp", "host/vti_reader.cpp", "host/dmi_host_capi.cpp"]
+SOURCES = ["fusion_kernels.hip", "fusion_tile.hip", "fusion_classify.hip", "coloration_kernels.hip", "grid_post.hip", "dmi_capi.hip", "dmi_multi.hip", "host/recon_host.cpp", "host/vti_reader.cpp", "host/recon_cli.cpp", "host/dmi_host_capi.cpp"]
 HEADERS = ["fusion_kernels.h", "fusion_device.h", "fusion_tile_acc.inc", os.path.join("host", "recon_host.h"),
-           os.path.join("host", "vti_reader.h"),
+           os.path.join("host", "vti_reader.h"), os.path.join("host", "recon_cli.h"),
            os.path.join("..", "..", "include", "dmi.h"), os.path.join("..", "..", "include", "dmi_host.h")]
 
 # -ffp-contract=off: no FMA contraction anywhere on the result path (parity contract).
@@ -204,4 +204,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB_PATH
+
+
+CLI_PATH = os.path.join(CSRC, "dmi_reconstruction")
+
+
+def build_cli(verbose: bool = False) -> str:
+    """The reference's `Reconstruction` command line over the library (csrc/host/recon_cli_main.cpp): a few lines of
+    main() linked against the .so next to it (rpath $ORIGIN).  Only for the default library."""
+    if os.path.basename(LIB_PATH) != "libdmi_hip.so":
+        return ""
+    src = os.path.join(CSRC, "host", "recon_cli_main.cpp")
+    if not _stale(CLI_PATH, [src, LIB_PATH]):
+        return CLI_PATH
+    cmd = [hipcc_path()] + COMMON_FLAGS + [src, "-L" + CSRC, "-ldmi_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI_PATH]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return CLI_PATH

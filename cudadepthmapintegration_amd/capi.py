@@ -710,6 +710,7 @@ HOST_ABI_SYMBOLS = [
     "dmi_filter_get_fuse_kernel_ms", "dmi_filter_get_number_of_cells", "dmi_filter_get_output",
     "dmi_filter_last_error", "dmi_read_krtd_file", "dmi_extract_all_file_path", "dmi_k3_to_k4",
     "dmi_apply_depth_threshold", "dmi_read_depth_map", "dmi_read_depth_map_color", "dmi_mesh_coloration_from_lists",
+    "dmi_cli_read_arguments", "dmi_cli_main",
 ]
 
 _host_bound = False
@@ -855,6 +856,34 @@ class ReconstructionFilter:
             return out[:got]
         px, py, pz = self._point_dims
         return out.reshape(pz - 1, py - 1, px - 1)
+
+
+class CliOptionsC(ctypes.Structure):
+    _fields_ = [("grid_dims", ctypes.c_int32 * 3), ("grid_spacing", ctypes.c_double * 3), ("grid_origin", ctypes.c_double * 3),
+                ("grid_end", ctypes.c_double * 3), ("grid_matrix", ctypes.c_double * 16), ("ray_thick", ctypes.c_double),
+                ("ray_rho", ctypes.c_double), ("ray_eta", ctypes.c_double), ("ray_delta", ctypes.c_double),
+                ("thresh_best_cost", ctypes.c_double), ("contour", ctypes.c_double), ("verbose", ctypes.c_int32),
+                ("summary", ctypes.c_int32), ("force_cubic_voxel", ctypes.c_int32)]
+
+
+def cli_read_arguments(args):
+    """ReadArguments of the `Reconstruction` tool (Reconstruction/main.cxx:216-343) on ["prog", "--flag", ...]:
+    (options or None, the text the tool would print)."""
+    L = load_host()
+    L.dmi_cli_read_arguments.restype = ctypes.c_int
+    L.dmi_cli_read_arguments.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(CliOptionsC),
+                                         ctypes.c_char_p, ctypes.c_size_t]
+    argv = (ctypes.c_char_p * len(args))(*[os.fsencode(a) for a in args])
+    out = CliOptionsC()
+    err = ctypes.create_string_buffer(1 << 15)
+    ok = L.dmi_cli_read_arguments(len(args), argv, ctypes.byref(out), err, len(err))
+    return (out if ok else None), err.value.decode()
+
+
+def cli_binary() -> str:
+    """Path of the dmi_reconstruction executable built next to the library."""
+    from . import build as _build
+    return _build.CLI_PATH
 
 
 def read_krtd_file(path):

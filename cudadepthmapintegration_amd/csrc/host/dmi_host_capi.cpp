@@ -3,10 +3,13 @@
 
 #include <cstring>
 #include <memory>
+#include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
 #include "recon_host.h"
+#include "recon_cli.h"
 
 using dmi::host::DepthImage;
 using dmi::host::ReconstructionData;
@@ -197,6 +200,43 @@ int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const
   std::memcpy(median, mc.GetMedianColoration().data(), (size_t)n_points * 3);
   for (int64_t i = 0; i < n_points; ++i) count[i] = mc.GetNbProjectedDepthMap()[(size_t)i];
   return 1;
+  });
+}
+
+int dmi_cli_read_arguments(int32_t argc, const char *const *argv, dmi_cli_options *out, char *err, size_t errlen) {
+  return guarded<int>(0, [&]() -> int {
+  if (!argv || !out || argc < 0) return 0;
+  dmi::host::cli::Options o;
+  std::ostringstream text;
+  const bool ok = dmi::host::cli::ReadArguments(argc, argv, &o, text);
+  if (err && errlen > 0) {
+    std::strncpy(err, text.str().c_str(), errlen - 1);
+    err[errlen - 1] = 0;
+  }
+  if (!ok) return 0;
+  std::memset(out, 0, sizeof(*out));
+  for (int a = 0; a < 3; ++a) {
+    out->grid_dims[a] = o.gridDims[(size_t)a];
+    out->grid_spacing[a] = o.gridSpacing[(size_t)a];
+    out->grid_origin[a] = o.gridOrigin[(size_t)a];
+    out->grid_end[a] = o.gridEnd[(size_t)a];
+  }
+  dmi::host::cli::CreateGridMatrixFromInput(o, out->grid_matrix);
+  out->ray_thick = o.rayThick; out->ray_rho = o.rayRho; out->ray_eta = o.rayEta; out->ray_delta = o.rayDelta;
+  out->thresh_best_cost = o.threshBestCost; out->contour = o.contour;
+  out->verbose = o.verbose; out->summary = o.summary; out->force_cubic_voxel = o.forceCubicVoxel;
+  return 1;
+  });
+}
+
+int dmi_cli_main(int32_t argc, const char *const *argv) {
+  return guarded<int>(1, [&]() -> int {
+  dmi::host::cli::Options o;
+  if (!dmi::host::cli::ReadArguments(argc, argv, &o, std::cerr)) return 1;  // EXIT_FAILURE, rmain:100-103
+  dmi::host::cli::RunResult result;
+  const int rc = dmi::host::cli::Run(o, argc, argv, std::cout, &result);
+  if (rc != 0) std::cerr << "dmi_reconstruction: " << result.error << std::endl;
+  return rc;
   });
 }
 

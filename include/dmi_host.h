@@ -84,6 +84,21 @@ int dmi_read_depth_map_color(const char *path, int32_t dims[3], uint8_t *color, 
 int dmi_mesh_coloration_from_lists(const double *points, int64_t n_points, const char *vti_list, const char *krtd_list,
                                    int32_t device, uint8_t *mean, uint8_t *median, int32_t *count, char *err, size_t errlen);
 
+/* ---- the `Reconstruction` command line (Reconstruction/main.cxx; csrc/host/recon_cli.h) ----
+ * What ReadArguments (rmain:216-343) makes of a command line: flags, defaults, validation and the derived grid. */
+typedef struct dmi_cli_options {
+  int32_t grid_dims[3];       /* POINT dimensions handed to the filter (rmain:118) */
+  double grid_spacing[3], grid_origin[3], grid_end[3];
+  double grid_matrix[16];     /* CreateGridMatrixFromInput (rmain:345-360), row-major */
+  double ray_thick, ray_rho, ray_eta, ray_delta, thresh_best_cost, contour;
+  int32_t verbose, summary, force_cubic_voxel;
+} dmi_cli_options;
+/* 1: the run may proceed, *out filled.  0: an error or --help; the text (what the tool would print) in err. */
+int dmi_cli_read_arguments(int32_t argc, const char *const *argv, dmi_cli_options *out, char *err, size_t errlen);
+/* The whole tool: ReadArguments, the filter, cell -> point data, meta_image_volume.mha (in the working directory, as the
+ * reference), the .vts volume, the summary file.  Process exit code: 0 on success.  No iso-surface (rmain:166-187). */
+int dmi_cli_main(int32_t argc, const char *const *argv);
+
 #ifdef __cplusplus
 }
 #endif
