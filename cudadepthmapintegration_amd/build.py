@@ -174,6 +174,8 @@ def run_accumulator_audit(verbose: bool = False) -> int:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
+        if not LIB_OVERRIDE:
+            build_cli(verbose)
         return LIB_PATH
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
