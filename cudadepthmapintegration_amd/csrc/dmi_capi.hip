@@ -1040,7 +1040,8 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // r22*wz(k) table, one row of kpad doubles per resident view
     t.rotated = grid_axis_aligned(ctx->grid) ? 0 : 1;
     t.flags = ((cfg.variant & dmi::VAR_NO_INTERIOR) ? dmi::TILE_FLAG_NO_INTERIOR : 0) |
-              ((cfg.variant & dmi::VAR_XCD_RUNS) ? dmi::TILE_FLAG_XCD_RUNS : 0);
+              ((cfg.variant & dmi::VAR_XCD_RUNS) ? dmi::TILE_FLAG_XCD_RUNS : 0) |
+              ((cfg.variant & dmi::VAR_NO_HELP) ? dmi::TILE_FLAG_NO_HELP : 0);
     t.maps = ctx->d_maps;
     // rotated: [kpad][4]; behind the table, the sums of n free-space constants (TileArgs::free_sums)
     const size_t table_doubles = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;

@@ -160,7 +160,8 @@ constexpr int kFreeSumsMax = 4096;
 __host__ __device__ inline int32_t pack_brick(int bx, int by, int bz) { return (int32_t)((uint32_t)bx | ((uint32_t)by << 11) | ((uint32_t)bz << 22)); }
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
-  TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
+  TILE_FLAG_XCD_RUNS = 2,     // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
+  TILE_FLAG_NO_HELP = 4       // tuning / tests: a persistent workgroup leaves when its own XCD's share is used up
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
@@ -208,7 +209,8 @@ enum VariantBits : int {
   VAR_NO_INTERIOR = 2048,       // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
   VAR_XCD_RUNS = 8192,          // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
   VAR_ZMAJOR_SLOTS = 16384,     // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
-  VAR_SLAB_TURNS = 65536        // tiled kernel, slab fuses: workgroups leave after four bricks (TileArgs::bricks_per_workgroup)
+  VAR_SLAB_TURNS = 65536,       // tiled kernel, slab fuses: workgroups leave after four bricks (TileArgs::bricks_per_workgroup)
+  VAR_NO_HELP = 131072          // tiled kernel: persistent workgroups do not take bricks of other XCDs' shares
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

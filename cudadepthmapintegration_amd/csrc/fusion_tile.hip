@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   for (;;) {
   const int xq = (b + helped) & 7;  // whose share
   if constexpr (PERSIST) {
-    if (helped == 8 || bricks_left == 0) break;
+    if (helped == ((KC(flags) & TILE_FLAG_NO_HELP) ? 1 : 8) || bricks_left == 0) break;
     int taken = 0;
     if (lane == 0) taken = atomicAdd(KC(queue_heads) + 16 * xq, 1);
     q = __builtin_amdgcn_readfirstlane(taken);
