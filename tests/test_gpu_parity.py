@@ -581,3 +581,24 @@ def test_fp64_probe_reports_a_plausible_rate():
     assert 5.0 < rate < 100.0
     with pytest.raises(capi.DmiError):
         capi.fp64_probe(0, -1.0)
+
+
+def test_more_views_than_the_free_sums_table_holds():
+    """4200 views in one fusion: beyond kFreeSumsMax (4096) the kernel has no table of n-fold free-space sums and adds view by
+    view from the start; class rows are 8192 bytes wide.  Same bits as the oracle, with and without hit counters."""
+    grid = scene.default_grid((16, 16, 16))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(4200, 16, 12, seed=3, dense=True)
+    want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                   n_threads=oracle.max_threads())
+    for count_hits in (False, True):
+        out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits)
+        assert bits_equal(out, want), count_hits
+        if count_hits:
+            assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w)
+    # and the same views fused in two calls: the second run starts from the first one's grid (no table either)
+    with capi.FusionContext(grid, rp) as ctx:
+        ctx.add_views(views)
+        ctx.fuse(0, 2000)
+        ctx.fuse(2000, 2200)
+        assert bits_equal(ctx.download_grid(), want)
