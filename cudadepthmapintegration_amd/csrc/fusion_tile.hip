@@ -1,17 +1,18 @@
 // fusion_tile.hip -- register-tiled TSDF fusion kernel for gfx950 (MI355X): the fast path of dmi_fuse.
 //
-// Preconditions (checked on the host, dmi_capi.hip `tile_eligible`): every K is a pinhole matrix
-// [fx s cx 0; 0 fy cy 0; 0 0 1 0], all magnitudes are finite and bounded, thickness >= 0 and delta >= 0.
-// Everything else runs the general kernel (fusion_kernels.hip).  The grid may have any axes (the reference
-// CLI builds the matrix from gridVecX/Y/Z, main.cxx:345-359): what follows describes the axis-aligned case
-// (3x3 part diagonal, the default); the ROT instantiation for rotated axes is described at the kernel.
+// Preconditions (checked on the host, dmi_capi.hip `tile_eligible` / `view_tile_ok`): all magnitudes are finite and
+// bounded, thickness >= 0 and delta >= 0; a view's K may be anything (a third row other than 0 0 1 0 takes the GENK
+// instantiation).  Views no fast path takes run the general kernel (fusion_kernels.hip).  The grid may have any axes
+// (the reference CLI builds the matrix from gridVecX/Y/Z, main.cxx:345-359): what follows describes the axis-aligned
+// case (3x3 part diagonal, the default); the ROT instantiation for rotated axes is described at the kernel.
 //
 // Decomposition.  A wavefront is an 8 x 8 patch of lanes in (i, j); every lane owns a COLUMN of TK
-// voxels along k and keeps their TK fp64 running sums in registers for the whole fusion; a workgroup
-// is WX x WY such waves = a brick of 8WX x 8WY x TK voxels (one wave in the two default shapes); bricks are
-// visited heaviest first, in runs that keep an XCD (own L2) on neighbouring bricks.  The kernel loops over the resident depth maps
-// (wave-uniform index -> camera record and cz table through scalar loads into SGPRs) and, inside,
-// over the column (fully unrolled).  The grid is written once at the end.
+// voxels along k and keeps their TK fp64 running sums in registers while the brick is fused; a brick is
+// 8WX x 8WY x TK voxels (one wave in the two default shapes).  One-wave workgroups are persistent: each takes brick after
+// brick from its XCD's share of the bricks -- heaviest first, Z-order inside a weight level -- and helps the other XCDs
+// when that is used up.  Per brick the kernel loops over the resident depth maps (wave-uniform index -> camera record and
+// cz table through scalar loads into SGPRs) and, inside, over the column (fully unrolled); the brick's part of the grid is
+// written once, at its end.
 //
 // What is exact and what is only proven.  The reference evaluates, per voxel and map (cu:158-212):
 //   c = RT*[w,1]; h = K*[c,1]; if (h.z < 0) return; px = round(h.x/h.z); py = round(h.y/h.z);
