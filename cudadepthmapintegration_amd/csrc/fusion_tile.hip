@@ -624,9 +624,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       }
     };
     bool interior = false;
-    if constexpr (!ROT && !GENK)
+    if constexpr (!GENK)
       interior = kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
-    if constexpr (!ROT && !GENK) {
+    if constexpr (!GENK) {
       if (interior) {
         if constexpr (!COUNT) {
           if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
