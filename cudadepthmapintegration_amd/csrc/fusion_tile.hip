@@ -623,22 +623,20 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         }
       }
     };
-    bool interior = false;
-    if constexpr (!GENK)
-      interior = kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
-    if constexpr (!GENK) {
-      if (interior) {
-        if constexpr (!COUNT) {
-          if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
-            column(std::true_type{}, std::true_type{});
-          else
-            column(std::true_type{}, std::false_type{});
-        } else {
+    // (every instantiation: the classification's proof covers rotated grids, 4b.1, and general K, 4b.7)
+    const bool interior = kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
+    if (interior) {
+      if constexpr (!COUNT) {
+        if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
+          column(std::true_type{}, std::true_type{});
+        else
           column(std::true_type{}, std::false_type{});
-        }
+      } else {
+        column(std::true_type{}, std::false_type{});
       }
+    } else {
+      column(std::false_type{}, std::false_type{});
     }
-    if (!interior) column(std::false_type{}, std::false_type{});
 
     // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so
     // doing them after the column keeps every voxel's accumulation in map order, cu:211)
