@@ -144,8 +144,8 @@ struct BoxFootprint {
   double czmin, czmax;
 };
 
-template <bool ROT>
-__device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const MapRec *__restrict__ mr,
+template <bool ROT, bool GK>
+__device__ __forceinline__ BoxFootprint box_footprint_k(const TileArgs &a, const MapRec *__restrict__ mr,
                                                       const TileMapRec *__restrict__ tr, int i0, int i1, int j0, int j1, int k0,
                                                       int k1) {
   BoxFootprint fp;
@@ -156,7 +156,7 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   // General K (third row not 0 0 1 0, cu:176): the divisor of cu:183-184 and the subject of cu:177 is h.z, an affine
   // function of the world position like h.x and h.y (TileMapRec::sx..s0), known to within errz; for a pinhole K it is c.z
   // itself and everything below reads as it always did.
-  const bool genk = tr->errz != 0.0;
+  constexpr bool genk = GK;  // (a compile-time branch: a pinhole view pays nothing for the general case)
   double hzmin = __builtin_inf(), hzmax = -__builtin_inf();
   bool bad = false;
   const double r23 = mr->rt[11];
@@ -178,9 +178,12 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
       double r = __builtin_amdgcn_rcp(hz);
       r = __builtin_fma(r, __builtin_fma(-hz, r, 1.0), r);
       const double u = hx * r, v = hy * r;
-      bad = bad || !(cz == cz) || !(hz == hz);
-      hzmin = fmin(hzmin, hz);
-      hzmax = fmax(hzmax, hz);
+      bad = bad || !(cz == cz);
+      if (genk) {
+        bad = bad || !(hz == hz);
+        hzmin = fmin(hzmin, hz);
+        hzmax = fmax(hzmax, hz);
+      }
       czmin = fmin(czmin, cz);
       czmax = fmax(czmax, cz);
       umin = fmin(umin, u);
@@ -232,9 +235,12 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
     double r = __builtin_amdgcn_rcp(hz);
     r = __builtin_fma(r, __builtin_fma(-hz, r, 1.0), r);
     const double u = hx * r, v = hy * r;
-    bad = bad || !(cz == cz) || !(hz == hz);
-    hzmin = fmin(hzmin, hz);
-    hzmax = fmax(hzmax, hz);
+    bad = bad || !(cz == cz);
+    if (genk) {
+      bad = bad || !(hz == hz);
+      hzmin = fmin(hzmin, hz);
+      hzmax = fmax(hzmax, hz);
+    }
     czmin = fmin(czmin, cz);
     czmax = fmax(czmax, cz);
     umin = fmin(umin, u);
@@ -287,6 +293,18 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   return fp;
 }
 
+// GK: some view of the launch has a general K (the host knows: FuseConfig::general_k); then each view is looked at.  A
+// launch of pinhole views alone -- the usual case -- runs the kernels without a trace of the general case in them.
+template <bool ROT, bool GK>
+__device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const MapRec *__restrict__ mr,
+                                                      const TileMapRec *__restrict__ tr, int i0, int i1, int j0, int j1, int k0,
+                                                      int k1) {
+  if constexpr (GK) {
+    if (tr->errz != 0.0) return box_footprint_k<ROT, true>(a, mr, tr, i0, i1, j0, j1, k0, k1);
+  }
+  return box_footprint_k<ROT, false>(a, mr, tr, i0, i1, j0, j1, k0, k1);
+}
+
 // Part 2: the class that depth bounds `d` over (a superset of) the footprint prove for c.z in [czmin, czmax]
 __device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const TileAcc &d, double czmin, double czmax) {
   if (d.flags & TILE_HAS_NAN) return BRICK_MIXED | (MIXED_NAN_DEPTH << 2);
@@ -297,11 +315,11 @@ __device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const Ti
   return BRICK_MIXED | (MIXED_NEAR_SURFACE << 2);
 }
 
-template <int kQueryTiles, bool ROT>
+template <int kQueryTiles, bool ROT, bool GK>
 __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
                                                 const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
                                                 int j0, int j1, int k0, int k1) {
-  const BoxFootprint fp = box_footprint<ROT>(a, mr, tr, i0, i1, j0, j1, k0, k1);
+  const BoxFootprint fp = box_footprint<ROT, GK>(a, mr, tr, i0, i1, j0, j1, k0, k1);
   if (!fp.query) return fp.cls;
   return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
 }
@@ -310,7 +328,7 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
 // from every surface a view saw: there the whole box is proven at once and its bricks inherit the class; the bricks of
 // unproven boxes are left to the fine pass.  threadIdx.x runs over 64 consecutive views, so the box's own table row
 // and every child row receive 64 consecutive bytes per store.  Boxes are numbered over the whole grid.
-template <bool ROT>
+template <bool ROT, bool GK>
 __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                               const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                               uint8_t *__restrict__ coarse) {
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
   const int bz0 = cbz * per_z;
-  const uint8_t cls = classify_box<5, ROT>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
+  const uint8_t cls = classify_box<5, ROT, GK>(a, maps + m, a.tile_maps + m, P, cbx * 32, cbx * 32 + 31, cby * 32, cby * 32 + 31, bz0 * tk,
                                    bz0 * tk + 31);
   coarse[(int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + m] = cls;
   if ((cls & 3) == BRICK_MIXED) return;  // the fine pass decides brick by brick
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
 constexpr int kWindow = 16;  // tiles per axis of the staged window
 
 // kChildren: wave bricks per box = lanes per view, 64 (8-voxel columns) or 32 (16-voxel columns)
-template <int kQueryTiles, int kChildren, bool ROT>
+template <int kQueryTiles, int kChildren, bool ROT, bool GK>
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                        const uint8_t *__restrict__ coarse) {
@@ -408,13 +426,15 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
       tr_u.err = cload(&tsrc->err);
       tr_u.cz_err = cload(&tsrc->cz_err);
       tr_u.errz = cload(&tsrc->errz);
-      tr_u.sx = cload(&tsrc->sx); tr_u.sy = cload(&tsrc->sy); tr_u.sz = cload(&tsrc->sz); tr_u.s0 = cload(&tsrc->s0);
+      if constexpr (GK) {
+        tr_u.sx = cload(&tsrc->sx); tr_u.sy = cload(&tsrc->sy); tr_u.sz = cload(&tsrc->sz); tr_u.s0 = cload(&tsrc->s0);
+      }
       mr = &mr_u;
       if (mine) {
-        fp = box_footprint<ROT>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+        fp = box_footprint<ROT, GK>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
       }
     } else {
-      if (mine) fp = box_footprint<ROT>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+      if (mine) fp = box_footprint<ROT, GK>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
     }
     const bool query = mine && fp.query;
     uint8_t cls = fp.cls;
@@ -659,7 +679,7 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 }
 
 hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, const PyramidDesc &P, int tk, uint8_t *classes,
-                                  uint8_t *coarse, hipStream_t stream) {
+                                  uint8_t *coarse, int general_k, hipStream_t stream) {
   const int bz_count = std::min(2 * a.super_z, a.bricks_z - 2 * a.sbz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
   if (n_bricks <= 0 || a.n_maps <= 0) return hipSuccess;
@@ -667,23 +687,37 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
   const int per_z = 32 / tk;
   const int64_t n_boxes = (int64_t)((a.wbricks_x + 3) / 4) * ((a.wbricks_y + 3) / 4) * ((bz_count + per_z - 1) / per_z);
   const dim3 coarse_grid((unsigned)((n_boxes + 3) / 4), (unsigned)((a.n_maps + 63) / 64));
-  if (a.rotated)
-    hipLaunchKernelGGL(classify_coarse_kernel<true>, coarse_grid, dim3(64, 4), 0, stream, a, maps_dev, P, tk, classes, coarse);
+#define DMI_LAUNCH_COARSE(R, G) \
+  hipLaunchKernelGGL((classify_coarse_kernel<R, G>), coarse_grid, dim3(64, 4), 0, stream, a, maps_dev, P, tk, classes, coarse)
+  if (a.rotated && general_k)
+    DMI_LAUNCH_COARSE(true, true);
+  else if (a.rotated)
+    DMI_LAUNCH_COARSE(true, false);
+  else if (general_k)
+    DMI_LAUNCH_COARSE(false, true);
   else
-    hipLaunchKernelGGL(classify_coarse_kernel<false>, coarse_grid, dim3(64, 4), 0, stream, a, maps_dev, P, tk, classes, coarse);
+    DMI_LAUNCH_COARSE(false, false);
+#undef DMI_LAUNCH_COARSE
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const dim3 fine_grid((unsigned)n_boxes, (unsigned)((a.n_maps + 63) / 64));
   // tiles per axis the fine pass may read for its depth bounds: 2 -> 3 -> 5 took the mixed pairs of cfg 3 from 10.1 M to
   // 8.4 M to 7.6 M and the fusion from 10.8 to 10.0 to 9.8 ms; more gains nothing at 8-pixel tiles, and 4-pixel tiles
   // cost more in this pass than they save in the next (profiles/r01zm_*)
-  int q = 5;
+  [[maybe_unused]] int q = 5;
 #ifdef DMI_TUNING
   if (const char *env = getenv("DMI_QUERY_TILES")) q = atoi(env);  // tuning experiments (tools/gpu_query_tiles.sh)
 #endif
   const bool wide = tk == 8;  // 64 bricks per box
-#define DMI_LAUNCH_FINE_R(Q, C, R) \
-  hipLaunchKernelGGL((classify_kernel<Q, C, R>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse)
+#define DMI_LAUNCH_FINE_G(Q, C, R, G) \
+  hipLaunchKernelGGL((classify_kernel<Q, C, R, G>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse)
+#define DMI_LAUNCH_FINE_R(Q, C, R)      \
+  do {                                  \
+    if (general_k)                      \
+      DMI_LAUNCH_FINE_G(Q, C, R, true); \
+    else                                \
+      DMI_LAUNCH_FINE_G(Q, C, R, false);\
+  } while (0)
 #define DMI_LAUNCH_FINE(Q)                      \
   do {                                          \
     if (wide && a.rotated)                      \
@@ -695,12 +729,15 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
     else                                        \
       DMI_LAUNCH_FINE_R(Q, 32, false);          \
   } while (0)
+#ifdef DMI_TUNING
   if (q <= 2)
     DMI_LAUNCH_FINE(2);
   else if (q == 3)
     DMI_LAUNCH_FINE(3);
   else
+#endif
     DMI_LAUNCH_FINE(5);
+#undef DMI_LAUNCH_FINE_G
 #undef DMI_LAUNCH_FINE_R
 #undef DMI_LAUNCH_FINE
   return hipGetLastError();

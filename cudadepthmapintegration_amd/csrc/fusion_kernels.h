@@ -249,8 +249,9 @@ PyramidDesc make_pyramid_desc(int W, int H);
 hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &desc,
                                  DepthTile *pyramids, hipStream_t stream);
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.
+// general_k: some view of the run has a K with a general third row (the kernels then look at every view's errz)
 hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, const PyramidDesc &desc, int tk,
-                                  uint8_t *classes, uint8_t *coarse, hipStream_t stream);
+                                  uint8_t *classes, uint8_t *coarse, int general_k, hipStream_t stream);
 // bytes of the coarse class table (one row of class_pitch bytes per box of 32^3 voxels of the whole grid)
 int64_t coarse_class_bytes(const TileArgs &args, int tk);
 // order[p] = slot (super_brick * 32 + brick) of the p-th workgroup, bricks with the most BRICK_MIXED pairs first;

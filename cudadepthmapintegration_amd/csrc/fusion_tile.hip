@@ -864,7 +864,7 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
   if (e != hipSuccess) return e;
   if (!(cfg.variant & VAR_NO_BRICK_CLASSES)) {
     const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0 || cfg.general_k != 0);
-    e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, stream);
+    e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, cfg.general_k, stream);
     if (e != hipSuccess) return e;
 #ifdef DMI_TUNING
     if (const char *env = getenv("DMI_DEBUG_CLASS_REMAP")) {  // e.g. 0x03020300: byte c = what class c becomes
