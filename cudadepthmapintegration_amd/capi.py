@@ -27,8 +27,6 @@ VARIANT_KEEP_BEHIND_ADDS = 1024  # tiled kernel: perform +0.0 adds even when the
 VARIANT_NO_INTERIOR = 2048  # tiled kernel: keep the in-front / in-image tests for every mixed pair
 VARIANT_XCD_RUNS = 8192  # tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of an eighth of a level each
 VARIANT_ZMAJOR_SLOTS = 16384  # tiled kernel: super-bricks enumerated x, y, z (until r03h) instead of in Z-order
-VARIANT_NO_HELP = 131072  # tiled kernel: persistent workgroups stay within their own XCD's share of the bricks
-VARIANT_SLAB_TURNS = 65536  # tiled kernel, slab fuses (dmi_fuse_slab, dmi_multi_*): workgroups leave after four bricks
 VARIANT_FIXED_TILE_SHAPE = 4096  # tile-shape bits 0 mean shape 0 (tk16_w5) whatever the grid size; without it grids
                                  # below 512^3 pick tk8_w7 on their own
 VARIANT_SPATIAL_ORDER = 512  # tiled kernel: workgroups in spatial order instead of heaviest bricks first

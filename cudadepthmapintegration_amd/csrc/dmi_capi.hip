@@ -1040,8 +1040,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // r22*wz(k) table, one row of kpad doubles per resident view
     t.rotated = grid_axis_aligned(ctx->grid) ? 0 : 1;
     t.flags = ((cfg.variant & dmi::VAR_NO_INTERIOR) ? dmi::TILE_FLAG_NO_INTERIOR : 0) |
-              ((cfg.variant & dmi::VAR_XCD_RUNS) ? dmi::TILE_FLAG_XCD_RUNS : 0) |
-              ((cfg.variant & dmi::VAR_NO_HELP) ? dmi::TILE_FLAG_NO_HELP : 0);
+              ((cfg.variant & dmi::VAR_XCD_RUNS) ? dmi::TILE_FLAG_XCD_RUNS : 0);
     t.maps = ctx->d_maps;
     // rotated: [kpad][4]; behind the table, the sums of n free-space constants (TileArgs::free_sums)
     const size_t table_doubles = std::max<size_t>((size_t)n_views, 4) * (size_t)t.kpad;
@@ -1062,11 +1061,6 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     t.cz_table = ctx->d_cz_table;
     if (!ctx->d_queue_heads) DMI_HIP(ctx, hipMalloc(&ctx->d_queue_heads, 128 * sizeof(int32_t)));
     t.queue_heads = ctx->d_queue_heads;
-    // A slab fuse is one step of a pipeline on several streams (dmi_multi_fuse: the exchange of the slab before runs
-    // meanwhile, and its kernels can only start where wave slots come free: at the boundary between two slab launches,
-    // where both queues are ready, when the workgroups are persistent).  VAR_SLAB_TURNS makes the workgroups of a slab
-    // fuse take turns, four bricks each -- 6 % slower on one GPU with sixteen; for whoever tunes the overlap on a node.
-    t.bricks_per_workgroup = (!whole_grid && (cfg.variant & dmi::VAR_SLAB_TURNS)) ? 4 : 0;
     // valid while every sum of the launch starts at +0.0 and hits are not counted (counted views are taken one by one)
     if (!a.init_from_grid && !ctx->opt.count_hits && count <= dmi::kFreeSumsMax) t.free_sums = ctx->d_cz_table + table_doubles;
     // brick classes: one byte per (8 x 8 x column wave brick, resident view)

@@ -150,18 +150,13 @@ struct TileArgs {
   int64_t wg_times_n;
   // brick counters of the persistent workgroups, one per XCD at [16 * xcd]; zeroed by the table kernel of every launch
   int32_t *queue_heads;
-  // 0: a persistent workgroup stays until every share is used up.  n > 0: it leaves after n bricks and the launch has
-  // correspondingly more workgroups -- wave slots then come free every few hundred microseconds, which is what lets the
-  // kernels of ANOTHER stream (the slab exchange of a multi-GPU fusion, RCCL) start while a slab is being fused
-  int32_t bricks_per_workgroup, pad4;
 };
 constexpr int kFreeSumsMax = 4096;
 // an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)
 __host__ __device__ inline int32_t pack_brick(int bx, int by, int bz) { return (int32_t)((uint32_t)bx | ((uint32_t)by << 11) | ((uint32_t)bz << 22)); }
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
-  TILE_FLAG_XCD_RUNS = 2,     // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
-  TILE_FLAG_NO_HELP = 4       // tuning / tests: a persistent workgroup leaves when its own XCD's share is used up
+  TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
@@ -208,9 +203,7 @@ enum VariantBits : int {
   VAR_KEEP_BEHIND_ADDS = 1024,  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
   VAR_NO_INTERIOR = 2048,       // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
   VAR_XCD_RUNS = 8192,          // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
-  VAR_ZMAJOR_SLOTS = 16384,     // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
-  VAR_SLAB_TURNS = 65536,       // tiled kernel, slab fuses: workgroups leave after four bricks (TileArgs::bricks_per_workgroup)
-  VAR_NO_HELP = 131072          // tiled kernel: persistent workgroups do not take bricks of other XCDs' shares
+  VAR_ZMAJOR_SLOTS = 16384      // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

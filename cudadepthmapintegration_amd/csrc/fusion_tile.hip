@@ -246,7 +246,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int b = blockIdx.x;
   int q = b >> 3;   // the q-th brick of an XCD's share
   int helped = 0;   // PERSIST: how many XCDs' shares this workgroup has seen the end of
-  int bricks_left = KA(bricks_per_workgroup) > 0 ? KA(bricks_per_workgroup) : 0x7fffffff;  // PERSIST: then it leaves
 #define DMI_NEXT_BRICK \
   {                    \
     if (PERSIST)       \
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   for (;;) {
   const int xq = (b + helped) & 7;  // whose share
   if constexpr (PERSIST) {
-    if (helped == ((KC(flags) & TILE_FLAG_NO_HELP) ? 1 : 8) || bricks_left == 0) break;
+    if (helped == 8) break;
     int taken = 0;
     if (lane == 0) taken = atomicAdd(KC(queue_heads) + 16 * xq, 1);
     q = __builtin_amdgcn_readfirstlane(taken);
@@ -307,7 +306,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       return;
     }
   }
-  --bricks_left;  // (only bricks count: every workgroup fuses its full number unless all shares are used up before)
   int bx, by, bz;
   if (KC(order)) {
     bx = entry & 2047, by = (entry >> 11) & 2047, bz = (int)((unsigned)entry >> 22);
@@ -773,10 +771,7 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>;
   if (WX * WY == 1) {  // persistent one-wave workgroups: as many as the chip holds (asked once per instantiation)
     static const unsigned resident[2] = {resident_workgroups(plain, 64), resident_workgroups(counted, 64)};
-    unsigned wanted = resident[cfg.count_hits ? 1 : 0];
-    if (a.bricks_per_workgroup > 0)  // workgroups that leave after so many bricks: enough of them for all the bricks
-      wanted += (unsigned)((a.super_x * a.super_y * a.super_z * 32 + a.bricks_per_workgroup - 1) / a.bricks_per_workgroup + 7) / 8u * 8u;
-    blocks = std::min(blocks, wanted);
+    blocks = std::min(blocks, resident[cfg.count_hits ? 1 : 0]);
   }
   if (cfg.count_hits)
     hipLaunchKernelGGL(counted, dim3(blocks), block, 0, s, a);
