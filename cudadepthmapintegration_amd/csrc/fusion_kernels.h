@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -154,6 +155,10 @@ struct TileArgs {
 constexpr int kFreeSumsMax = 4096;
 // an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)
 __host__ __device__ inline int32_t pack_brick(int bx, int by, int bz) { return (int32_t)((uint32_t)bx | ((uint32_t)by << 11) | ((uint32_t)bz << 22)); }
+// fuse_tile_kernel reads the first sixteen ints as two vectors
+static_assert(offsetof(TileArgs, nx) == 0 && offsetof(TileArgs, nz) == 8 && offsetof(TileArgs, kpad) == 32 &&
+                  offsetof(TileArgs, bricks_x) == 36 && offsetof(TileArgs, bricks_z) == 44 && offsetof(TileArgs, sbz_first) == 60,
+              "TileArgs head layout");
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
   TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)

@@ -254,23 +254,36 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       return;          \
   }
   for (;;) {
+  // one fresh view of the argument block per brick: what the prologue needs arrives in a few wide scalar loads and ONE
+  // wait, instead of a chain of dependent single loads (a persistent wave pays the prologue's latency once per brick)
+  const kernarg_t kb = KFRESH();
+  // (the first sixteen ints of TileArgs: nx ny nz W H first_map n_maps init_from_grid | kpad bricks_x bricks_y bricks_z
+  // super_x super_y super_z sbz_first; static_asserts below pin the layout)
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  const i32x8 head0 = *reinterpret_cast<const i32x8 __attribute__((address_space(4))) *>(kb);
+  const i32x8 head1 = *(reinterpret_cast<const i32x8 __attribute__((address_space(4))) *>(kb) + 1);
+  const int32_t *const p_order = kb->order, *const p_levels = kb->order_levels, *const p_n_order = kb->n_order;
+  const int kflags = kb->flags;
   const int xq = (b + helped) & 7;  // whose share
   if constexpr (PERSIST) {
     if (helped == 8) break;
     int taken = 0;
-    if (lane == 0) taken = atomicAdd(KC(queue_heads) + 16 * xq, 1);
+    if (lane == 0) taken = atomicAdd(kb->queue_heads + 16 * xq, 1);
     q = __builtin_amdgcn_readfirstlane(taken);
   }
   int entry = -1;  // the brick as the ordering kernels pack it (pack_brick), when there is an order
   int p = -1;      // else: position in the slab's own enumeration
   bool used_up = false;
-  if (KC(order) && !(KC(flags) & TILE_FLAG_XCD_RUNS)) {
+  if (p_order && !(kflags & TILE_FLAG_XCD_RUNS)) {
     int rest = q, found = -1;
-    const kernarg_t ko = KFRESH();
-    int lo = cload(ko->order_levels);
+    // the five level boundaries at once (order_levels[0..3] are consecutive; n_order is elsewhere)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 bounds = cload(reinterpret_cast<const i32x4 *>(p_levels));
+    const int last = cload(p_n_order);
+    int lo = bounds[0];
 #pragma unroll
     for (int level = 0; level < 4; ++level) {
-      const int hi = level < 3 ? cload(ko->order_levels + level + 1) : cload(ko->n_order);
+      const int hi = level < 3 ? bounds[level + 1] : last;
       const int n = hi - lo;
       const int s0 = (int)(((long long)xq * n) >> 3), s1 = (int)(((long long)(xq + 1) * n) >> 3);
       if (found < 0) {
@@ -284,17 +297,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     if (found < 0)
       used_up = true;
     else
-      entry = cload(ko->order + found);
+      entry = cload(p_order + found);
     p = found;
   } else {
-    const int run = KC(xcd_run_wg);             // bricks dealt to one XCD in a row
+    const int run = kb->xcd_run_wg;             // bricks dealt to one XCD in a row
     p = (q / run) * (8 * run) + xq * run + q % run;
-    if (KC(order)) {
-      if (p >= cload(KC(n_order)))
+    if (p_order) {
+      if (p >= cload(p_n_order))
         used_up = true;
       else
-        entry = cload(KC(order) + p);
-    } else if (p >= KC(slot_count)) {
+        entry = cload(p_order + p);
+    } else if (p >= kb->slot_count) {
       used_up = true;
     }
   }
@@ -307,32 +320,32 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     }
   }
   int bx, by, bz;
-  if (KC(order)) {
+  if (p_order) {
     bx = entry & 2047, by = (entry >> 11) & 2047, bz = (int)((unsigned)entry >> 22);
   } else {
     const int within = p & 31;
-    const int code = cload(KC(sb_perm) + (p >> 5));  // the slab's super-bricks in Z-order (fusion_kernels.h)
-    const int sbx = code & 1023, sby = (code >> 10) & 1023, sbz = (code >> 20) + KC(sbz_first);
+    const int code = cload(kb->sb_perm + (p >> 5));  // the slab's super-bricks in Z-order (fusion_kernels.h)
+    const int sbx = code & 1023, sby = (code >> 10) & 1023, sbz = (code >> 20) + head1[7];
     bx = sbx * 4 + (within & 3), by = sby * 4 + ((within >> 2) & 3), bz = sbz * 2 + (within >> 4);
   }
-  if (bx >= KC(bricks_x) || by >= KC(bricks_y) || bz >= KC(bricks_z)) DMI_NEXT_BRICK  // padding of the super-brick grid
+  if ((bx >= head1[1]) | (by >= head1[2]) | (bz >= head1[3])) DMI_NEXT_BRICK  // padding of the super-brick grid
 
 #ifdef DMI_TUNING
   unsigned long long wg_t0 = 0;
-  if (KC(wg_times)) wg_t0 = __builtin_amdgcn_s_memrealtime();
+  if (kb->wg_times) wg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
-  if (wbx >= KC(wbricks_x) || wby >= KC(wbricks_y)) DMI_NEXT_BRICK     // wave entirely outside the grid
+  if ((wbx >= kb->wbricks_x) | (wby >= kb->wbricks_y)) DMI_NEXT_BRICK     // wave entirely outside the grid
   const int i = wbx * kLX + (lane % kLX);
   const int j = wby * kLY + (lane / kLX);
   const int k0 = bz * TK;
-  const int kcount = KC(nz) - k0 < TK ? KC(nz) - k0 : TK;  // wave-uniform, >= 1
-  const bool lane_ok = i < KC(nx) && j < KC(ny);
+  const int kcount = head0[2] - k0 < TK ? head0[2] - k0 : TK;  // wave-uniform, >= 1
+  const bool lane_ok = (i < head0[0]) & (j < head0[1]);
 
   // cu:78-83 + cu:168 once per lane.  With a diagonal 3x3 grid matrix wx depends on i only, wy on j
   // only, wz on k only (the off-diagonal products are exact zeros; only the sign of a zero result can
   // depend on the other indices, and no later step observes it: DESIGN.md).
-  const kernarg_t kg = KFRESH();
+  const kernarg_t kg = kb;
   const double gx = kg->ox + (i + 0.5) * kg->sx;
   const double gy = kg->oy + (j + 0.5) * kg->sy;
   const double gz0 = kg->oz + ((k0 + kg->kz0) + 0.5) * kg->sz;
