@@ -14,9 +14,9 @@ from helpers import bits_equal, oracle_params_from_scene
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(seed):
+def _random_case(seed, medium=False):
     rng = np.random.default_rng(seed)
-    dims = tuple(int(v) for v in rng.integers(5, 45, size=3))
+    dims = tuple(int(v) for v in (rng.integers(140, 215, size=3) if medium else rng.integers(5, 45, size=3)))
     extent = rng.uniform(0.5, 3.0, size=3)
     origin = tuple(-extent / 2 + rng.uniform(-0.3, 0.3, size=3))
     spacing = tuple(extent / np.array(dims))
@@ -33,8 +33,8 @@ def _random_case(seed):
             gm[:3, :3] = q
             gm[:3, 3] = rng.uniform(-0.2, 0.2, size=3)
     grid = scene.GridDesc(dims, origin, spacing, gm)
-    n = int(rng.integers(1, 9))
-    W, H = int(rng.integers(8, 90)), int(rng.integers(6, 70))
+    n = int(rng.integers(9, 20)) if medium else int(rng.integers(1, 9))
+    W, H = (int(rng.integers(200, 400)), int(rng.integers(150, 300))) if medium else (int(rng.integers(8, 90)), int(rng.integers(6, 70)))
     radius = float(rng.choice([0.3, 1.2, 3.0, 6.0]))
     views = scene.make_views(n, W, H, seed=int(rng.integers(1 << 30)), dense=bool(rng.integers(0, 2)), radius=radius,
                              focal_scale=float(rng.uniform(0.4, 1.5)))
@@ -89,3 +89,19 @@ def test_random_scenes_bit_exact(seed):
         assert np.array_equal(mh, mh_w), (seed, variant)
         assert np.array_equal(vh, vh_w), (seed, variant)
         assert bits_equal(out, want), (seed, variant)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_medium_scenes_bit_exact(seed):
+    """The same generator at 140..215 cells per axis (6 000 to 19 000 bricks: more than the 5120 persistent workgroups the
+    chip holds, so every workgroup fuses several bricks, runs out of its XCD's share and helps the others) and 9..19 views
+    of a few hundred pixels: the whole grid against the oracle, bit for bit, default path and the path without classes."""
+    grid, rp, views = _random_case(1000 + seed, medium=True)
+    with np.errstate(all="ignore"):
+        want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                       n_threads=oracle.max_threads())
+    for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_NO_BRICK_CLASSES, False), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False)):
+        out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
+        assert bits_equal(out, want), (seed, variant, count_hits)
+        if count_hits:
+            assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w), (seed, variant)
