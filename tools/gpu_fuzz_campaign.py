@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--count", type=int, default=1000)
     ap.add_argument("--seconds", type=float, default=420.0, help="stop starting new cases after this long")
+    ap.add_argument("--medium-every", type=int, default=0,
+                    help="every n-th seed is a medium-size scene (more bricks than persistent workgroups); 0 = none")
     args = ap.parse_args()
     fx = capi.VARIANT_FIXED_TILE_SHAPE
     variants = [(0, True), (0, False), (fx, True), (fx, False), (fx | capi.VARIANT_NO_BRICK_CLASSES, True), (96, True),
@@ -42,7 +44,7 @@ def main():
     for seed in range(args.first, args.first + args.count):
         if time.time() - t0 > args.seconds:
             break
-        grid, rp, views = _random_case(seed)
+        grid, rp, views = _random_case(seed, medium=(args.medium_every > 0 and seed % args.medium_every == 0))
         init = None
         if seed % 5 == 0:
             init = np.random.default_rng(seed).normal(size=(grid.cell_dims[2], grid.cell_dims[1], grid.cell_dims[0]))
