@@ -24,6 +24,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +35,16 @@ struct ColorView {
   double rt[12];           // rows 0..2 of [R|T]
   double k[9];             // rows 0..2, columns 0..2 of the 4x4 K (TransformVector ignores column 3)
   const uchar4 *color;     // [H][W] RGBA, TOP image row first (the reference's vtk order is flipped at upload)
+  double p[12];            // rows 0..2 of K3 * [R|T]: the pixel selection's shortcut (project_color_kernel)
+  double mag[12];          // |K3| * |[R|T]|, the same product of magnitudes: what bounds the shortcut's error
+};
+
+// Per view and chunk of vertices (ViewMargin, uploaded by dmi_color_process): how far the shortcut's homogeneous
+// coordinates can be from the reference's, as (ex, ey) = E0 + 65537 E2, E1 + 65537 E2 with Ei = 2^-47 * sum_j mag[i][j] *
+// max|p_j| over the chunk (p_3 = 1): the reference's d_i carries at most 11 roundings of terms bounded by that sum, the
+// host's product K3*[R|T] three, the FMA chain four (see round_to_pixel_near).
+struct ViewMargin {
+  double ex, ey;
 };
 
 template <typename T>
@@ -72,6 +83,20 @@ struct FastQuotient {
       return true;
     }
     return to_pixel(num / den, p);
+  }
+  // The same for a numerator and a denominator that are only NEAR the reference's (each within the bounds behind
+  // `margin` = (E_num + 65537 E_den)): |num/den - num_ref/den_ref| <= (E_num + |u| E_den) / |den| with |u| < 2^16, so
+  // ua is within margin * |r| + 2^-21 of the reference's quotient; accepted iff further than that + 2^-21 from every
+  // half-integer.  false = not decided (the caller takes the reference's own expression).
+  __device__ __forceinline__ bool round_to_pixel_near(double num, double margin, int &p) const {
+    const double ua = num * r;
+    const double fl = __builtin_floor(ua), fr = ua - fl;
+    const double reach = __builtin_fma(margin, __builtin_fabs(r), 0x1p-20);
+    if (usable && __builtin_fabs(ua) < 65536.0 && __builtin_fabs(fr - 0.5) > reach) {  // a NaN margin or r: not taken
+      p = (int)fl + (fr > 0.5 ? 1 : 0);
+      return true;
+    }
+    return false;
   }
 };
 
@@ -169,7 +194,8 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
                                                             const uint32_t *__restrict__ perm,
                                                             const ColorView *__restrict__ views, int n, int W, int H,
                                                             uchar4 *__restrict__ scratch, uint8_t *__restrict__ mean,
-                                                            int32_t *__restrict__ count, MedianSeed *__restrict__ seeds) {
+                                                            int32_t *__restrict__ count, MedianSeed *__restrict__ seeds,
+                                                            const ViewMargin *__restrict__ margins) {
   __shared__ uint32_t hist[HIST ? 3 * kHistWords * 256 : 1];  // [channel][word][lane]: 24 KB
   const int lane = threadIdx.x;
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // position along the Z-order curve
@@ -185,19 +211,31 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
     for (int q = 0; q < 3 * kHistWords; ++q) hist[q * 256 + lane] = 0;
   for (int m = 0; m < n; ++m) {
     const ColorView *v = views + m;  // wave-uniform
-    // vtkTransform::TransformPoint with MatrixTR (RD.cxx:173): M[i][0]*x + M[i][1]*y + M[i][2]*z + M[i][3], left to right
-    const double cx = ((cload(&v->rt[0]) * x + cload(&v->rt[1]) * y) + cload(&v->rt[2]) * z) + cload(&v->rt[3]);
-    const double cy = ((cload(&v->rt[4]) * x + cload(&v->rt[5]) * y) + cload(&v->rt[6]) * z) + cload(&v->rt[7]);
-    const double cz = ((cload(&v->rt[8]) * x + cload(&v->rt[9]) * y) + cload(&v->rt[10]) * z) + cload(&v->rt[11]);
-    // vtkTransform::TransformVector with Matrix4K (RD.cxx:175): no translation
-    const double dx = (cload(&v->k[0]) * cx + cload(&v->k[1]) * cy) + cload(&v->k[2]) * cz;
-    const double dy = (cload(&v->k[3]) * cx + cload(&v->k[4]) * cy) + cload(&v->k[5]) * cz;
-    const double dz = (cload(&v->k[6]) * cx + cload(&v->k[7]) * cy) + cload(&v->k[8]) * cz;
+    // The pixel only has to be the reference's pixel: the homogeneous coordinates come from the rows of K3*[R|T] (nine
+    // FMAs instead of the reference's 33 operations), and the pixel they select is taken when it provably is the
+    // reference's (round_to_pixel_near with this view's margin for this chunk of vertices); whatever is not decided
+    // that way goes through the reference's own expression below.
+    const double ax = __builtin_fma(cload(&v->p[0]), x, __builtin_fma(cload(&v->p[1]), y, __builtin_fma(cload(&v->p[2]), z, cload(&v->p[3]))));
+    const double ay = __builtin_fma(cload(&v->p[4]), x, __builtin_fma(cload(&v->p[5]), y, __builtin_fma(cload(&v->p[6]), z, cload(&v->p[7]))));
+    const double az = __builtin_fma(cload(&v->p[8]), x, __builtin_fma(cload(&v->p[9]), y, __builtin_fma(cload(&v->p[10]), z, cload(&v->p[11]))));
     uchar4 out = make_uchar4(0, 0, 0, 0);
-    int px, py;
-    const FastQuotient by_dz(dz);
-    if (by_dz.round_to_pixel(dx, dz, px) && by_dz.round_to_pixel(dy, dz, py) &&   // RD.cxx:177-181
-        px >= 0 && py >= 0 && px < W && py < H) {                                 // MC.cxx:158-163
+    int px = 0, py = 0;
+    const FastQuotient by_az(az);
+    bool have_pixel = by_az.round_to_pixel_near(ax, cload(&margins[m].ex), px) && by_az.round_to_pixel_near(ay, cload(&margins[m].ey), py);
+    bool is_pixel = have_pixel;
+    if (!have_pixel) {
+      // vtkTransform::TransformPoint with MatrixTR (RD.cxx:173): M[i][0]*x + M[i][1]*y + M[i][2]*z + M[i][3], left to right
+      const double cx = ((cload(&v->rt[0]) * x + cload(&v->rt[1]) * y) + cload(&v->rt[2]) * z) + cload(&v->rt[3]);
+      const double cy = ((cload(&v->rt[4]) * x + cload(&v->rt[5]) * y) + cload(&v->rt[6]) * z) + cload(&v->rt[7]);
+      const double cz = ((cload(&v->rt[8]) * x + cload(&v->rt[9]) * y) + cload(&v->rt[10]) * z) + cload(&v->rt[11]);
+      // vtkTransform::TransformVector with Matrix4K (RD.cxx:175): no translation
+      const double dx = (cload(&v->k[0]) * cx + cload(&v->k[1]) * cy) + cload(&v->k[2]) * cz;
+      const double dy = (cload(&v->k[3]) * cx + cload(&v->k[4]) * cy) + cload(&v->k[5]) * cz;
+      const double dz = (cload(&v->k[6]) * cx + cload(&v->k[7]) * cy) + cload(&v->k[8]) * cz;
+      const FastQuotient by_dz(dz);
+      is_pixel = by_dz.round_to_pixel(dx, dz, px) && by_dz.round_to_pixel(dy, dz, py);   // RD.cxx:177-181
+    }
+    if (is_pixel && px >= 0 && py >= 0 && px < W && py < H) {                            // MC.cxx:158-163
       const uchar4 c = cload(&v->color)[(int64_t)py * W + px];      // RD.cxx:106-108 (row flip done at upload)
       out = make_uchar4(c.x, c.y, c.z, 1);
       cnt += 1;
@@ -376,6 +414,8 @@ struct dmi_color_context {
   uint8_t *d_mean = nullptr, *d_median = nullptr;
   int32_t *d_count = nullptr;
   MedianSeed *d_seeds = nullptr;  // per vertex of a chunk: what the projection pass hands the histogram-median pass
+  ViewMargin *d_margins = nullptr;  // per view, for the chunk being processed
+  size_t margins_capacity = 0;
   // processing order of a chunk: Z-order keys and vertex indices (in / out of the radix sort), its temporary storage,
   // the chunk's bounding box
   uint32_t *d_keys = nullptr, *d_keys_sorted = nullptr, *d_index = nullptr, *d_perm = nullptr;
@@ -470,7 +510,7 @@ void dmi_color_destroy(dmi_color_context *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (ColorBatch &b : c->batches) (void)hipFree(b.d_rgba);
   for (void *p : {(void *)c->d_views, (void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median,
-                  (void *)c->d_count, (void *)c->d_seeds, (void *)c->d_stage, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index,
+                  (void *)c->d_count, (void *)c->d_seeds, (void *)c->d_margins, (void *)c->d_stage, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index,
                   (void *)c->d_perm, c->d_sort_temp, (void *)c->d_box})
     if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -533,6 +573,16 @@ int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const doubl
     for (int r = 0; r < 3; ++r)
       for (int q = 0; q < 3; ++q) v.k[3 * r + q] = K4[16 * (size_t)m + 4 * r + q];
     v.color = b.d_rgba + (size_t)m * npix;
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 4; ++q) {
+        double sum = 0.0, mag = 0.0;
+        for (int t = 0; t < 3; ++t) {
+          sum += v.k[3 * r + t] * v.rt[4 * t + q];
+          mag += std::fabs(v.k[3 * r + t]) * std::fabs(v.rt[4 * t + q]);
+        }
+        v.p[4 * r + q] = sum;
+        v.mag[4 * r + q] = mag;
+      }
     c->h_views.push_back(v);
   }
   c->views_dirty = true;
@@ -570,6 +620,9 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     c->d_views = nullptr;
     c->d_views_capacity = 0;
     DMI_COLOR_HIP(c, hipMalloc(&c->d_views, n_views * sizeof(ColorView)));
+    if (c->d_margins) (void)hipFree(c->d_margins);
+    c->d_margins = nullptr;
+    DMI_COLOR_HIP(c, hipMalloc(&c->d_margins, n_views * sizeof(ViewMargin)));
     c->d_views_capacity = n_views;
     c->views_dirty = true;
   }
@@ -578,6 +631,7 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
     c->views_dirty = false;
   }
+  std::vector<ViewMargin> margins;
   // vertices per chunk: the scratch table [view][vertex] stays within its budget
   const size_t budget = c->scratch_budget;
   size_t chunk = std::max<size_t>(256, budget / (n_views * sizeof(uchar4)) / 256 * 256);
@@ -614,6 +668,29 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     const int64_t nv = std::min<int64_t>((int64_t)chunk, n_points - v0);
     const unsigned blocks = (unsigned)((nv + 255) / 256);
     DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_points, points + 3 * v0, (size_t)nv * 24, hipMemcpyHostToDevice, c->stream));
+    {
+      // the chunk's largest coordinate magnitudes bound the error of the pixel selection's shortcut (ViewMargin); a
+      // coordinate that is not finite makes the margins infinite: every pair then takes the reference's expression
+      double pmax[4] = {0.0, 0.0, 0.0, 1.0};
+      for (int64_t i = 0; i < nv; ++i)
+        for (int a = 0; a < 3; ++a) {
+          const double m = std::fabs(points[3 * (v0 + i) + a]);
+          if (!(m <= pmax[a])) pmax[a] = m == m ? m : HUGE_VAL;
+        }
+      margins.resize(n_views);
+      for (size_t m = 0; m < n_views; ++m) {
+        double e[3];
+        for (int r = 0; r < 3; ++r) {
+          double sum = 0.0;
+          for (int q = 0; q < 4; ++q) sum += c->h_views[m].mag[4 * r + q] * pmax[q];
+          e[r] = sum * 0x1p-47 * (1.0 + 0x1p-20);
+        }
+        margins[m].ex = e[0] + 65537.0 * e[2];
+        margins[m].ey = e[1] + 65537.0 * e[2];
+      }
+      // pageable source: the copy has left the host buffer when the call returns
+      DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_margins, margins.data(), n_views * sizeof(ViewMargin), hipMemcpyHostToDevice, c->stream));
+    }
     DMI_COLOR_HIP(c, hipEventRecord(c->ev0, c->stream));
     const uint32_t *perm = nullptr;
     if (c->reorder) {
@@ -634,13 +711,13 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
 #endif
     if (histogram_medians) {
       hipLaunchKernelGGL(project_color_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds);
+                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
       DMI_COLOR_HIP(c, hipGetLastError());
       hipLaunchKernelGGL(median_low_nibble_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
                          c->d_count, c->d_seeds, c->d_median);
     } else {
       hipLaunchKernelGGL(project_color_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds);
+                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
       DMI_COLOR_HIP(c, hipGetLastError());
       hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
                          c->d_count, c->d_median);
