@@ -426,12 +426,15 @@ def main():
     b_alg = algorithmic_bytes(n_vox, maps_per_gpu, W, H, grid_bytes, depth_bytes)
     achieved_gbps = b_alg / (main_ms * 1e-3) / 1e9
     traffic = None
+    issue_counts = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             rec = json.load(open(pmc_path)).get(f"{args.workload}:{args.scene}:{args.grid_dtype}")
             if rec:
                 traffic = rec["hbm_bytes_per_launch"]
+                if rec.get("valu_insts"):
+                    issue_counts = rec
         except Exception:
             traffic = None
     proj_per_launch = float(n_vox) * maps_per_gpu
@@ -492,6 +495,19 @@ def main():
                     "the default path proves most (brick, view) pairs uniform and skips their projections",
         },
         "brick_classes": hist,
+        # what actually bounds the default path: instruction issue.  Counts per launch from the committed PMC passes
+        # (profiles/pmc_traffic.json, same workload), time from this run.  A SIMD issues one fp64-rate vector instruction
+        # per 4 cycles; a CU's four SIMDs share one scalar unit (one SALU / branch / SMEM instruction per cycle).
+        "roofline_issue": None if not issue_counts else {
+            "bound": "vector_issue",
+            "vector_wave_instructions": issue_counts["valu_insts"],
+            "scalar_wave_instructions": (issue_counts.get("salu_insts") or 0) + (issue_counts.get("branch_insts") or 0) + (issue_counts.get("smem_insts") or 0),
+            "vector_floor_ms": issue_counts["valu_insts"] * 4 / (1024 * 2.4e9) * 1e3,
+            "scalar_floor_ms": ((issue_counts.get("salu_insts") or 0) + (issue_counts.get("branch_insts") or 0) + (issue_counts.get("smem_insts") or 0)) / (256 * 2.4e9) * 1e3,
+            "kernel_ms": main_ms,
+            "frac": issue_counts["valu_insts"] * 4 / (1024 * 2.4e9) * 1e3 / main_ms,
+            "source": issue_counts.get("tag"),
+        },
         "box_state": {"fp64_vector_tflops_now": fp64_now, "peak": FP64_VECTOR_PEAK_TFLOPS,
                       "note": "dmi_fp64_probe right after the timed steps: independent v_fma_f64 chains on every SIMD for 20 ms"},
     }

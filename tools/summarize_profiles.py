@@ -138,7 +138,10 @@ def main():
                 path = os.path.join(pdir, "pmc_traffic.json")
                 db = json.load(open(path)) if os.path.exists(path) else {}
                 db[args.key] = {"hbm_bytes_per_launch": traffic, "fetch_kib": fetch, "write_kib": write,
-                                "fetch_scale": args.fetch_scale or 2.0, "tag": args.tag, "kernel": k[:120]}
+                                "fetch_scale": args.fetch_scale or 2.0, "tag": args.tag, "kernel": k[:120],
+                                # wave-instructions per launch (bench.py's roofline_issue object)
+                                "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"),
+                                "branch_insts": c.get("SQ_INSTS_BRANCH"), "smem_insts": c.get("SQ_INSTS_SMEM")}
                 json.dump(db, open(path, "w"), indent=1, sort_keys=True)
         lines.append("")
     with open(os.path.join(pdir, f"{args.tag}_summary.md"), "w") as f:
