@@ -21,7 +21,11 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s
   roofline_valu the binding roof of the per-voxel path: fp64 VALU issue (DESIGN.md "Roofline"), measured on
                 the same workload with brick classes switched off (every projection computed)
+  roofline_issue what bounds the default path: vector / scalar instruction issue -- counts per launch from the committed
+                PMC passes of the same workload (profiles/pmc_traffic.json) against this run's kernel time
+  box_state     the fp64 vector rate the box sustains on bare FMAs right after the timed steps (dmi_fp64_probe)
   ablation      the same fusion without brick classes / with workgroups in spatial order
+  end_to_end, cell_to_point, coloration   the PCIe-inclusive contract figures against their floor; the passes either side
   cpu_baseline  the CPU oracle (restated reference arithmetic) timed on this host's cores on a
                 bounded sample of the same workload (N = 1 only)
 """
