@@ -193,7 +193,8 @@ constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw
 // (cu:177) is proven from h.z -+ errz, and whatever is not proven goes through the exact expression as before.  c.z
 // -- what enters the ray potential -- is exact in every instantiation.  Pinhole views run through the same code: for
 // them h.z restates c.z and errz is 0.
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false, bool GENK = false>
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false, bool GENK = false,
+          bool STAY = (WX * WY == 1)>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
   // The argument block is read where it is needed, straight from the kernarg segment (scalar loads), instead of through
@@ -242,7 +243,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // workgroup per brick, a tenth of the wave slots sat empty between a workgroup's end and its successor's arrival, and
   // the XCDs finished up to 0.46 ms apart (profiles/r03p_wg_timeline_*.json).  Every wave reaches the exit: the counters
   // only grow, and a share is used up once its counter passes its size.
-  constexpr bool PERSIST = WX * WY == 1;
+  // STAY = false: one workgroup per brick, as multi-wave workgroups always run.  Launches of few views take that form
+  // too (launch_shape): a brick then is 10-20 us of work, and the 3-4 us a persistent wave spends between two bricks --
+  // the counter's round trip, the dependent loads of the prologue -- cost more than the dispatcher's gaps (256^3 x 64
+  // views: 0.31 against 0.37 ms; 384^3 x 128 the other way round, 1.69 against 1.42; profiles/r04u_exp_persistent_by_size.json)
+  constexpr bool PERSIST = STAY && WX * WY == 1;
   const int b = blockIdx.x;
   int q = b >> 3;   // the q-th brick of an XCD's share
   int helped = 0;   // PERSIST: how many XCDs' shares this workgroup has seen the end of
@@ -758,6 +763,8 @@ __global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double 
   table[4 * k + 3] = 0.0;
 }
 
+constexpr int kPersistentMinViews = 96;  // below: one workgroup per brick (fuse_tile_kernel, STAY)
+
 // workgroups of `kernel` the device holds at once: what the persistent launch asks for (more would only queue up behind
 // the ones that never leave before the work is done; 8192 instead of 5120 cost 1.5 %, profiles/r03_exp_v_blocks.json)
 template <typename Kernel>
@@ -782,7 +789,16 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   const dim3 block(64 * WX * WY);
   const auto counted = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>;
   const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>;
-  if (WX * WY == 1) {  // persistent one-wave workgroups: as many as the chip holds (asked once per instantiation)
+  if constexpr (WX * WY == 1) {
+    // few views per brick (and classes to make most of them cheap): one workgroup per brick, see the kernel
+    if (a.n_maps < kPersistentMinViews && !(cfg.variant & VAR_NO_BRICK_CLASSES)) {
+      if (cfg.count_hits)
+        hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
+      else
+        hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
+      return hipGetLastError();
+    }
+    // persistent one-wave workgroups: as many as the chip holds (asked once per instantiation)
     static const unsigned resident[2] = {resident_workgroups(plain, 64), resident_workgroups(counted, 64)};
     blocks = std::min(blocks, resident[cfg.count_hits ? 1 : 0]);
   }
