@@ -14,7 +14,7 @@ from helpers import bits_equal, oracle_params_from_scene
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(seed, medium=False):
+def _random_case(seed, medium=False, many_views=False):
     rng = np.random.default_rng(seed)
     dims = tuple(int(v) for v in (rng.integers(140, 215, size=3) if medium else rng.integers(5, 45, size=3)))
     extent = rng.uniform(0.5, 3.0, size=3)
@@ -35,6 +35,8 @@ def _random_case(seed, medium=False):
     grid = scene.GridDesc(dims, origin, spacing, gm)
     n = int(rng.integers(9, 20)) if medium else int(rng.integers(1, 9))
     W, H = (int(rng.integers(200, 400)), int(rng.integers(150, 300))) if medium else (int(rng.integers(8, 90)), int(rng.integers(6, 70)))
+    if many_views:  # launches of 96 views and more run persistent workgroups (fusion_tile.hip: kPersistentMinViews)
+        n, W, H = int(rng.integers(96, 130)), int(rng.integers(60, 120)), int(rng.integers(40, 90))
     radius = float(rng.choice([0.3, 1.2, 3.0, 6.0]))
     views = scene.make_views(n, W, H, seed=int(rng.integers(1 << 30)), dense=bool(rng.integers(0, 2)), radius=radius,
                              focal_scale=float(rng.uniform(0.4, 1.5)))
@@ -101,6 +103,22 @@ def test_random_medium_scenes_bit_exact(seed):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        n_threads=oracle.max_threads())
     for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_NO_BRICK_CLASSES, False), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False)):
+        out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
+        assert bits_equal(out, want), (seed, variant, count_hits)
+        if count_hits:
+            assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w), (seed, variant)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_many_view_scenes_bit_exact(seed):
+    """Medium-size grids with 96..129 small views: the persistent form of the kernel (launches of fewer views run one
+    workgroup per brick), more bricks than workgroups, every kind of K and grid the generator knows: the whole grid against
+    the oracle, bit for bit."""
+    grid, rp, views = _random_case(2000 + seed, medium=True, many_views=True)
+    with np.errstate(all="ignore"):
+        want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                       n_threads=oracle.max_threads())
+    for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False)):
         out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
         assert bits_equal(out, want), (seed, variant, count_hits)
         if count_hits:
