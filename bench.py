@@ -502,16 +502,7 @@ def main():
         # what actually bounds the default path: instruction issue.  Counts per launch from the committed PMC passes
         # (profiles/pmc_traffic.json, same workload), time from this run.  A SIMD issues one fp64-rate vector instruction
         # per 4 cycles; a CU's four SIMDs share one scalar unit (one SALU / branch / SMEM instruction per cycle).
-        "roofline_issue": None if not issue_counts else {
-            "bound": "vector_issue",
-            "vector_wave_instructions": issue_counts["valu_insts"],
-            "scalar_wave_instructions": (issue_counts.get("salu_insts") or 0) + (issue_counts.get("branch_insts") or 0) + (issue_counts.get("smem_insts") or 0),
-            "vector_floor_ms": issue_counts["valu_insts"] * 4 / (1024 * 2.4e9) * 1e3,
-            "scalar_floor_ms": ((issue_counts.get("salu_insts") or 0) + (issue_counts.get("branch_insts") or 0) + (issue_counts.get("smem_insts") or 0)) / (256 * 2.4e9) * 1e3,
-            "kernel_ms": main_ms,
-            "frac": issue_counts["valu_insts"] * 4 / (1024 * 2.4e9) * 1e3 / main_ms,
-            "source": issue_counts.get("tag"),
-        },
+        "roofline_issue": issue_roofline(issue_counts, main_ms),
         "box_state": {"fp64_vector_tflops_now": fp64_now, "peak": FP64_VECTOR_PEAK_TFLOPS,
                       "note": "dmi_fp64_probe right after the timed steps: independent v_fma_f64 chains on every SIMD for 20 ms"},
     }
@@ -532,6 +523,22 @@ def main():
         out["cpu_baseline"] = cpu_baseline(grid, ray, views, args.cpu_seconds)
     ctx.close()
     emit(out)
+
+
+def issue_roofline(counts, kernel_ms):
+    """Instruction-issue floors of the fusion launch.  A SIMD issues one fp64-rate vector instruction per 4 cycles; a
+    CU's four SIMDs share one scalar unit (one scalar-side instruction per cycle: SALU, branch, SMEM -- counted
+    together, which is the pessimistic reading of the issue rules).  `frac` = the larger floor / the kernel's time."""
+    if not counts:
+        return None
+    vector = counts["valu_insts"]
+    scalar = (counts.get("salu_insts") or 0) + (counts.get("branch_insts") or 0) + (counts.get("smem_insts") or 0)
+    vector_ms = vector * 4 / (1024 * 2.4e9) * 1e3
+    scalar_ms = scalar / (256 * 2.4e9) * 1e3
+    return {"bound": "vector_issue" if vector_ms >= scalar_ms else "scalar_issue",
+            "vector_wave_instructions": vector, "scalar_wave_instructions": scalar,
+            "vector_floor_ms": vector_ms, "scalar_floor_ms": scalar_ms, "kernel_ms": kernel_ms,
+            "frac": max(vector_ms, scalar_ms) / kernel_ms, "source": counts.get("tag")}
 
 
 # ---- N > 1 -------------------------------------------------------------------------------------------------------
