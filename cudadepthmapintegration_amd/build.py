@@ -75,9 +75,35 @@ if LIB_OVERRIDE:
     LIB_PATH = os.path.abspath(LIB_OVERRIDE)
 
 
+def source_digest(files=None) -> str:
+    """sha256 over the compiler flags and the contents of the sources and headers: what the library was built FROM.
+    Written next to the library (libdmi_hip.so.digest) by build(); a library whose digest matches is up to date whatever
+    the files' timestamps say (a checkout, a copy to another machine), one whose digest differs is not."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(" ".join(COMMON_FLAGS + HIP_FLAGS).encode())
+    if files is None:
+        files = [os.path.join(CSRC, s) for s in _sources()] + _headers() + [os.path.join(CSRC, "host", "recon_cli_main.cpp")]
+    for f in files:
+        h.update(os.path.relpath(f, CSRC).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _digest_path() -> str:
+    return LIB_PATH + ".digest"
+
+
 def needs_build() -> bool:
     if LIB_OVERRIDE:
         return False
+    if not os.path.exists(LIB_PATH):
+        return True
+    if os.path.exists(_digest_path()):
+        with open(_digest_path()) as fh:
+            return fh.read().strip() != source_digest()
     deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
     return _stale(LIB_PATH, deps)
 
@@ -144,6 +170,22 @@ def audit_accumulator_registers(asm_text: str) -> tuple[int, list[str]]:
     return checked, bad
 
 
+def _audit_digest() -> str:
+    return source_digest([os.path.join(CSRC, "fusion_tile.hip")] + _headers())
+
+
+def audit_is_current() -> bool:
+    """The audit record of this object directory is about the tiled kernel's present source and flags."""
+    import json
+
+    marker = os.path.join(OBJ_DIR, "acc_audit.json")
+    try:
+        with open(marker) as fh:
+            return json.load(fh).get("digest") == _audit_digest()
+    except (OSError, ValueError):
+        return False
+
+
 def run_accumulator_audit(verbose: bool = False) -> int:
     """Compile fusion_tile.hip to gfx950 assembly with the build's flags and audit it; raises on any violation.
     Runs inside build() whenever fusion_tile.hip is recompiled, and as a non-GPU test."""
@@ -166,7 +208,7 @@ def run_accumulator_audit(verbose: bool = False) -> int:
     version = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
     os.makedirs(OBJ_DIR, exist_ok=True)
     with open(os.path.join(OBJ_DIR, "acc_audit.json"), "w") as fh:
-        json.dump({"instantiations": checked, "violations": 0, "hipcc": version[:2]}, fh)
+        json.dump({"instantiations": checked, "violations": 0, "hipcc": version[:2], "digest": _audit_digest()}, fh)
     if verbose:
         print(f"accumulator audit: {checked} fuse_tile_kernel instantiations clean ({version[0] if version else 'hipcc'})", flush=True)
     return checked
@@ -180,7 +222,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = _headers()
-    audit_marker = os.path.join(OBJ_DIR, "acc_audit.json")
+    digest = source_digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(_digest_path()):
+        # the contents changed but perhaps not the timestamps' order (files restored with old dates): trust no object
+        srcs = [os.path.join(CSRC, s) for s in _sources()]
+        if not any(_stale(_obj(s), [p] + headers) for s, p in zip(_sources(), srcs)):
+            force = True
 
     def compile_one(src: str):
         path = os.path.join(CSRC, src)
@@ -195,7 +242,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def audit_if_needed(_):
         # same staleness rule as the object: a recompiled tiled kernel is a re-audited one
-        if force or _stale(audit_marker, [os.path.join(CSRC, "fusion_tile.hip")] + headers):
+        if force or not audit_is_current():
             run_accumulator_audit(verbose)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -207,6 +254,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     build_cli(verbose)
+    with open(_digest_path(), "w") as fh:
+        fh.write(digest + "\n")
     return LIB_PATH
 
 

@@ -68,18 +68,33 @@ def test_product_package_never_touches_the_oracle():
 def test_accumulator_register_audit_covers_this_build():
     """fusion_tile.hip keeps its running sums in VGPRs the compiler only knows as clobbers (fusion_tile_acc.inc): a
     toolchain that allocates one of them would corrupt sums silently.  build() audits the gfx950 assembly whenever the
-    kernel is recompiled; here: the audit record exists, is not older than the kernel source, and saw every shape."""
+    kernel is recompiled; here: the audit record exists, is about the kernel's present source and flags (content digest), and saw every shape."""
     import json
 
     from cudadepthmapintegration_amd import build
 
     capi.load()
     marker = os.path.join(build.OBJ_DIR, "acc_audit.json")
-    src = os.path.join(build.CSRC, "fusion_tile.hip")
-    if not os.path.exists(marker) or os.path.getmtime(marker) < os.path.getmtime(src):
-        build.run_accumulator_audit()           # e.g. a prebuilt .so copied without build/: audit now (hipcc -S, ~30 s)
+    if not build.audit_is_current():
+        build.run_accumulator_audit()           # e.g. a prebuilt .so copied without build/: audit now (hipcc -S, minutes)
     rec = json.load(open(marker))
-    assert rec["violations"] == 0 and rec["instantiations"] >= 30
+    assert rec["violations"] == 0 and rec["instantiations"] >= 30 and rec["digest"]
+
+
+def test_library_freshness_is_decided_by_content_not_timestamps():
+    """A checkout or a copy to another machine (the GPU box) changes timestamps, not contents: the library built from
+    these sources must not be rebuilt there (build.source_digest, libdmi_hip.so.digest)."""
+    from cudadepthmapintegration_amd import build
+
+    capi.load()
+    assert os.path.exists(build.LIB_PATH + ".digest") and not build.needs_build()
+    src = os.path.join(build.CSRC, "grid_post.hip")
+    st = os.stat(src)
+    try:
+        os.utime(src, None)  # "newer than the library"
+        assert not build.needs_build()
+    finally:
+        os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
 
 
 def test_accumulator_register_audit_flags_a_violation():
