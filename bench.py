@@ -21,8 +21,9 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s
   roofline_valu the binding roof of the per-voxel path: fp64 VALU issue (DESIGN.md "Roofline"), measured on
                 the same workload with brick classes switched off (every projection computed)
-  roofline_issue what bounds the default path: vector / scalar instruction issue -- counts per launch from the committed
-                PMC passes of the same workload (profiles/pmc_traffic.json) against this run's kernel time
+  roofline_issue what bounds the default path: vector / scalar instruction issue -- vector-pipe busy cycles and SALU
+                counts per launch from the committed PMC passes of the same workload (profiles/pmc_traffic.json)
+                against this run's kernel time
   box_state     the fp64 vector rate the box sustains on bare FMAs right after the timed steps (dmi_fp64_probe)
   ablation      the same fusion without brick classes / with workgroups in spatial order
   end_to_end, cell_to_point, coloration   the PCIe-inclusive contract figures against their floor; the passes either side
@@ -499,9 +500,7 @@ def main():
                     "the default path proves most (brick, view) pairs uniform and skips their projections",
         },
         "brick_classes": hist,
-        # what actually bounds the default path: instruction issue.  Counts per launch from the committed PMC passes
-        # (profiles/pmc_traffic.json, same workload), time from this run.  A SIMD issues one fp64-rate vector instruction
-        # per 4 cycles; a CU's four SIMDs share one scalar unit (one SALU / branch / SMEM instruction per cycle).
+        # what actually bounds the default path: instruction issue (issue_roofline below)
         "roofline_issue": issue_roofline(issue_counts, main_ms),
         "box_state": {"fp64_vector_tflops_now": fp64_now, "peak": FP64_VECTOR_PEAK_TFLOPS,
                       "note": "dmi_fp64_probe right after the timed steps: independent v_fma_f64 chains on every SIMD for 20 ms"},
@@ -526,17 +525,21 @@ def main():
 
 
 def issue_roofline(counts, kernel_ms):
-    """Instruction-issue floors of the fusion launch.  A SIMD issues one fp64-rate vector instruction per 4 cycles; a
-    CU's four SIMDs share one scalar unit (one scalar-side instruction per cycle: SALU, branch, SMEM -- counted
-    together, which is the pessimistic reading of the issue rules).  `frac` = the larger floor / the kernel's time."""
+    """Instruction-issue floors of the fusion launch, from the committed PMC passes of the same workload.  Vector: the
+    quad-cycles the vector pipes spent executing (SQ_ACTIVE_INST_VALU: a quarter-rate v_rcp_f64 counts four times; without
+    that counter, one quad-cycle per vector instruction) spread over 1024 SIMDs at 2.4 GHz.  Scalar: one SALU instruction
+    per cycle per CU (four SIMDs share the scalar unit); branches and scalar loads have issue ports of their own and are
+    reported, not added.  `frac` = the larger floor / the kernel's time of THIS run."""
     if not counts:
         return None
     vector = counts["valu_insts"]
-    scalar = (counts.get("salu_insts") or 0) + (counts.get("branch_insts") or 0) + (counts.get("smem_insts") or 0)
-    vector_ms = vector * 4 / (1024 * 2.4e9) * 1e3
-    scalar_ms = scalar / (256 * 2.4e9) * 1e3
+    busy = counts.get("valu_active_quad_cycles") or vector
+    salu = counts.get("salu_insts") or 0
+    vector_ms = busy * 4 / (1024 * 2.4e9) * 1e3
+    scalar_ms = salu / (256 * 2.4e9) * 1e3
     return {"bound": "vector_issue" if vector_ms >= scalar_ms else "scalar_issue",
-            "vector_wave_instructions": vector, "scalar_wave_instructions": scalar,
+            "vector_wave_instructions": vector, "vector_busy_quad_cycles": busy, "salu_wave_instructions": salu,
+            "branch_wave_instructions": counts.get("branch_insts"), "smem_wave_instructions": counts.get("smem_insts"),
             "vector_floor_ms": vector_ms, "scalar_floor_ms": scalar_ms, "kernel_ms": kernel_ms,
             "frac": max(vector_ms, scalar_ms) / kernel_ms, "source": counts.get("tag")}
 

@@ -141,7 +141,9 @@ def main():
                                 "fetch_scale": args.fetch_scale or 2.0, "tag": args.tag, "kernel": k[:120],
                                 # wave-instructions per launch (bench.py's roofline_issue object)
                                 "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"),
-                                "branch_insts": c.get("SQ_INSTS_BRANCH"), "smem_insts": c.get("SQ_INSTS_SMEM")}
+                                "branch_insts": c.get("SQ_INSTS_BRANCH"), "smem_insts": c.get("SQ_INSTS_SMEM"),
+                                # quad-cycles the vector pipes spent executing (a quarter-rate instruction counts four times)
+                                "valu_active_quad_cycles": c.get("SQ_ACTIVE_INST_VALU")}
                 json.dump(db, open(path, "w"), indent=1, sort_keys=True)
         lines.append("")
     with open(os.path.join(pdir, f"{args.tag}_summary.md"), "w") as f:
