@@ -117,3 +117,16 @@ def test_accumulator_register_audit_flags_a_violation():
     assert n == 1 and len(bad) == 1 and "SCC" in bad[0]
     fine = ok.replace("\ts_endpgm", masked + "\ts_cmp_eq_u64 s[0:1], -1\n\ts_cbranch_scc1 .LBB0_1\n.LBB0_1:\n\ts_endpgm")
     assert build.audit_accumulator_registers(fine) == (1, [])
+
+
+def test_issue_roofline_takes_the_larger_floor():
+    """bench.py's `roofline_issue`: vector floor from the pipes' busy quad-cycles (falling back to the instruction count),
+    scalar floor from SALU alone, `frac` against the run's kernel time."""
+    import bench
+
+    assert bench.issue_roofline(None, 5.0) is None
+    r = bench.issue_roofline({"valu_insts": 1024 * 2.4e6, "salu_insts": 256 * 2.4e6, "tag": "t"}, 8.0)
+    assert r["bound"] == "vector_issue" and abs(r["vector_floor_ms"] - 4.0) < 1e-9 and abs(r["scalar_floor_ms"] - 1.0) < 1e-9
+    assert abs(r["frac"] - 0.5) < 1e-9 and r["source"] == "t"
+    r = bench.issue_roofline({"valu_insts": 1024 * 2.4e6, "valu_active_quad_cycles": 1024 * 3.0e6, "salu_insts": 256 * 2.4e6 * 6}, 8.0)
+    assert abs(r["vector_floor_ms"] - 5.0) < 1e-9 and r["bound"] == "scalar_issue" and abs(r["frac"] - 0.75) < 1e-9
