@@ -37,11 +37,11 @@ __device__ __forceinline__ Quad<GridT> load_quad(const GridT *__restrict__ layer
 // Block = 64 x 4 points in (i, j); every thread produces KZ point layers along k from KZ + 1 cell layers, all
 // loaded before the first use (KZ + 1 independent loads of 4 values in flight per thread), so each cell value is
 // requested 4 (1 + 1/KZ) times -- served by L1/L2 -- instead of 8.
-template <typename GridT, int KZ>
-__global__ __launch_bounds__(256) void cell_to_point_kernel(const GridT *__restrict__ cells, double *__restrict__ points,
+template <typename GridT, int KZ, int BY>
+__global__ __launch_bounds__(64 * BY) void cell_to_point_kernel(const GridT *__restrict__ cells, double *__restrict__ points,
                                                             int nx, int ny, int nz) {
   const int i = blockIdx.x * 64 + threadIdx.x;  // point indices: 0..nx, 0..ny, 0..nz
-  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int j = blockIdx.y * BY + threadIdx.y;
   const int k0 = blockIdx.z * KZ;
   if (i > nx || j > ny) return;
   const bool xm = i >= 1, xp = i < nx, ym = j >= 1, yp = j < ny;
@@ -77,31 +77,33 @@ __global__ __launch_bounds__(256) void cell_to_point_kernel(const GridT *__restr
       if (xp && ym && zp) c += w * (double)here.pm;
       if (xp && ym && zm) c += w * (double)below.pm;
       if (xp && yp && zm) c += w * (double)below.pp;
-      points[((int64_t)k * (ny + 1) + j) * prow + i] = c;
+      // written once and not read again by this kernel: a non-temporal store (5-6 % off the pass, same box, A/B:
+      // profiles/r05i_cell_to_point_stores.json)
+      __builtin_nontemporal_store(c, &points[((int64_t)k * (ny + 1) + j) * prow + i]);
     }
   }
 }
 
-template <typename GridT, int KZ>
+template <typename GridT, int KZ, int BY>
 void launch_kz(const GridT *cells, double *points, int nx, int ny, int nz, hipStream_t stream) {
-  const dim3 block(64, 4);
-  const dim3 grid((unsigned)((nx + 1 + 63) / 64), (unsigned)((ny + 1 + 3) / 4), (unsigned)((nz + 1 + KZ - 1) / KZ));
-  hipLaunchKernelGGL((cell_to_point_kernel<GridT, KZ>), grid, block, 0, stream, cells, points, nx, ny, nz);
+  const dim3 block(64, BY);
+  const dim3 grid((unsigned)((nx + 1 + 63) / 64), (unsigned)((ny + 1 + BY - 1) / BY), (unsigned)((nz + 1 + KZ - 1) / KZ));
+  hipLaunchKernelGGL((cell_to_point_kernel<GridT, KZ, BY>), grid, block, 0, stream, cells, points, nx, ny, nz);
 }
 
 template <typename GridT>
 void launch_typed(const GridT *cells, double *points, int nx, int ny, int nz, hipStream_t stream) {
-  int kz = 8;
 #ifdef DMI_TUNING
-  if (const char *e = getenv("DMI_C2P_KZ")) kz = atoi(e);  // tuning experiments (tools/gpu_c2p_tune.py)
+  // tuning experiments (tools/gpu_c2p_tune.py): column height and block height from the environment
+  const char *e = getenv("DMI_C2P_KZ"), *f = getenv("DMI_C2P_BY");
+  const int kz = e ? atoi(e) : 8, by = f ? atoi(f) : 4;
+#define DMI_C2P_CASE(KZ_, BY_) \
+  if (kz == KZ_ && by == BY_) return launch_kz<GridT, KZ_, BY_>(cells, points, nx, ny, nz, stream);
+  DMI_C2P_CASE(1, 4) DMI_C2P_CASE(2, 4) DMI_C2P_CASE(4, 4) DMI_C2P_CASE(16, 4)
+  DMI_C2P_CASE(4, 2) DMI_C2P_CASE(8, 2) DMI_C2P_CASE(16, 2) DMI_C2P_CASE(4, 8) DMI_C2P_CASE(8, 8) DMI_C2P_CASE(8, 1) DMI_C2P_CASE(16, 1)
+#undef DMI_C2P_CASE
 #endif
-  switch (kz) {
-    case 1: return launch_kz<GridT, 1>(cells, points, nx, ny, nz, stream);
-    case 2: return launch_kz<GridT, 2>(cells, points, nx, ny, nz, stream);
-    case 4: return launch_kz<GridT, 4>(cells, points, nx, ny, nz, stream);
-    case 16: return launch_kz<GridT, 16>(cells, points, nx, ny, nz, stream);
-    default: return launch_kz<GridT, 8>(cells, points, nx, ny, nz, stream);  // profiles/r01w_cell_to_point_tuning.json
-  }
+  return launch_kz<GridT, 8, 4>(cells, points, nx, ny, nz, stream);  // profiles/r01w_cell_to_point_tuning.json, r05i
 }
 
 }  // namespace

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times dmi_cell_to_point at 512^3 for the column heights the kernel is built with (DMI_C2P_KZ), f32 and f64 grids."""
+"""Times dmi_cell_to_point at 512^3 for the column heights x block heights a tuning build holds (DMI_C2P_KZ, DMI_C2P_BY),
+f32 and f64 grids.  Needs the tuning library: DMI_TUNING=1 at build time and in the environment of this script."""
 import json
 import os
 import sys
@@ -21,15 +22,16 @@ for dtype in ("f32", "f64"):
     torch.cuda.synchronize()
     ctx = capi.FusionContext(grid, ray, grid_dtype=dtype, external_grid=g.data_ptr())
     nbytes = (4 if dtype == "f32" else 8) * 512 ** 3 + 8 * 513 ** 3
-    for kz in sys.argv[1:] or ["1", "2", "4", "8", "16"]:
-        os.environ["DMI_C2P_KZ"] = kz
+    for spec in sys.argv[1:] or ["1x4", "2x4", "4x4", "8x4", "16x4", "4x2", "8x2", "16x2", "4x8", "8x8", "8x1", "16x1"]:
+        kz, by = spec.split("x")
+        os.environ["DMI_C2P_KZ"], os.environ["DMI_C2P_BY"] = kz, by
         ts = []
-        for _ in range(6):
+        for _ in range(21):
             ctx.cell_to_point()
             ctx.synchronize()
             ts.append(ctx.timings().last_cell_to_point_ms)
         ms = float(np.median(ts[1:]))
-        rec = {"grid": dtype, "kz": int(kz), "ms": ms, "GBps": nbytes / ms / 1e6}
+        rec = {"grid": dtype, "kz": int(kz), "by": int(by), "ms": ms, "min_ms": float(min(ts[1:])), "GBps": nbytes / ms / 1e6}
         res.append(rec)
         print(json.dumps(rec), flush=True)
     ctx.close()
