@@ -707,7 +707,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
       if (kk < kcount) {
-        grid[gid] = (GridT)acc_get<BASE, TK>(kk);
+        // non-temporal: a brick's 32-byte row pieces are written once and not read again by this launch; stored plainly they
+        // cost a line fill each (fabric reads 5.60 -> 5.20 GB, writes 0.72 -> 0.62 GB per launch at cfg 3, the time unchanged:
+        // profiles/r05k_exp_nt_grid_store.json, r05l_traffic_nt_grid_store.json)
+        __builtin_nontemporal_store((GridT)acc_get<BASE, TK>(kk), &grid[gid]);
         if (COUNT) ke->voxel_hits[gid] += nh[kk];
       }
       gid += plane;
