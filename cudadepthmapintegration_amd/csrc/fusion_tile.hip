@@ -707,10 +707,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
       if (kk < kcount) {
-        // non-temporal: a brick's 32-byte row pieces are written once and not read again by this launch; stored plainly they
-        // cost a line fill each (fabric reads 5.60 -> 5.20 GB, writes 0.72 -> 0.62 GB per launch at cfg 3, the time unchanged:
-        // profiles/r05k_exp_nt_grid_store.json, r05l_traffic_nt_grid_store.json)
-        __builtin_nontemporal_store((GridT)acc_get<BASE, TK>(kk), &grid[gid]);
+        // Persistent launches store NON-TEMPORALLY: their bricks end at unrelated times, the 32-byte row pieces of
+        // neighbouring bricks do not meet in the L2, and stored plainly each piece cost a line fill (fabric reads 5.60 ->
+        // 5.20 GB, writes 0.72 -> 0.62 GB per launch at cfg 3, the time unchanged or 0.5-0.9 % better:
+        // profiles/r05k_exp_nt_grid_store.json, r05l_traffic_nt_grid_store.json).  One workgroup per brick (few views,
+        // or multi-wave workgroups): neighbours are dispatched together and their pieces DO merge into whole lines --
+        // non-temporal stores made 1024^3 x 64 views 12-20 % slower (profiles/r05o_exp_nt_grid_store_by_size.json).
+        const GridT sum = (GridT)acc_get<BASE, TK>(kk);
+        if constexpr (PERSIST)
+          __builtin_nontemporal_store(sum, &grid[gid]);
+        else
+          grid[gid] = sum;
         if (COUNT) ke->voxel_hits[gid] += nh[kk];
       }
       gid += plane;
