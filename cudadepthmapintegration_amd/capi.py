@@ -27,6 +27,8 @@ VARIANT_KEEP_BEHIND_ADDS = 1024  # tiled kernel: perform +0.0 adds even when the
 VARIANT_NO_INTERIOR = 2048  # tiled kernel: keep the in-front / in-image tests for every mixed pair
 VARIANT_XCD_RUNS = 8192  # tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of an eighth of a level each
 VARIANT_ZMAJOR_SLOTS = 16384  # tiled kernel: super-bricks enumerated x, y, z (until r03h) instead of in Z-order
+VARIANT_PERSISTENT_ALWAYS = 32768  # tiled kernel: persistent one-wave workgroups whatever the number of views (default: from 96 on)
+VARIANT_PERSISTENT_NEVER = 65536  # tiled kernel: one workgroup per brick whatever the number of views
 VARIANT_FIXED_TILE_SHAPE = 4096  # tile-shape bits 0 mean shape 0 (tk16_w5) whatever the grid size; without it grids
                                  # below 512^3 pick tk8_w7 on their own
 VARIANT_SPATIAL_ORDER = 512  # tiled kernel: workgroups in spatial order instead of heaviest bricks first

@@ -208,7 +208,9 @@ enum VariantBits : int {
   VAR_KEEP_BEHIND_ADDS = 1024,  // tiled kernel: perform the +0.0 adds of BRICK_BEHIND pairs even when they cannot matter
   VAR_NO_INTERIOR = 2048,       // tiled kernel: full in-front / in-image tests for every mixed pair (never the INTERIOR variant)
   VAR_XCD_RUNS = 8192,          // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
-  VAR_ZMAJOR_SLOTS = 16384      // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
+  VAR_ZMAJOR_SLOTS = 16384,     // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
+  VAR_PERSISTENT_ALWAYS = 32768,  // tiled kernel, one-wave workgroups: persistent whatever the number of views (default: from 96 views on)
+  VAR_PERSISTENT_NEVER = 65536    // tiled kernel, one-wave workgroups: one workgroup per brick whatever the number of views
 };
 
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.

@@ -801,7 +801,10 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>;
   if constexpr (WX * WY == 1) {
     // few views per brick (and classes to make most of them cheap): one workgroup per brick, see the kernel
-    if (a.n_maps < kPersistentMinViews && !(cfg.variant & VAR_NO_BRICK_CLASSES)) {
+    const bool stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
+                      : (cfg.variant & VAR_PERSISTENT_NEVER) ? false
+                      : a.n_maps >= kPersistentMinViews || (cfg.variant & VAR_NO_BRICK_CLASSES);
+    if (!stay) {
       if (cfg.count_hits)
         hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
       else

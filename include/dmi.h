@@ -85,7 +85,8 @@ typedef struct dmi_options {
                              output; they expose every in-frustum / sentinel decision for parity) */
   int32_t kernel_variant; /* 0 = default; bit field of tuning / test switches (DESIGN.md "kernel_variant"):
                              1 exact division in the general kernel, 2 ignore K structure, 4|8 block shape of
-                             the general kernel, 16 never use the tiled kernel, 32..224 tile shape */
+                             the general kernel, 16 never use the tiled kernel, 32..224 tile shape, 256.. the tiled kernel's
+                             switches */
   int32_t z_first;        /* this context's grid is the z-slab [z_first, z_first + cell_dims[2]) of a taller grid
                              with the same origin and spacing: voxel k has the centre of global cell z_first + k
                              (cu:78-83 with the global index), so slabs fused on different GPUs are bit-identical

@@ -86,7 +86,8 @@ def test_random_scenes_bit_exact(seed):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        init_grid=init, n_threads=oracle.max_threads())
     for variant in (0, capi.VARIANT_FIXED_TILE_SHAPE, capi.VARIANT_NO_BRICK_CLASSES, 96, capi.VARIANT_FORCE_GENERAL,
-                    capi.VARIANT_NO_INTERIOR | capi.VARIANT_XCD_RUNS, capi.VARIANT_ZMAJOR_SLOTS):
+                    capi.VARIANT_NO_INTERIOR | capi.VARIANT_XCD_RUNS, capi.VARIANT_ZMAJOR_SLOTS,
+                    capi.VARIANT_PERSISTENT_ALWAYS, capi.VARIANT_PERSISTENT_NEVER):
         out, vh, mh = capi.fuse_once(grid, rp, views, init_grid=init, kernel_variant=variant)
         assert np.array_equal(mh, mh_w), (seed, variant)
         assert np.array_equal(vh, vh_w), (seed, variant)
@@ -102,7 +103,8 @@ def test_random_medium_scenes_bit_exact(seed):
     with np.errstate(all="ignore"):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        n_threads=oracle.max_threads())
-    for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_NO_BRICK_CLASSES, False), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False)):
+    for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_NO_BRICK_CLASSES, False), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False),
+                                (capi.VARIANT_PERSISTENT_ALWAYS, False), (capi.VARIANT_PERSISTENT_ALWAYS, True)):
         out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
         assert bits_equal(out, want), (seed, variant, count_hits)
         if count_hits:
@@ -118,7 +120,8 @@ def test_random_many_view_scenes_bit_exact(seed):
     with np.errstate(all="ignore"):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        n_threads=oracle.max_threads())
-    for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False)):
+    for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False),
+                                (capi.VARIANT_PERSISTENT_NEVER, False)):
         out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
         assert bits_equal(out, want), (seed, variant, count_hits)
         if count_hits:
