@@ -51,6 +51,34 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor peak, FMA counted as 2 flop (SURVEY.md 
 FLOP_PER_PROJECTION = 48.0  # algorithmic fp64 flop per voxel-projection
 MAPREC_BYTES = 208  # per-map camera record read by the kernel (fusion_kernels.h)
 
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
+SCENE_SEED = 1000
+
+
+def upload_scene(ctx, scene, kind: str, n: int, W: int, H: int, spacing: float, keep_host: bool = False, chunk: int = 32):
+    """The n views of scene `kind` onto ctx, `chunk` views at a time (bounded host memory).  Scenes with best-cost values go
+    through dmi_add_views with the threshold, as the reference's driver applies it per view (cu:348); the others through the
+    f32 entry point.  keep_host: also return the views as the device now holds them (f32, thresholded) for the CPU baseline
+    and the secondary contexts."""
+    kept = []
+    for c0 in range(0, n, chunk):
+        v, thr = scene.make_scene_views(kind, n, W, H, seed=SCENE_SEED, view_range=(c0, min(n, c0 + chunk)), noise_sigma=spacing)
+        if thr is None:
+            v = scene.Views(v.depth.astype(np.float32), v.K4, v.RT4)
+            ctx.add_views(v)
+        else:
+            ctx.add_views(v, threshold=thr)
+        if keep_host:
+            d = v.depth.astype(np.float32)
+            if thr is not None:
+                d[v.best_cost > thr] = -1.0   # RD.cxx:159-166
+            kept.append(scene.Views(d, v.K4, v.RT4))
+    if not keep_host:
+        return None
+    return scene.Views(np.concatenate([k.depth for k in kept]), np.concatenate([k.K4 for k in kept]),
+                       np.concatenate([k.RT4 for k in kept]))
+
+
 WORKLOADS = {
     # name: (grid cells, maps per GPU, W, H)   -- BASELINE.json configs
     "cfg1": ((64, 64, 64), 4, 320, 240),
@@ -235,8 +263,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--scene", default="dense", choices=["dense", "sparse"],
-                    help="dense: background behind the sphere, ~every in-frustum voxel accumulates")
+    ap.add_argument("--scene", default="speckle", choices=list(SCENE_KINDS),
+                    help="speckle (default): SURVEY.md 8d's input -- the dense sphere scene with best-cost values ~ U[0,1) and the "
+                         "threshold that turns ~10 %% of the pixels into 'no depth', applied by dmi_add_views as the reference's "
+                         "filter applies it (RD.cxx:138-167); dense: every pixel holds a depth; sparse: sphere only; noisy: speckle "
+                         "+ one voxel of depth noise + holes")
+    ap.add_argument("--no-scenes", action="store_true", help="N = 1: skip the `scenes` object (the other scene kinds, timed beside the headline)")
     ap.add_argument("--grid-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -259,7 +291,6 @@ def main():
     ap.add_argument("--no-coloration", action="store_true")
     ap.add_argument("--coloration-vertices", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--secondary", action="store_true", help="also time the other scene variant (N = 1)")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
@@ -333,14 +364,11 @@ def main():
         return
 
     # ---------------------------------------------------------------- N = 1 -----------------------------------
-    def make(scene_kind: str):
-        return scene.make_views(maps_per_gpu, W, H, seed=1000, dense=(scene_kind == "dense"), layout="sphere", dtype=np.float32)
-
-    views = make(args.scene)
+    spacing = float(max(grid.spacing))
     ctx = capi.FusionContext(grid, ray, device=local_rank, grid_dtype=args.grid_dtype, depth_storage="auto",
                              kernel_variant=args.variant)
     t_up = time.perf_counter()
-    ctx.add_views(views)
+    views = upload_scene(ctx, scene, args.scene, maps_per_gpu, W, H, spacing, keep_host=True)
     upload_s = time.perf_counter() - t_up
     info = ctx.info()
     depth_bytes = 8 if info.depth_storage_in_use == capi.DMI_DEPTH_F64 else 4
@@ -417,16 +445,23 @@ def main():
                      "algorithmic_bytes": c2p_bytes, "achieved": c2p_bytes / (c2p_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c2p_bytes / (c2p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
-    secondary = None
-    if args.secondary:
-        other = "sparse" if args.scene == "dense" else "dense"
-        v2 = make(other)
-        ctx.clear_views()
-        ctx.add_views(v2)
-        dt2, kern2 = timed(max(2, args.steps // 2), 1)
-        secondary = {"scene": other, "value": n_vox * maps_per_gpu * max(2, args.steps // 2) / dt2 / 1e9,
-                     "kernel_ms": kern2}
-        del v2
+    # the other scene kinds on the same context, timed like the headline (fewer steps): what the path does when the depth
+    # tables change character -- every pixel valid (dense), 10 % invalid speckle (speckle), speckle + noise + holes (noisy)
+    scenes = None
+    if not args.no_scenes:
+        scenes = {}
+        for kind in ("dense", "speckle", "noisy"):
+            if kind != args.scene:
+                ctx.clear_views()
+                upload_scene(ctx, scene, kind, maps_per_gpu, W, H, spacing)
+            n_steps = max(2, args.steps // 2)
+            dt2, kern2 = timed(n_steps, 1)
+            scenes[kind] = {"value": n_vox * maps_per_gpu * n_steps / dt2 / 1e9, "ms_per_step": dt2 / n_steps * 1e3,
+                            "fuse_ms": kern2, "kernel_ms": timed.main_ms, "brick_classes": ctx.brick_class_histogram(),
+                            "mixed_reasons": ctx.mixed_reason_histogram()}
+        if args.scene != "noisy":    # leave the context as the sections below expect it: the headline scene resident
+            ctx.clear_views()
+            upload_scene(ctx, scene, args.scene, maps_per_gpu, W, H, spacing)
 
     b_alg = algorithmic_bytes(n_vox, maps_per_gpu, W, H, grid_bytes, depth_bytes)
     achieved_gbps = b_alg / (main_ms * 1e-3) / 1e9
@@ -507,8 +542,8 @@ def main():
     }
     if ablation:
         out["ablation"] = ablation
-    if secondary:
-        out["secondary"] = secondary
+    if scenes:
+        out["scenes"] = scenes
     out["cell_to_point"] = cell_to_point
     if not args.no_end_to_end:
         pcie = capi.pcie_probe(local_rank)

@@ -400,7 +400,8 @@ class FusionContext:
         """Why the mixed (brick, view) pairs of the last fuse could not be proven uniform (diagnostic)."""
         h = (ctypes.c_uint64 * 8)()
         self._check(self._lib.dmi_get_mixed_reason_histogram(self._h, h))
-        names = ["unspecified", "degenerate", "camera_plane", "image_border", "nan_depth", "sentinel_and_depth", "near_surface"]
+        names = ["unspecified", "degenerate", "camera_plane", "image_border", "nan_depth", "sentinel_and_depth", "near_surface",
+                 "free_or_no_depth"]
         return {n: int(h[i]) for i, n in enumerate(names)}
 
     def timings(self) -> TimingsC:

@@ -305,14 +305,24 @@ __device__ __forceinline__ BoxFootprint box_footprint(const TileArgs &a, const M
   return box_footprint_k<ROT, false>(a, mr, tr, i0, i1, j0, j1, k0, k1);
 }
 
-// Part 2: the class that depth bounds `d` over (a superset of) the footprint prove for c.z in [czmin, czmax]
+// Part 2: the class that depth bounds `d` over (a superset of) the footprint prove for c.z in [czmin, czmax].  dmin / dmax
+// bound the VALID depths of those tiles (neither -1 nor NaN); a "no depth" pixel makes its voxel return at cu:202 whatever
+// the others do.  So with holes among the depths:
+//   * all valid depths far behind the brick's c.z range: every voxel accumulates -eta*rho or returns: MIXED_FREE_OR_NODEPTH,
+//     the per-voxel question is one compare with the sentinel;
+//   * all valid depths far in front of it: every voxel accumulates +0 (cu:115) or returns.  Neither is observable when adding
+//     +0 cannot change a sum and hits are not counted (TileArgs::behind_mask, 4b.6): the pair is skipped like a BEHIND one.
 __device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const TileAcc &d, double czmin, double czmax) {
   if (d.flags & TILE_HAS_NAN) return BRICK_MIXED | (MIXED_NAN_DEPTH << 2);
   if (!(d.flags & TILE_HAS_VALID)) return BRICK_SKIP;  // only "no depth" pixels (cu:202)
-  if (d.flags & TILE_HAS_SENTINEL) return BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2);
-  if ((czmax - (double)d.dmin) < -a.delta) return BRICK_FREE;    // cu:114-115: |diff| > delta and diff < 0 for every voxel
-  if ((czmin - (double)d.dmax) > a.delta) return BRICK_BEHIND;   // cu:114-115: diff > delta for every voxel
-  return BRICK_MIXED | (MIXED_NEAR_SURFACE << 2);
+  const bool holes = (d.flags & TILE_HAS_SENTINEL) != 0;
+  if ((czmax - (double)d.dmin) < -a.delta)  // cu:114-115: |diff| > delta and diff < 0 for every voxel with a depth
+    return holes ? (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2)) : (uint8_t)BRICK_FREE;
+  if ((czmin - (double)d.dmax) > a.delta) {  // cu:114-115: diff > delta for every voxel with a depth
+    if (!holes) return BRICK_BEHIND;
+    return a.behind_mask ? (uint8_t)BRICK_SKIP : (uint8_t)(BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2));
+  }
+  return BRICK_MIXED | ((holes ? MIXED_SENTINEL_AND_DEPTH : MIXED_NEAR_SURFACE) << 2);
 }
 
 template <int kQueryTiles, bool ROT, bool GK>

@@ -181,7 +181,12 @@ enum MixedReason : uint8_t {
   MIXED_IMAGE_BORDER = 3,        // the footprint is partly outside the depth map
   MIXED_NAN_DEPTH = 4,           // a NaN depth in the footprint's tiles
   MIXED_SENTINEL_AND_DEPTH = 5,  // both "no depth" pixels and depths in the footprint's tiles
-  MIXED_NEAR_SURFACE = 6         // the depths of the footprint's tiles come within delta of the brick's c.z range
+  MIXED_NEAR_SURFACE = 6,        // the depths of the footprint's tiles come within delta of the brick's c.z range
+  // "No depth" pixels among depths that are ALL far behind the brick (fl(czmax - dmin) < -delta over the valid depths):
+  // every voxel either returns at cu:202 or accumulates -eta*rho (cu:115), and which of the two is all that is left to find
+  // out per voxel -- the pixel, its load and one compare, no diff and no three-way potential (the FREE column of
+  // fuse_tile_kernel).  What a best-cost threshold leaves of free space (RD.cxx:138-167: scattered -1 pixels).
+  MIXED_FREE_OR_NODEPTH = 7
 };
 
 struct FuseConfig {

@@ -489,8 +489,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // The column, in two instantiations chosen per (brick, view): INTERIOR when the classification has proven every
     // voxel of the brick in front of the camera and inside the depth map for this view (the mixed pairs that are mixed
     // because a surface is near: MIXED_NAN_DEPTH and above), the full tests otherwise.
-    auto column = [&](auto interior_tag, auto surface_tag) __attribute__((always_inline)) {
+    auto column = [&](auto interior_tag, auto surface_tag, auto free_tag) __attribute__((always_inline)) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
+      // FREEONLY (a refinement of INTERIOR, MIXED_FREE_OR_NODEPTH): every depth of the brick's footprint is far behind the
+      // brick or missing, so a voxel accumulates -eta*rho (cu:115) unless its pixel holds no depth (cu:202): phase B is one
+      // compare with the sentinel and one masked add, without diff, the two far tests or the near-surface value
+      constexpr bool FREEONLY = decltype(free_tag)::value;
       // SURFACE (a refinement of INTERIOR): every pixel of the brick's footprint holds a depth (no "no depth" pixel, no
       // NaN: MIXED_NEAR_SURFACE), the sums cannot be -0.0 and hits are not counted
       constexpr bool SURFACE = decltype(surface_tag)::value;
@@ -612,6 +616,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const typename DL::raw_t d = dg[q];  // lanes that did not load still hold the sentinel
           // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike; SURFACE: every lane has a depth
           const mask_t m_hit = SURFACE ? ~0ull : ballot(!DL::is_sentinel(d));
+          if constexpr (FREEONLY) {
+            // proven by the classification (4b.8): fl(c.z - depth) < -delta for every depth the footprint holds
+            acc_add_s<BASE, TK>(kk, m_hit, free_space);  // -eta*rho (cu:115); under an empty mask when no lane has a depth
+            continue;
+          }
           if (SURFACE || m_hit) {  // wave-uniform: skip the potential when no lane accumulates
             const double diff = czg[q] - DL::widen(d);  // cu:108
             // cu:114-115 as two signed compares: diff < -delta is "far in front" (-eta*rho), diff > delta "far behind" (+0);
@@ -643,15 +652,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     const bool interior = kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
     if (interior) {
       if constexpr (!COUNT) {
-        if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
-          column(std::true_type{}, std::true_type{});
+        if (cbyte == ((unsigned)MIXED_FREE_OR_NODEPTH << 2 | BRICK_MIXED))
+          column(std::true_type{}, std::false_type{}, std::true_type{});
+        else if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
+          column(std::true_type{}, std::true_type{}, std::false_type{});
         else
-          column(std::true_type{}, std::false_type{});
+          column(std::true_type{}, std::false_type{}, std::false_type{});
       } else {
-        column(std::true_type{}, std::false_type{});
+        column(std::true_type{}, std::false_type{}, std::false_type{});
       }
     } else {
-      column(std::false_type{}, std::false_type{});
+      column(std::false_type{}, std::false_type{}, std::false_type{});
     }
 
     // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so

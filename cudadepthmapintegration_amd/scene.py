@@ -169,6 +169,52 @@ def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", de
     return Views(depth, K4, RT4, best)
 
 
+# ---- scenes as a stereo pipeline hands them over: invalid speckle, noise, holes --------------------------------------
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy")
+SPECKLE_THRESHOLD = 0.9  # best cost ~ U[0, 1): "threshold chosen to kill ~10 % of pixels" 
+
+
+def view_rng(seed: int, m: int, stream: int) -> np.random.Generator:
+    """Generator of view m's own random content: the same whoever renders the view and in whatever chunks."""
+    return np.random.default_rng([int(seed), int(m), int(stream)])
+
+
+def make_scene_views(kind: str, n: int, W: int, H: int, seed: int = 0, view_range: tuple | None = None,
+                     noise_sigma: float = 0.0, speckle: float = 1.0 - SPECKLE_THRESHOLD, holes: int = 6,
+                     layout: str = "sphere") -> tuple["Views", float | None]:
+    """The bench / test scenes by name; returns (views, best-cost threshold or None).
+      dense    sphere + background plane, every pixel holds a depth (hit rate ~100 %)
+      sparse   sphere only, -1 where a ray misses it
+      speckle  dense + "Best Cost Values" ~ U[0, 1) per pixel; with the returned threshold (0.9) the reference's
+               ApplyDepthThresholdFilter (RD.cxx:138-167, called at cu:348) turns ~10 % of the pixels, scattered at
+               random, into the -1 sentinel -- SURVEY.md 8d's scene, what the filter sees on real stereo output
+      noisy    speckle + depth noise (every depth += N(0, noise_sigma), in scene units: the bench passes one voxel's
+               spacing) + `holes` discs of 8-40 pixels radius without depth per view
+    Depths stay f32-representable (the device keeps them as f32 without changing a bit); best cost is f64 as the
+    reference's array is.  Views lo .. hi-1 of the n-camera scene when view_range is given."""
+    if kind not in SCENE_KINDS:
+        raise ValueError(f"scene kind {kind!r}: one of {SCENE_KINDS}")
+    base = make_views(n, W, H, seed=seed, layout=layout, dense=(kind != "sparse"), view_range=view_range)
+    if kind in ("dense", "sparse"):
+        return base, None
+    lo, hi = (0, n) if view_range is None else (int(view_range[0]), int(view_range[1]))
+    best = np.empty((hi - lo, H, W), dtype=np.float64)
+    for m in range(lo, hi):
+        best[m - lo] = view_rng(seed, m, 1).random((H, W), dtype=np.float32)
+        if kind == "noisy":
+            d = base.depth[m - lo]
+            rng = view_rng(seed, m, 2)
+            valid = d != -1.0
+            d += np.where(valid, noise_sigma * rng.standard_normal((H, W), dtype=np.float32), 0.0)
+            yy, xx = np.ogrid[0:H, 0:W]
+            for _ in range(holes):
+                cx, cy, r = rng.integers(0, W), rng.integers(0, H), rng.integers(8, 41)
+                d[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = -1.0
+            base.depth[m - lo] = d.astype(np.float32).astype(np.float64)
+    # the speckle fraction is what the threshold leaves above it
+    return Views(base.depth, base.K4, base.RT4, best), 1.0 - float(speckle)
+
+
 # ---- file forms of a view (what the reference's filter reads: Sources/Helper.h:105-168, RD.cxx:223-229) ----
 def write_krtd(path: str, K3: np.ndarray, RT4: np.ndarray) -> None:
     """.krtd text: 3 lines K, blank, 3 lines R, blank, 1 line T (%.17g round-trips every double)."""

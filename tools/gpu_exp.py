@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from bench import parse_workload  # noqa: E402
+from bench import parse_workload, upload_scene  # noqa: E402
 from cudadepthmapintegration_amd import build as _build, capi, scene  # noqa: E402
 
 
@@ -52,13 +52,12 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     out = []
     for sc in args.scenes.split(","):
-        views = scene.make_views(n_maps, W, H, seed=1000, dense=(sc == "dense"), dtype=np.float32)
         ctxs = {}
         for name, path in libs:
             load_lib(path)
             for v in variants:
                 c = capi.FusionContext(grid, ray, grid_dtype="f32", kernel_variant=v)
-                c.add_views(views)
+                upload_scene(c, scene, sc, n_maps, W, H, float(max(grid.spacing)))
                 ctxs[(name, v)] = c
         fuse = {k: [] for k in ctxs}
         main_ms = {k: [] for k in ctxs}
@@ -82,7 +81,8 @@ def main():
                 ref_grid = g
             same[k] = bool(np.array_equal(g, ref_grid))
         for k in ctxs:
-            rec = {"scene": sc, "lib": k[0], "variant": k[1], "fuse_ms": float(np.median(fuse[k])), "main_ms": float(np.median(main_ms[k])),
+            rec = {"scene": sc, "lib": k[0], "variant": k[1], "brick_classes": ctxs[k].brick_class_histogram(),
+                   "mixed_reasons": ctxs[k].mixed_reason_histogram(), "fuse_ms": float(np.median(fuse[k])), "main_ms": float(np.median(main_ms[k])),
                    "main_min_ms": float(np.min(main_ms[k])), "grid_bits_equal_first": same[k]}
             if ref is None:
                 ref = rec["main_ms"]
