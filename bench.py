@@ -6,7 +6,8 @@
 A step = one pass of the hot path over one batch of synthetic input: zero the grid, fuse every HBM-resident depth map
 of this rank into it and, for N > 1, sum the f32 grids of the ranks over RCCL (the path's only exchange step; issued
 by the library itself, dmi_multi_fuse, slab by slab behind the fusion).  Depth maps are resident before the timed
-region.  N = 1 workload = BASELINE.json configs[2]: 512^3 voxels x 256 depth maps of 1280x720.
+region.  N = 1 workload = BASELINE.json configs[2]: 512^3 voxels x 256 depth maps of 1280x720, SURVEY.md 8d's scene: a sphere in
+front of a background, best-cost values ~ U[0,1) with the threshold that invalidates ~10 % of the pixels (--scene speckle).
 
 N > 1: one process per GPU.  Launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
 environment) the script joins as a rank; launched plainly (`python bench.py --gpus 2`) it starts the N rank
@@ -18,7 +19,10 @@ the rendezvous: the RCCL unique id, the barriers and the max over ranks; every G
                                        checks the N-rank grid of cfg3 against its own single-GPU fusion of all views
 
 Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
-  roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s
+  roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s; flop_frac_* say how much of
+                SURVEY 8d's arithmetic the timed kernel executes (the brick classes prove most of it away)
+  scenes        the other scene kinds on the same context: dense (every pixel valid), speckle (the default: 10 % of the
+                pixels invalidated by the best-cost threshold), noisy (+ depth noise and holes)
   roofline_valu the binding roof of the per-voxel path: fp64 VALU issue (DESIGN.md "Roofline"), measured on
                 the same workload with brick classes switched off (every projection computed)
   roofline_issue what bounds the default path: vector / scalar instruction issue -- vector-pipe busy cycles and SALU
@@ -515,6 +519,13 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbps / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_source": (f"profiles/pmc_traffic.json [{args.workload}:{args.scene}:{args.grid_dtype}]: FETCH_SIZE / WRITE_SIZE "
+                               "passes of rocprofv3 over this workload at an earlier commit, NOT measured in this run") if traffic else None,
+            # the same launch against the fp64 vector peak, by SURVEY.md 8d's count of 48 flop per voxel-projection: above 1
+            # means the timed kernel does not execute the algorithmic work -- the brick classes prove most (brick, view)
+            # pairs uniform and never project them (brick_classes); the path that does project every pair is beside it
+            "flop_frac_default_path": FLOP_PER_PROJECTION * proj_per_launch / (main_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "flop_frac_per_voxel_path": valu_tflops / FP64_VECTOR_PEAK_TFLOPS if ablation else None,
             "kernel": "dmi::fuse_tile_kernel" if info.tiled_kernel else "dmi::fuse_kernel",
             "kernel_ms": main_ms,
             "fuse_ms": kern_ms,

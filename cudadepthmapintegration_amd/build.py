@@ -214,11 +214,24 @@ def run_accumulator_audit(verbose: bool = False) -> int:
     return checked
 
 
+def _record(mode: str) -> None:
+    """build/obj/build_record.json: what the last build() call in this tree did (a reader can tell a recompilation from
+    the acceptance of a prebuilt library by its digest)."""
+    import json
+    import time
+
+    try:
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        with open(os.path.join(OBJ_DIR, "build_record.json"), "w") as fh:
+            json.dump({"mode": mode, "library": os.path.relpath(LIB_PATH, ROOT), "digest": source_digest(), "time": time.time()}, fh)
+    except OSError:
+        pass
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
-        if not LIB_OVERRIDE:
-            build_cli(verbose)
-        return LIB_PATH
+        _record("up_to_date: the library's digest file names the present sources and flags; nothing compiled")
+        return LIB_PATH  # (the command-line tool is built with the library below, or on demand: capi.cli_binary)
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = _headers()
@@ -249,13 +262,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         jobs = [ex.submit(compile_one, s) for s in _sources()] + [ex.submit(audit_if_needed, None)]
         for j in jobs:
             j.result()
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-lz", "-ldl", "-pthread", "-o", LIB_PATH]  # zlib: compressed .vti arrays (host/vti_reader.cpp)
+    # linked inside the object directory (hipcc leaves its offload-bundler temporaries next to the output), then moved
+    # into place in one step: a concurrent loader sees the old library or the new one, never half of one
+    staged = os.path.join(OBJ_DIR, os.path.basename(LIB_PATH) + f".{os.getpid()}.tmp")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-lz", "-ldl", "-pthread", "-o", staged]  # zlib: compressed .vti arrays (host/vti_reader.cpp)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    build_cli(verbose)
+    os.replace(staged, LIB_PATH)
     with open(_digest_path(), "w") as fh:
         fh.write(digest + "\n")
+    build_cli(verbose)
+    _record("rebuilt: hipcc compiled the stale objects and linked the library")
     return LIB_PATH
 
 
@@ -264,14 +282,25 @@ CLI_PATH = os.path.join(CSRC, "dmi_reconstruction")
 
 def build_cli(verbose: bool = False) -> str:
     """The reference's `Reconstruction` command line over the library (csrc/host/recon_cli_main.cpp): a few lines of
-    main() linked against the .so next to it (rpath $ORIGIN).  Only for the default library."""
-    if os.path.basename(LIB_PATH) != "libdmi_hip.so":
+    main() linked against the .so next to it (rpath $ORIGIN).  Only for the default library.  Built by build() right after
+    the library and on demand by capi.cli_binary(); up to date = its digest file names the library's source digest
+    (timestamps say nothing after a checkout or a copy).  Linked to a temporary and moved into place."""
+    if os.path.basename(LIB_PATH) != "libdmi_hip.so" or LIB_OVERRIDE:
         return ""
     src = os.path.join(CSRC, "host", "recon_cli_main.cpp")
-    if not _stale(CLI_PATH, [src, LIB_PATH]):
-        return CLI_PATH
-    cmd = [hipcc_path()] + COMMON_FLAGS + [src, "-L" + CSRC, "-ldmi_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI_PATH]
+    digest = source_digest()
+    marker = CLI_PATH + ".digest"
+    if os.path.exists(CLI_PATH) and os.path.exists(marker):
+        with open(marker) as fh:
+            if fh.read().strip() == digest:
+                return CLI_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    staged = os.path.join(OBJ_DIR, f"dmi_reconstruction.{os.getpid()}.tmp")
+    cmd = [hipcc_path()] + COMMON_FLAGS + [src, "-L" + CSRC, "-ldmi_hip", "-Wl,-rpath,$ORIGIN", "-o", staged]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(staged, CLI_PATH)
+    with open(marker, "w") as fh:
+        fh.write(digest + "\n")
     return CLI_PATH

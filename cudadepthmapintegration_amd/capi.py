@@ -883,8 +883,11 @@ def cli_read_arguments(args):
 
 
 def cli_binary() -> str:
-    """Path of the dmi_reconstruction executable built next to the library."""
+    """Path of the dmi_reconstruction executable next to the library (linked now if the build has not done so: it needs
+    hipcc, which a box that only runs a prebuilt library may lack -- loading the library never depends on it)."""
     from . import build as _build
+    if not os.path.exists(_build.CLI_PATH):
+        _build.build_cli()
     return _build.CLI_PATH
 
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -336,6 +337,79 @@ bool grid_axis_aligned(const dmi_grid_desc &g) {
   return m[1] == 0 && m[2] == 0 && m[4] == 0 && m[6] == 0 && m[8] == 0 && m[9] == 0;
 }
 
+// Smallest float >= x (x >= 0, finite): the tier-1 margins are rounded up.
+float float_not_below(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
+// The pixel selection of a pinhole view on an axis-aligned grid works in coordinates measured from the image centre
+// (TileMapRec::cpx ...), in two tiers (fusion_tile.hip).  P, Q, S: rows 0..2 of K*[R|T]; Sx, Sy: magnitudes of
+// the terms of h.x, h.y over the grid; M[2]: of c.z.
+void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4], const double Q[4], const double S[4],
+                       double Sx, double Sy, const double M[3], bool general, bool aligned, TileMapRec *out) {
+  TileMapRec &t = *out;
+  t.t1_ok = 0;
+  t.t1_e1 = std::numeric_limits<float>::infinity();
+  t.t1_c1 = 0.5f - 0x1p-20f;
+  const double cxc = (double)(ctx->W / 2), cyc = (double)(ctx->H / 2);
+  t.t1_cidx = (int32_t)((int64_t)ctx->W * (ctx->H / 2) + ctx->W / 2);
+  if (general || !aligned) return;  // those launches (GENK / ROT instantiations) read px .. q0 and errk
+  double Pc[4], Qc[4];
+  for (int c = 0; c < 4; ++c) {
+    Pc[c] = P[c] - cxc * S[c];
+    Qc[c] = Q[c] - cyc * S[c];
+  }
+  t.cpx = Pc[0]; t.cpy = Pc[1]; t.cpz = Pc[2]; t.cp0 = Pc[3];
+  t.cqx = Qc[0]; t.cqy = Qc[1]; t.cqz = Qc[2]; t.cq0 = Qc[3];
+  const double *g = ctx->grid.grid_matrix;
+  const double sz = ctx->grid.spacing[2];
+  t.cdhx = (Pc[0] * (g[2] * sz) + Pc[1] * (g[6] * sz)) + Pc[2] * (g[10] * sz);
+  t.cdhy = (Qc[0] * (g[2] * sz) + Qc[1] * (g[6] * sz)) + Qc[2] * (g[10] * sz);
+  // |hx''_ref - hx''_kernel|: the reference's h.x carries <= 11 ulp(Sx), cxc times its c.z <= 6 ulp(cxc * M[2]); the kernel's
+  // affine value the 73 ulp of DESIGN.md 4.2 on the centred magnitudes (+ 2 per coefficient for the subtraction above);
+  // 512 ulp of Sx + cxc * M[2] covers the sum five times over
+  const double Sxc = Sx + cxc * M[2], Syc = Sy + cyc * M[2];
+  const double cerr = std::max(Sxc, Syc) * 0x1p-44;
+  t.cerrk = cerr + 0x1p-22 * M[2] * (1.0 + 0x1p-20);
+  t.t1_dhx = (float)t.cdhx;
+  t.t1_dhy = (float)t.cdhy;
+  const double dcz = t.dhz;  // pinhole: row 2 of [R|T] times the step of the world position per voxel along k
+  t.t1_dcz = (float)dcz;
+  t.t1_dthr = (float)(dcz * (double)t.t1_c1);
+  if (!(cerr < 0x1p-14)) return;  // (such a view fails the tiled kernel's per-view test anyway)
+  // c.z over the voxels of the grid: at least czmin (the real-valued minimum over the box of voxel centres, less the
+  // rounding of the computed value)
+  double lo[3], hi[3];
+  voxel_world(ctx->grid, 0, 0, ctx->opt.z_first, lo);
+  voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1, ctx->opt.z_first + ctx->grid.cell_dims[2] - 1, hi);
+  double czmin = r.rt[11];
+  for (int a = 0; a < 3; ++a) czmin += std::min(r.rt[8 + a] * lo[a], r.rt[8 + a] * hi[a]);
+  czmin -= 16.0 * 0x1p-52 * M[2];
+  // |hx''|, |hy''| over the grid, from the centred rows themselves (for a principal point at the image centre the cz terms
+  // of row 0 cancel: this is what keeps |u''| <= W / 2 instead of W)
+  double wmc[3];
+  for (int a = 0; a < 3; ++a) wmc[a] = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+  const double Scx = std::fabs(Pc[0]) * wmc[0] + std::fabs(Pc[1]) * wmc[1] + std::fabs(Pc[2]) * wmc[2] + std::fabs(Pc[3]);
+  const double Scy = std::fabs(Qc[0]) * wmc[0] + std::fabs(Qc[1]) * wmc[1] + std::fabs(Qc[2]) * wmc[2] + std::fabs(Qc[3]);
+  const double Sc = (std::max(Scx, Scy) + cerr) * (1.0 + 0x1p-20);               // bounds |hx''|, |hy''| and their fp32 images
+  const double D = kMaxColumn * std::max(std::fabs(t.cdhx), std::fabs(t.cdhy));  // their change over a column
+  const double Dz = kMaxColumn * std::fabs(dcz);
+  const double nl = 32.0 * 0x1p-53 * M[2];  // computed c.z against its affine model along a column (roundings of cu:80-92)
+  if (!(czmin > 0.0) || !std::isfinite(czmin)) return;  // the camera is inside (or too near) the grid: fp64 tier only
+  const double pmax = Sc / czmin + 1.0;                 // bounds every accepted tier-1 candidate |P|
+  const bool index_exact = ((int64_t)ctx->H + 2) * (int64_t)ctx->W < (int64_t(1) << 24);  // W*py'' + px'' exact in fp32
+  // e1 = e_abs + e_rel * HB, HB = the lane's bound on |hx''|, |hy''| along its column
+  double e1 = cerr + 3.0 * 0x1p-24 * Dz * pmax + 0x1p-22 * Dz + nl * (pmax + 2.0) + 0x1p-53 * std::max(Sx, Sy);
+  e1 *= 1.0 + 0x1p-10;
+  t.t1_erel = 0x1p-22f * (1.0f + 0x1p-10f);
+  t.t1_hspan = float_not_below(D * (1.0 + 0x1p-20));
+  if (!(pmax < 0x1p22) || !index_exact || !(e1 > 0x1p-100) || !(Sc < 0x1p60) || !std::isfinite(e1)) return;
+  t.t1_e1 = float_not_below(e1);
+  t.t1_ok = 1;
+}
+
 // Per-map record of the tiled kernel: row 2 of RT for the exact c.z, rows 0 and 1 of K*[R|T] for the
 // pixel selection, and `err`, a bound on the absolute difference between the reference's computed
 // h.x / h.y and the kernel's affine evaluation anywhere in the grid (DESIGN.md "Tiled kernel: proof
@@ -418,6 +492,7 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   //                                  (Sz * r >= 1 - 2^-39).
   t.errk = (t.err + 65536.0 * t.errz) + 0x1p-22 * Sz * (1.0 + 0x1p-20);
   t.depth = r.depth;
+  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, general, aligned, &t);
   return t;
 }
 
@@ -486,7 +561,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);
     // pixel selection must be provable for nearly every lane: the error bounds over h.z must stay far below one pixel
-    ctx->view_tile_ok.push_back(finite && t.err < 0x1p-14 && 65536.0 * t.errz < 0x1p-14 ? 1 : 0);
+    // (the centred rows' bound, cerrk, is below err + cxc * |c.z| terms: checked with the same limit)
+    ctx->view_tile_ok.push_back(finite && t.err < 0x1p-14 && 65536.0 * t.errz < 0x1p-14 && t.cerrk < 0x1p-13 ? 1 : 0);
   }
   ctx->maps_dirty = true;
   ctx->timings.last_upload_ms =

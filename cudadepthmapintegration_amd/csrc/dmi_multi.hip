@@ -11,6 +11,7 @@
 // `comm` (RCCL).  dmi_multi_fuse fuses the grid slab by slab on `compute`; after each slab an event lets `comm` start
 // that slab's all-reduce while `compute` goes on with the next slab; at the end `compute` waits for `comm`.
 #include "../../include/dmi.h"
+#include "fusion_kernels.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -28,7 +29,8 @@ namespace {
 thread_local std::string g_multi_create_error;
 
 constexpr int kMaxSlabs = 64;
-constexpr int kZSlabAlignment = 16;  // DMI_PARTITION_Z_SLABS: slab heights are multiples of the tallest voxel column
+static_assert(DMI_Z_SLAB_ALIGNMENT % dmi::kMaxColumnHeight == 0, "z-slab boundaries must not cut a voxel column");
+constexpr int kZSlabAlignment = DMI_Z_SLAB_ALIGNMENT;  // DMI_PARTITION_Z_SLABS: slab heights are multiples of the tallest voxel column (16)
 
 // ---- RCCL through dlopen: the signatures come from <rccl/rccl.h>, the symbols from librccl.so.1 at run time --------
 struct Rccl {
@@ -630,11 +632,16 @@ int dmi_multi_fuse(dmi_multi_context *m) {
     const int64_t plane = (int64_t)m->grid.cell_dims[0] * m->grid.cell_dims[1];
     std::vector<void *> grids(m->ranks.size(), nullptr);
 
+    {  // the step's clock starts on local rank 0's compute stream whether or not that rank owns any cell layer (a z-slab
+       // rank of a short grid may own none and has no context: its step is empty, its events must still pair up)
+      Rank &r0 = m->ranks[0];
+      DMI_M_HIP(m, hipSetDevice(r0.device));
+      DMI_M_HIP(m, hipEventRecord(r0.step_start, r0.compute));
+    }
     for (size_t i = 0; i < m->ranks.size(); ++i) {
       Rank &r = m->ranks[i];
       if (!r.ctx) continue;
       DMI_M_HIP(m, hipSetDevice(r.device));
-      if (i == 0) DMI_M_HIP(m, hipEventRecord(r.step_start, r.compute));
       DMI_M_CTX(m, r, dmi_reset_grid(r.ctx));  // filt.cxx:133: every fusion starts from zeros
       if (exchange) {
         // the collective reads the grid whether or not this rank fused anything: the pointer call also settles a

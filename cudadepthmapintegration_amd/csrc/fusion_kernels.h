@@ -61,9 +61,24 @@ struct alignas(16) TileMapRec {
   // general K (third row not 0 0 1 0, cu:176): h.z ~ sx*wx + sy*wy + sz*wz + s0 (row 2 of K*[R|T]) and its step per
   // voxel along k; errz bounds |h.z_ref - h.z_affine|.  For a pinhole K these restate RT row 2 and errz is 0.
   double sx, sy, sz, s0, dhz, errz;
+  // Pinhole view on an axis-aligned grid: the same two rows in pixel coordinates measured from the image centre
+  // (cxc, cyc) = (W / 2, H / 2): hx'' = hx - cxc*c.z, i.e. row 0 of K*[R|T] minus cxc times row 2 of [R|T] (and hy''
+  // likewise).  round(h.x/h.z) = cxc + round(hx''/h.z) in exact arithmetic, |u''| <= W/2 halves what a relative error
+  // costs in pixels, and the fusion kernel's two-tier pixel selection (fusion_tile.hip "tier 1") works in them; cerr,
+  // cerrk: err and errk for these rows.  The classification kernels keep reading px .. q0.
+  double cpx, cpy, cpz, cp0, cqx, cqy, cqz, cq0;
+  double cdhx, cdhy, cerrk;
+  // tier 1 of the pixel selection: the centred numerators, c.z and the acceptance threshold as fp32 affine functions of
+  // the voxel's position in its column: steps per voxel of hx'', hy'', c.z and of the threshold
+  // c1*c.z - e1 (c1 = 1/2 - 2^-20, e1 the absolute margin of the view; +inf when the view does not qualify)
+  float t1_dhx, t1_dhy, t1_dcz, t1_dthr;
+  float t1_e1, t1_c1;  // e1 = t1_e1 + t1_erel * (max(|hx''|, |hy''|) at the column's first voxel + t1_hspan)
+  float t1_erel, t1_hspan;
+  int32_t t1_cidx;  // W * cyc + cxc: pixel index of the image centre
+  int32_t t1_ok;
   double pad;
 };
-static_assert(sizeof(TileMapRec) == 192, "TileMapRec layout");
+static_assert(sizeof(TileMapRec) == 320, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical
 // shortcuts proven in DESIGN.md ("K specialisation").
@@ -218,6 +233,7 @@ enum VariantBits : int {
   VAR_PERSISTENT_NEVER = 65536    // tiled kernel, one-wave workgroups: one workgroup per brick whatever the number of views
 };
 
+constexpr int kMaxColumnHeight = 16;  // the tallest column of any tile shape: what z-slab partitions must be multiples of
 // Column height (voxels along k owned by one lane) and workgroup shape of tile shape `s`.
 struct TileShape {
   int tk, wx, wy;  // column height; waves per workgroup along x and y (a wave is 8 x 8 lanes)

@@ -90,6 +90,50 @@ __device__ __forceinline__ int cvt_saturating(double x) {
   return r;
 }
 
+// ---- tier 1 of the pixel selection: packed fp32 (two floats per lane in a register pair), see the kernel --------------
+#ifndef DMI_TIER1
+#define DMI_TIER1 1  // 0: every instantiation selects its pixels in fp64 only (A/B builds, tools/exp_list*.txt)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// a * b + c on both halves, a = the float in the low dword of a wave-uniform 64-bit value (an SGPR pair)
+__device__ __forceinline__ f32x2 pk_fma_s(unsigned long long a_bits, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(a_bits), "v"(b), "v"(c));
+  return d;
+}
+// a * b.x on both halves (b.y is never read)
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// c - a * b.x on both halves, one rounding each
+__device__ __forceinline__ f32x2 pk_fnma_lo(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// max(|a|, |b|) as ONE instruction (a C expression may pay a canonicalising v_max first)
+__device__ __forceinline__ float max_abs(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// v_rcp_f32 whose result an inline-asm instruction may read next.  gfx950 does not interlock a transcendental result against
+// the very next VALU instruction; the compiler inserts the wait state for consumers it generates itself, but it cannot see
+// into an asm statement (found the hard way: the packed multiply below read a stale register in a part of the wave, and
+// only the acceptance test's independence of the reciprocal kept the results right).  s_nop 0 = the one wait state.
+__device__ __forceinline__ float rcp_f32_for_asm(float x) {
+  float r;
+  asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int cvt_i32_f32(float x) {  // saturating, NaN -> 0
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // Read-only, wave-uniform data (camera records, the cz table, the FuseArgs copy) is read through the
 // constant address space: with a uniform address that is a scalar load into SGPRs.
 template <typename T>
@@ -227,6 +271,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   asm("" : "+v"(vW));
   asm("" : "+v"(vH));
   [[maybe_unused]] const double Wd = pinned((double)KA(W));  // the row pitch as the interior column multiplies it
+  // Tier 1 of the pixel selection (pinhole views on an axis-aligned grid): the row pitch as a float and the
+  // pixel index of the image centre, from which tier 1 counts
+  constexpr bool T1 = DMI_TIER1 != 0 && !ROT && !GENK;
+  [[maybe_unused]] const float Wf = __int_as_float(pinned_word(__float_as_int((float)KA(W))));
+  [[maybe_unused]] const int cidx = pinned_word(KA(W) * (KA(H) / 2) + KA(W) / 2);
   double tiny = 0x1p-20;  // the reciprocal seed's residual must stay below this; a value in registers, not a literal
   asm volatile("" : "+v"(tiny));  // rebuilt with two scalar moves next to every voxel's compare
   const int lane = threadIdx.x & 63;
@@ -454,6 +503,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // the grid get -inf: their c.z is -inf, i.e. "behind the camera" (cu:177), at no cost per voxel.
     // Voxels above the grid (k >= nz) get the same through a -inf entry of the cz table.
     double sz, rz3, hx, hy;
+    [[maybe_unused]] f32x2 H0 = {0.f, 0.f}, C0 = {0.f, 0.f}, DH = {0.f, 0.f}, DC = {0.f, 0.f};  // tier 1 (T1 only)
     double r20 = 0, r21 = 0, r22 = 0;  // ROT only
     if constexpr (ROT) {
       r20 = cload(&rec->rz0);
@@ -466,13 +516,35 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       const double sz_in = cload(&rec->rz0) * wx + cload(&rec->rz1) * wy;
       sz = lane_ok ? sz_in : -__builtin_inf();
       rz3 = cload(&rec->rz3);
+      if constexpr (T1) {
+        // pixel selection only: the centred h.x, h.y at the column's first voxel (TileMapRec::cpx ...), their fp32 images
+        // and steps, the column's first c.z and the acceptance threshold at it (tier 1, below)
+        hx = __builtin_fma(cload(&rec->cpx), wx,
+                           __builtin_fma(cload(&rec->cpy), wy, __builtin_fma(cload(&rec->cpz), wz0, cload(&rec->cp0))));
+        hy = __builtin_fma(cload(&rec->cqx), wx,
+                           __builtin_fma(cload(&rec->cqy), wy, __builtin_fma(cload(&rec->cqz), wz0, cload(&rec->cq0))));
+        const double cz_first = (sz + cload(ct)) + rz3;  // the exact c.z of the column's first voxel (cu:92); -inf off the grid
+        const float czf = (float)cz_first;
+        H0.x = (float)hx;
+        H0.y = (float)hy;
+        C0.x = czf;
+        // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column
+        const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
+        C0.y = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
+        DH.x = cload(&rec->t1_dhx);
+        DH.y = cload(&rec->t1_dhy);
+        DC.x = cload(&rec->t1_dcz);
+        DC.y = cload(&rec->t1_dthr);
+        asm volatile("" : "+v"(DH), "+v"(DC));  // wave-uniform, but VGPR operands of the packed FMAs: placed there once per view
+      } else {
       // pixel selection only: h.x, h.y at the column's first voxel, then one add per step
       hx = __builtin_fma(cload(&rec->px), wx,
                          __builtin_fma(cload(&rec->py), wy, __builtin_fma(cload(&rec->pz), wz0, cload(&rec->p0))));
       hy = __builtin_fma(cload(&rec->qx), wx,
                          __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
+      }
     }
-    const double dhx = cload(&rec->dhx), dhy = cload(&rec->dhy), errk = cload(&rec->errk);
+    [[maybe_unused]] const double dhx = T1 ? 0.0 : cload(&rec->dhx), dhy = T1 ? 0.0 : cload(&rec->dhy), errk = T1 ? 0.0 : cload(&rec->errk);
     [[maybe_unused]] double hz = 0, dhz = 0, errz = 0;
     if constexpr (GENK) {
       dhz = cload(&rec->dhz);
@@ -483,7 +555,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       }
     }
 
-    uint32_t undecided = 0;  // per lane: bit kk set = redo voxel kk of this map exactly
+    uint32_t undecided = 0;  // per lane: bit kk set = voxel kk of this map is redone after the column (tier 2, then exactly)
+    uint32_t und_kk = 0;     // wave-uniform: the voxels kk for which some lane is
     uint32_t map_hits = 0;   // wave-uniform
 
     // The column, in two instantiations chosen per (brick, view): INTERIOR when the classification has proven every
@@ -502,13 +575,20 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       // what the other lanes fetch (range-checked by the buffer descriptor) is never used: an unproven voxel's value is
       // replaced below by one that adds nothing, and a lane outside the grid owns no voxel (its sums are never stored)
       constexpr bool UNMASKED = INTERIOR && !COUNT;
+      // the image centre, from which tier 1 counts pixels: read once per column where the in-image test needs it
+      [[maybe_unused]] int cxc = 0, cyc = 0;
+      if constexpr (T1 && !INTERIOR) {
+        cxc = KC(W) >> 1;
+        cyc = KC(H) >> 1;
+      }
   #pragma unroll
       for (int g0 = 0; g0 < TK; g0 += kGroup) {
         double czg[kGroup];
         // Every lane starts from the "no depth" sentinel and only the lanes that are in the map load over it: phase B then
         // needs no mask from phase A (eight lane masks = sixteen SGPRs the loop does not have), cu:202 covers both.
         typename DL::raw_t dg[kGroup];
-                if constexpr (!ROT) {
+        // (a FREEONLY column of tier 1 never looks at c.z in fp64: neither its pixels nor its sums need it)
+        if constexpr (!ROT && !(T1 && FREEONLY)) {
           // exact c.z of the group's voxels first (cu:92, cu:172; h.z == c.z for a pinhole K): r22*wz(k) comes as one
           // scalar load for the group and its sixteen SGPRs are free again before the projections start
           const czvec ctg = cload(reinterpret_cast<const czvec *>(ct + g0));
@@ -521,6 +601,89 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         for (int q = 0; q < kGroup; ++q) {
           const int kk = g0 + q;
           if constexpr (!UNMASKED) dg[q] = DL::sentinel();
+          if constexpr (T1) {
+            // ---- tier 1.  In pixel coordinates counted from the image centre, the numerators hx'', hy'',
+            // c.z and the acceptance threshold are affine in the voxel's position kk in its column: fp32 images of all four
+            // come from two packed FMAs.  The candidate pixel P = rne(h'' / c.z) (v_rcp_f32, one packed multiply) is
+            // ACCEPTED when |h'' - P * c.z| < c1 * c.z - e1 in both coordinates (one packed FMA, one maximum, one compare):
+            // e1 and c1 cover every rounding on the way -- whatever v_rcp_f32 returned -- and the bound err of the affine
+            // form, so an accepted P is the reference's round(h.x / h.z) - W/2 and no tie.  The ~0.1 % of lanes that are not
+            // accepted are redone after the column: in fp64 (tier 2: the selection every instantiation used to run inline),
+            // then, if still unproven, with the reference's own expression.
+            f32x2 h = H0, cth = C0;
+            if (kk > 0) {
+              const unsigned long long kbits = (unsigned long long)(unsigned)__float_as_int((float)kk);
+              h = pk_fma_s(kbits, DH, H0);
+              cth = pk_fma_s(kbits, DC, C0);
+            }
+            f32x2 rr;
+            rr.x = rcp_f32_for_asm(cth.x);
+            const f32x2 ua = pk_mul_lo(h, rr);
+            f32x2 rp;
+            rp.x = __builtin_rintf(ua.x);
+            rp.y = __builtin_rintf(ua.y);
+            const f32x2 t = pk_fnma_lo(rp, cth, h);
+            const mask_t m_p1 = ballot(max_abs(t.x, t.y) < cth.y);
+            // W*py'' + px'' in one fp32 operation (exact: the host admits tier 1 only while (H + 2) * W < 2^24), then the
+            // centre's index; garbage on unaccepted lanes, whose loads the buffer descriptor range-checks
+            unsigned pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(rp.y, Wf, rp.x)) + cidx);
+            mask_t m_in, m_und;
+            [[maybe_unused]] mask_t m_front = 0;
+            if constexpr (INTERIOR) {
+              m_in = m_p1 & m_lane_ok;  // (every voxel of the brick is in front of the camera and inside the map: 4c)
+              m_und = m_lane_ok & ~m_p1;
+            } else {
+              m_front = ballot(!(czg[q] < 0.0));  // cu:177, exact (lanes and voxels off the grid: c.z = -inf)
+              // cu:192-197 on the integers
+              const int px1 = cvt_i32_f32(rp.x) + cxc, py1 = cvt_i32_f32(rp.y) + cyc;
+              m_in = m_front & m_p1 & ballot((unsigned)px1 < vW) & ballot((unsigned)py1 < vH);
+              m_und = m_front & ~m_p1;
+            }
+            if (m_und) {
+              // ---- tier 2, for the voxels (a few per cent of a wave's) in which some lane is left: the fp64 selection
+              // (in centred coordinates), evaluated by every lane and used by the lanes of m_und
+              const double kd = (double)kk;
+              const double hxk = __builtin_fma(kd, cload(&rec->cdhx), hx), hyk = __builtin_fma(kd, cload(&rec->cdhy), hy);
+              double cz2;
+              if constexpr (FREEONLY)
+                cz2 = (sz + cload(ct + kk)) + rz3;  // the exact c.z (cu:92), which this column does not keep
+              else
+                cz2 = czg[q];
+              const double r0 = __builtin_amdgcn_rcp(cz2);
+              const double e0 = __builtin_fma(-cz2, r0, 1.0);
+              const double r = __builtin_fma(r0, e0, r0);
+              const double ua2 = hxk * r, va2 = hyk * r;
+              const double ru2 = __builtin_rint(ua2), rv2 = __builtin_rint(va2);
+              const double fu = ua2 - ru2, fv = va2 - rv2;
+              const double chk = __builtin_fma(cload(&rec->cerrk), r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
+              const mask_t m_p2 = ballot(chk < 0.5) & ballot(__builtin_fabs(e0) < tiny) & m_und;
+              const unsigned pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + cidx);
+              if (__builtin_amdgcn_inverse_ballot_w64(m_p2)) pix = pix2;
+              if constexpr (INTERIOR) {
+                m_in |= m_p2;
+              } else {  // cu:192-197 on the integers (a saturated conversion plus the centre stays outside every map)
+                const int px2 = cvt_saturating(ru2) + cxc, py2 = cvt_saturating(rv2) + cyc;
+                m_in |= m_p2 & ballot((unsigned)px2 < vW) & ballot((unsigned)py2 < vH);
+              }
+              m_und &= ~m_p2;
+            }
+            if constexpr (UNMASKED) {
+              dg[q] = DL::load(rsrc, pix);
+              if (m_und) {  // wave-uniform branch
+                or_where(undecided, m_und, 1u << kk);
+                und_kk |= 1u << kk;
+                // the redo below adds this voxel's value; here it must add nothing (see the fp64 form below)
+                if (__builtin_amdgcn_inverse_ballot_w64(m_und)) dg[q] = SURFACE ? DL::minus_inf() : DL::sentinel();
+              }
+            } else {
+              if (m_und) {
+                or_where(undecided, m_und, 1u << kk);
+                und_kk |= 1u << kk;
+              }
+              if (__builtin_amdgcn_inverse_ballot_w64(m_in)) dg[q] = DL::load(rsrc, pix);  // cu:201
+            }
+            continue;
+          }
           if constexpr (ROT) {
             if (kk >= kcount) continue;  // wave-uniform: a voxel above the grid (the table has no -inf trick here)
             // the k-dependent products g_r2*gz(k) of cu:168 (wk table, scalar load), then w and c.z in the reference's order
@@ -593,6 +756,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             dg[q] = DL::load(rsrc, (unsigned)cvt_saturating(__builtin_fma(rv, Wd, ru)));
             if (m_und) {  // wave-uniform branch, rarely taken
               or_where(undecided, m_und, 1u << kk);
+              und_kk |= 1u << kk;
               // the exact redo below adds this voxel's value; here it must add nothing: "no depth" (cu:202), or, where
               // that is not looked for, a depth of -inf: diff = +inf > delta adds the +0 (cu:115) no sum can notice
               if (__builtin_amdgcn_inverse_ballot_w64(m_und)) dg[q] = SURFACE ? DL::minus_inf() : DL::sentinel();
@@ -601,7 +765,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             const int px = cvt_saturating(ru), py = cvt_saturating(rv);
             if constexpr (!INTERIOR)  // cu:192-197 on the integers: a saturated conversion is >= 2^31 as unsigned, outside any map
               m_in &= ballot((unsigned)px < vW) & ballot((unsigned)py < vH);
-            if (m_und) or_where(undecided, m_und, 1u << kk);  // wave-uniform branch, rarely taken
+            if (m_und) {  // wave-uniform branch, rarely taken
+              or_where(undecided, m_und, 1u << kk);
+              und_kk |= 1u << kk;
+            }
             if (__builtin_amdgcn_inverse_ballot_w64(m_in))
               dg[q] = DL::load(rsrc, __umul24((unsigned)py, vW) + (unsigned)px);  // cu:201
           }
@@ -665,25 +832,32 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       column(std::false_type{}, std::false_type{}, std::false_type{});
     }
 
-    // ---- exact redo of the unproven voxels of this map (each voxel gets at most one add per map, so
-    // doing them after the column keeps every voxel's accumulation in map order, cu:211)
-    if (ballot(undecided != 0)) {
+    // ---- exact redo of the voxels of this map whose pixel the column has not proven, about 2^-19 of all lanes (each voxel
+    // gets at most one add per map, so doing them after the column keeps every voxel's accumulation in map order, cu:211)
 #pragma unroll 1
-      for (int kk = 0; kk < kcount; ++kk) {
-        const bool mine = (undecided >> kk) & 1u;
-        if (!ballot(mine)) continue;
-        double val = 0.0;
-        bool hit = false;
-        if (mine) hit = tile_exact<DepthT>(KC(full), m, rsrc, i, j, k0 + kk, val);
-#pragma unroll
-        for (int q = 0; q < TK; ++q) {
-          if (kk == q) {  // wave-uniform
-            acc_add_v<BASE, TK>(q, ballot(hit), val);
-            if (COUNT) nh[q] += hit ? 1u : 0u;
-          }
+    while (und_kk) {  // wave-uniform: the voxels for which some lane is undecided
+      const int kk = __builtin_ctz(und_kk);
+      und_kk &= und_kk - 1;
+      const bool mine = (undecided >> kk) & 1u;
+      double val = 0.0;
+      bool hit = false;
+      const bool exact = mine;
+      if (ballot(exact)) {
+        double ev = 0.0;
+        const bool eh = exact ? tile_exact<DepthT>(KC(full), m, rsrc, i, j, k0 + kk, ev) : false;
+        if (exact) {
+          hit = eh;
+          val = ev;
         }
-        if (COUNT) map_hits += (uint32_t)__popcll(ballot(hit));
       }
+#pragma unroll
+      for (int q = 0; q < TK; ++q) {
+        if (kk == q) {  // wave-uniform
+          acc_add_v<BASE, TK>(q, ballot(hit), val);
+          if (COUNT) nh[q] += hit ? 1u : 0u;
+        }
+      }
+      if (COUNT) map_hits += (uint32_t)__popcll(ballot(hit));
     }
     if (COUNT) {
       if (map_hits != 0 && lane == 0) atomicAdd(&KC(map_hits)[m], (unsigned long long)map_hits);
@@ -803,6 +977,7 @@ unsigned resident_workgroups(Kernel kernel, int threads) {
 
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
+  static_assert(TK <= kMaxColumnHeight, "dmi_multi_z_slab aligns slabs to kMaxColumnHeight");
   // one workgroup per brick: super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
   // (+ 32: an XCD's eighths of the four levels can add up to four workgroups more than an eighth of the total)
   const int per_round = 8 * a.xcd_run_wg;

@@ -331,7 +331,10 @@ void dmi_multi_default_options(dmi_multi_options *opt); /* f32 grid, AUTO depth 
  * get one more) */
 int dmi_multi_view_shard(int64_t n, int32_t rank, int32_t world, int64_t *first, int64_t *count);
 /* cell layers [*z_first, *z_first + *z_count) owned by `rank` under DMI_PARTITION_Z_SLABS: boundaries are multiples of
- * DMI_SLAB_ALIGNMENT except the top of the grid; a rank may own nothing when nz is small */
+ * DMI_Z_SLAB_ALIGNMENT (16, the tallest voxel column of the fusion kernel: each rank's slab is a grid of its own, created
+ * with dmi_options.z_first, not a dmi_fuse_slab range -- those need DMI_SLAB_ALIGNMENT) except the top of the grid; a rank
+ * may own nothing when nz is small */
+#define DMI_Z_SLAB_ALIGNMENT 16
 int dmi_multi_z_slab(int32_t nz, int32_t rank, int32_t world, int32_t *z_first, int32_t *z_count);
 /* the z-slabs of the overlapped exchange: writes at most max_slabs (z_first, z_count) pairs, returns how many */
 int dmi_multi_slab_ranges(int32_t nz, int32_t n_slabs, int32_t *z_first, int32_t *z_count, int32_t max_slabs);

@@ -84,6 +84,56 @@ def test_cfg3_512cubed_256_maps_720p_f32_grid():
     assert np.abs(want).max() > 1.0
 
 
+@pytest.mark.parametrize("kind", ["speckle", "noisy"])
+def test_cfg3_speckled_depth_tables(kind):
+    """BASELINE configs[2] on the input the reference's filter really sees: best-cost values ~ U[0, 1) and the
+    threshold that turns ~10 % of the pixels, scattered, into "no depth" -- applied by dmi_add_views as
+    ApplyDepthThresholdFilter does (RD.cxx:138-167, cu:348); `noisy` adds one voxel of depth noise and holes.  Nearly every
+    footprint then holds sentinels next to depths: the path through MIXED_FREE_OR_NODEPTH / the FREE column and the skipped
+    far-behind pairs.  tiled == tiled without classes == general over the whole grid, 4096 oracle voxels."""
+    from bench import upload_scene
+    grid = scene.default_grid(512)
+    rp = scene.default_ray_potential(grid)
+    out = {}
+    views = None
+    for name, variant in (("tiled", 0), ("tiled_no_classes", capi.VARIANT_NO_BRICK_CLASSES), ("general", G)):
+        with capi.FusionContext(grid, rp, grid_dtype="f32", kernel_variant=variant) as ctx:
+            v = upload_scene(ctx, scene, kind, 256, 1280, 720, float(max(grid.spacing)), keep_host=(views is None))
+            views = views or v
+            assert ctx.info().tiled_kernel == (1 if name.startswith("tiled") else 0)
+            ctx.fuse()
+            out[name] = ctx.download_grid(np.float32)
+            if name == "tiled":
+                reasons = ctx.mixed_reason_histogram()
+                hist = ctx.brick_class_histogram()
+    assert np.array_equal(out["tiled"].view(np.uint32), out["general"].view(np.uint32))
+    assert np.array_equal(out["tiled"].view(np.uint32), out["tiled_no_classes"].view(np.uint32))
+    # the classes this scene is about: free space seen through holes, and far-behind pairs skipped whatever the holes
+    assert reasons["free_or_no_depth"] > 20_000_000 and hist["free"] == 0 and hist["skip"] > 25_000_000
+    frac = float((views.depth == -1.0).mean())
+    assert 0.09 < frac < 0.13, frac
+    ids = _sample_ids(grid, 4096, 6)
+    want, _ = oracle.fuse_voxels(oracle_params_from_scene(grid, rp, views), views.depth.astype(np.float64), views.K4,
+                                 views.RT4, ids, n_threads=oracle.max_threads())
+    assert np.array_equal(out["tiled"].reshape(-1)[ids], want.astype(np.float32))
+    assert np.abs(want).max() > 1.0
+
+
+def test_wide_depth_maps_leave_tier_one():
+    """Depth maps so large that W * py + px is no longer exact in fp32 ((H + 2) * W >= 2^24): the tiled kernel's packed-fp32
+    pixel selection (tier 1) declines the view on the host and every pixel comes from the fp64 tier; also a view whose
+    camera sits inside the grid (no positive lower bound of c.z: tier 1 declines as well).  Bit for bit against the
+    general kernel and oracle samples."""
+    grid = scene.default_grid((96, 80, 72))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(3, 4608, 3648, seed=31, dense=True, layout="sphere", dtype=np.float32)
+    views.RT4[2] = scene.look_at_rt(np.array([0.2, -0.1, 0.3]), target=(1.0, 0.5, -0.2))   # inside the grid
+    rng = np.random.default_rng(5)
+    views.depth[rng.random(views.depth.shape) < 0.1] = -1.0
+    want = _tiled_general_and_oracle_sample(grid, rp, views, 4096, 7)
+    assert np.abs(want).max() > 0.1
+
+
 def test_1024cubed_grid_indexing():
     """BASELINE configs[4] grid size (1024^3 voxels = 4.3 GB f32, 2^30 cells): 64-bit indexing of the grid, the class
     table and the brick order.  Fewer and smaller views than config 5 to keep the test short."""

@@ -61,7 +61,7 @@ def _random_case(seed, medium=False, many_views=False):
         views.K4[:, 0, 3] = rng.uniform(-3, 3)
     depth = views.depth
     m = rng.random(depth.shape)
-    depth[m < 0.05] = -1.0
+    depth[m < float(rng.choice([0.05, 0.1, 0.2, 0.3]))] = -1.0   # "no depth" speckle (a best-cost threshold's work, RD.cxx:138-167)
     if rng.integers(0, 3) == 0:
         depth[m > 0.995] = np.nan
     if rng.integers(0, 2) == 0:                     # values that are not f32-representable -> f64 storage

@@ -75,6 +75,20 @@ KERNEL_B32(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %1")
 KERNEL_B32(k_cmp_u32, "v_cmp_lt_u32 vcc, %0, %1")
 KERNEL_B32(k_bfi_b32, "v_bfi_b32 %0, %1, %0, %1")
 
+KERNEL_B32(k_max_abs_f32, "v_max_f32 %0, |%0|, |%1|")
+KERNEL_B32(k_cmp_f32, "v_cmp_lt_f32 vcc, %0, %1")
+KERNEL_B32(k_cvt_i32_f32, "v_cvt_i32_f32 %0, %0")
+KERNEL_B32(k_lshl_add_u32, "v_lshl_add_u32 %0, %0, 2, %1")
+KERNEL_B32(k_add_lshl_u32, "v_add_lshl_u32 %0, %0, %1, 2")
+KERNEL_B32(k_lshlrev_b32, "v_lshlrev_b32 %0, 2, %0")
+KERNEL_B32(k_med3_f32, "v_med3_f32 %0, %0, %1, %1")
+KERNEL_B32(k_fma_f32_sgpr, "v_fma_f32 %0, s8, %1, %0")
+// packed f32: two floats per lane in a 64-bit register pair
+KERNEL_F64_2(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %1")
+KERNEL_F64_2(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+KERNEL_F64_2(k_pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+KERNEL_F64_2(k_pk_fma_f32_bcast, "v_pk_fma_f32 %0, %0, %1, %1 op_sel_hi:[1,0,1]")
+
 // conversions: f64 <-> f32 / i32 (dst and src differ in width)
 #define KERNEL_CVT(NAME, ASM_A, ASM_B)                                                              \
   __global__ void NAME(double *out, unsigned long long *cyc, double s) {                            \
@@ -157,7 +171,7 @@ int main() {
   CHECK(hipMalloc(&d_out, sizeof(double) * 256 * 4 * 8 * 64));
   CHECK(hipMalloc(&d_cyc, sizeof(unsigned long long) * 256 * 4 * 8));
   const double ghz = 2.4;
-  for (int wps : {1, 4, 8}) {
+  for (int wps : {1, 5, 8}) {
     run("v_add_f64", k_add_f64, wps, d_out, d_cyc, ghz);
     run("v_mul_f64", k_mul_f64, wps, d_out, d_cyc, ghz);
     run("v_fma_f64", k_fma_f64, wps, d_out, d_cyc, ghz);
@@ -175,6 +189,18 @@ int main() {
     run("v_mad_u32_u24", k_mad_u32_u24, wps, d_out, d_cyc, ghz);
     run("v_cmp_lt_u32", k_cmp_u32, wps, d_out, d_cyc, ghz);
     run("v_bfi_b32", k_bfi_b32, wps, d_out, d_cyc, ghz);
+    run("v_max_f32 |a|,|b|", k_max_abs_f32, wps, d_out, d_cyc, ghz);
+    run("v_cmp_lt_f32", k_cmp_f32, wps, d_out, d_cyc, ghz);
+    run("v_cvt_i32_f32", k_cvt_i32_f32, wps, d_out, d_cyc, ghz);
+    run("v_lshl_add_u32", k_lshl_add_u32, wps, d_out, d_cyc, ghz);
+    run("v_add_lshl_u32", k_add_lshl_u32, wps, d_out, d_cyc, ghz);
+    run("v_lshlrev_b32", k_lshlrev_b32, wps, d_out, d_cyc, ghz);
+    run("v_med3_f32", k_med3_f32, wps, d_out, d_cyc, ghz);
+    run("v_fma_f32 (sgpr)", k_fma_f32_sgpr, wps, d_out, d_cyc, ghz);
+    run("v_pk_fma_f32", k_pk_fma_f32, wps, d_out, d_cyc, ghz);
+    run("v_pk_mul_f32", k_pk_mul_f32, wps, d_out, d_cyc, ghz);
+    run("v_pk_add_f32", k_pk_add_f32, wps, d_out, d_cyc, ghz);
+    run("v_pk_fma_f32 bcast", k_pk_fma_f32_bcast, wps, d_out, d_cyc, ghz);
     run("cvt f32<->f64 (avg)", k_cvt_f32_f64_pair, wps, d_out, d_cyc, ghz);
     run("cvt i32<->f64 (avg)", k_cvt_i32_f64_pair, wps, d_out, d_cyc, ghz);
     printf("\n");
