@@ -281,14 +281,19 @@ def main():
     ap.add_argument("--no-ablation", action="store_true")
     ap.add_argument("--slabs", type=int, default=4,
                     help="N > 1: z-slabs per fusion; the all-reduce of a slab overlaps the fusion of the next (1 = no overlap)")
-    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter", "peer_copy"],
                     help="N > 1: all_reduce = the contract (every rank gets the whole grid, overlapped slab by slab); "
-                         "reduce_scatter = every rank gets the sum of its own 1/N of the grid (half the traffic, no overlap)")
+                         "reduce_scatter = every rank gets the sum of its own 1/N of the grid (half the traffic, no overlap); "
+                         "peer_copy = the all-reduce by peer-to-peer copies and a sum kernel behind the fusion, no RCCL "
+                         "(ranks of one process: implies --one-process)")
     ap.add_argument("--partition", default="views", choices=["views", "z_slabs"],
                     help="N > 1: views = the north star's depth-map shards + exchange; z_slabs = every rank fuses all views into "
                          "its own cell layers, no collective")
     ap.add_argument("--one-process", action="store_true",
                     help="N > 1: one process drives all N devices (dmi_multi_create / ncclCommInitAll) instead of one process per GPU")
+    ap.add_argument("--share-device", action="store_true",
+                    help="--exchange peer_copy only: every rank on device 0 (a rehearsal of the N-rank exchange on a one-GPU box; "
+                         "the figures say nothing about N GPUs)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling objects")
     ap.add_argument("--force-multi", action="store_true",
                     help="rehearsal on a one-GPU box: run the N > 1 code path (dmi_multi_*, RCCL with one rank) with --gpus 1")
@@ -299,6 +304,10 @@ def main():
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
+    if args.exchange == "peer_copy":
+        args.one_process = True   # DMI_EXCHANGE_PEER_COPY: every rank in one process (no IPC handles between processes)
+        if env_world is not None and int(env_world) > 1:
+            raise SystemExit("bench.py --exchange peer_copy drives every GPU from ONE process: start it plainly, not under a launcher")
     if args.gpus > 1 and env_world is None and not args.one_process:
         sys.exit(self_launch(args.gpus))
     # ONE JSON line on stdout: native libraries that write to file descriptor 1 (RCCL prints a version banner there) are
@@ -325,7 +334,8 @@ def main():
     if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the fusion path has no CPU fallback")
     n_ranks = args.gpus  # ranks of the fusion = GPUs, however they are spread over processes
-    if n_dev < args.gpus or local_rank >= n_dev:   # one node: every rank sees every GPU, so every rank decides alike
+    share = args.share_device and args.exchange == "peer_copy"
+    if (n_dev < args.gpus and not share) or local_rank >= n_dev:   # one node: every rank sees every GPU, so every rank decides alike
         raise SystemExit(f"bench.py: {args.gpus} GPUs asked for, {n_dev} visible")
     have_torch_gpu = torch.cuda.is_available()
     if have_torch_gpu:
@@ -605,7 +615,8 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
         kw = dict(grid_dtype=args.grid_dtype, depth_storage="auto", kernel_variant=args.variant, partition=args.partition,
                   exchange=args.exchange, n_slabs=args.slabs)
         if args.one_process:
-            return capi.MultiContext(g, ray, devices=list(range(n_ranks)), **kw)
+            devs = [0] * n_ranks if (args.share_device and args.exchange == "peer_copy") else list(range(n_ranks))
+            return capi.MultiContext(g, ray, devices=devs, **kw)
         unique_id = None
         if args.partition == "views":  # every communicator needs an id of its own: rank 0 makes it, the launcher's store carries it
             box = [capi.multi_unique_id() if rank == 0 else None]
@@ -667,7 +678,7 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
                             "algorithmic_bytes_per_launch": b_alg,
                             "note": "rank 0's fusion kernel (all slabs of one step) over the algorithmic bytes of its own "
                                     "views and grid; the path is bound by fp64 VALU issue, not HBM (DESIGN.md)"}}
-        if check and rank == 0 and args.partition == "views" and args.exchange == "all_reduce":
+        if check and rank == 0 and args.partition == "views" and args.exchange in ("all_reduce", "peer_copy"):
             # the N-rank grid against this GPU's own fusion of ALL views (same views whatever N is)
             got, _ = m.download_grid(np_grid)
             got = got.copy()
@@ -702,7 +713,9 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
             strong.append(rec)
     top = weak if (args.scaling == "weak" or not strong) else strong[0]
     exchange_txt = {"all_reduce": f"one RCCL all-reduce of the {args.grid_dtype} grid in {info.n_slabs} z-slabs overlapped with the fusion",
-                    "reduce_scatter": f"RCCL reduce-scatter of the grid (each rank keeps 1/{n_ranks})"}[args.exchange]
+                    "reduce_scatter": f"RCCL reduce-scatter of the grid (each rank keeps 1/{n_ranks})",
+                    "peer_copy": f"all-reduce of the {args.grid_dtype} grid by peer-to-peer copies (SDMA) in {info.n_slabs} z-slabs, "
+                                 "summed in rank order by a kernel behind the fusion, no RCCL"}[args.exchange]
     out = {
         "metric": "Gvoxel-projections/s",
         "value": top["value"],
@@ -728,6 +741,7 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
             "rccl_ranks": int(info.rccl_ranks),
             "rccl_version": int(info.rccl_version),
             "launched_by": os.environ.get("DMI_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "bench.py --one-process"),
+            "ranks_share_device_0": bool(args.share_device and args.exchange == "peer_copy"),
         },
         "roofline": top["roofline"],
         "weak": weak,

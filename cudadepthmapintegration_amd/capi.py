@@ -84,7 +84,7 @@ class MultiTimingsC(ctypes.Structure):
 
 
 DMI_PARTITION_VIEWS, DMI_PARTITION_Z_SLABS = 0, 1
-DMI_EXCHANGE_ALL_REDUCE, DMI_EXCHANGE_REDUCE_SCATTER = 0, 1
+DMI_EXCHANGE_ALL_REDUCE, DMI_EXCHANGE_REDUCE_SCATTER, DMI_EXCHANGE_PEER_COPY = 0, 1, 2
 DMI_UNIQUE_ID_BYTES = 128
 
 # every symbol include/dmi.h declares (tests/test_abi.py checks the library exports them all)
@@ -96,8 +96,8 @@ ABI_SYMBOLS = [
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
     "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram",
-    "dmi_color_set_scratch_budget", "dmi_color_set_vertex_reorder",
-    "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_create",
+    "dmi_color_set_scratch_budget", "dmi_color_set_vertex_reorder", "dmi_iso_active_cells",
+    "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_peer_chunk", "dmi_multi_create",
     "dmi_multi_get_unique_id", "dmi_multi_create_rank", "dmi_multi_destroy", "dmi_multi_last_error", "dmi_multi_add_views",
     "dmi_multi_add_views_f32", "dmi_multi_add_local_views", "dmi_multi_add_local_views_f32", "dmi_multi_clear_views", "dmi_multi_fuse", "dmi_multi_synchronize",
     "dmi_multi_download_grid_f32", "dmi_multi_download_grid_f64", "dmi_multi_get_info", "dmi_multi_get_timings",
@@ -160,6 +160,8 @@ def load() -> ctypes.CDLL:
     L.dmi_cell_to_point.argtypes = [vp]
     L.dmi_download_point_data_f64.argtypes = [vp, dp]
     L.dmi_point_data_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
+    L.dmi_iso_active_cells.argtypes = [vp, ctypes.c_double, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.c_uint64]
     L.dmi_get_brick_class_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_mixed_reason_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
@@ -187,6 +189,7 @@ def load() -> ctypes.CDLL:
     L.dmi_multi_view_shard.argtypes = [i64, i32, i32, i64p, i64p]
     L.dmi_multi_z_slab.argtypes = [i32, i32, i32, i32p, i32p]
     L.dmi_multi_slab_ranges.argtypes = [i32, i32, i32p, i32p, i32]
+    L.dmi_multi_peer_chunk.argtypes = [i64, i32, i32, i64p, i64p]
     L.dmi_multi_create.argtypes = [ctypes.POINTER(GridDescC), ctypes.POINTER(RayPotentialC), ctypes.POINTER(MultiOptionsC),
                                    i32p, i32, ctypes.POINTER(vp)]
     L.dmi_multi_get_unique_id.argtypes = [u8p]
@@ -390,6 +393,19 @@ class FusionContext:
         self._check(self._lib.dmi_download_point_data_f64(self._h, _dp(out)))
         return out.reshape(nz + 1, ny + 1, nx + 1)
 
+    def iso_active_cells(self, iso: float, ids: bool = True):
+        """(count, ids): the cells whose corner point values straddle `iso` (dmi_iso_active_cells); ids ascending int64, or
+        None when ids=False."""
+        n = ctypes.c_uint64(0)
+        self._check(self._lib.dmi_iso_active_cells(self._h, float(iso), ctypes.byref(n), None, 0))
+        if not ids:
+            return int(n.value), None
+        out = np.empty(int(n.value), dtype=np.int64)
+        if n.value:
+            self._check(self._lib.dmi_iso_active_cells(self._h, float(iso), ctypes.byref(n),
+                                                       out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), out.size))
+        return int(n.value), out
+
     def brick_class_histogram(self) -> dict:
         """(brick, view) pairs of the last fuse by proven class (diagnostic)."""
         h = (ctypes.c_uint64 * 4)()
@@ -443,6 +459,15 @@ def multi_z_slab(nz: int, rank: int, world: int) -> tuple[int, int]:
     return int(a.value), int(a.value + b.value)
 
 
+def multi_peer_chunk(n: int, world: int, c: int) -> tuple[int, int]:
+    """[first, first + count) of an n-element slab that rank c of a peer-copy exchange sums (dmi_multi_peer_chunk)."""
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    rc = load().dmi_multi_peer_chunk(int(n), int(world), int(c), ctypes.byref(a), ctypes.byref(b))
+    if rc != DMI_OK:
+        raise DmiError(rc, "dmi_multi_peer_chunk: invalid argument")
+    return int(a.value), int(b.value)
+
+
 def multi_slab_ranges(nz: int, n_slabs: int) -> list[tuple[int, int]]:
     """(z_first, z_count) of the z-slabs of the overlapped exchange (dmi_multi_slab_ranges; needs no GPU)."""
     a, b = (ctypes.c_int32 * 64)(), (ctypes.c_int32 * 64)()
@@ -477,7 +502,8 @@ class MultiContext:
         o.depth_storage = {"auto": DMI_DEPTH_AUTO, "f32": DMI_DEPTH_F32, "f64": DMI_DEPTH_F64}[depth_storage]
         o.kernel_variant = int(kernel_variant)
         o.partition = {"views": DMI_PARTITION_VIEWS, "z_slabs": DMI_PARTITION_Z_SLABS}[partition]
-        o.exchange = {"all_reduce": DMI_EXCHANGE_ALL_REDUCE, "reduce_scatter": DMI_EXCHANGE_REDUCE_SCATTER}[exchange]
+        o.exchange = {"all_reduce": DMI_EXCHANGE_ALL_REDUCE, "reduce_scatter": DMI_EXCHANGE_REDUCE_SCATTER,
+                      "peer_copy": DMI_EXCHANGE_PEER_COPY}[exchange]
         o.n_slabs = int(n_slabs)
         g = _grid_c(grid)
         r = RayPotentialC(float(ray.thickness), float(ray.rho), float(ray.eta), float(ray.delta))
@@ -590,6 +616,20 @@ class MultiContext:
             if rc != DMI_OK:
                 raise DmiError(rc, self._lib.dmi_last_error(h).decode())
         return t
+
+    def local_context_grid(self, local_index: int, dtype=np.float32) -> np.ndarray:
+        """The grid as local rank `local_index` holds it (after an all-reduce exchange every rank holds the sums)."""
+        h = ctypes.c_void_p()
+        self._check(self._lib.dmi_multi_local_context(self._h, int(local_index), ctypes.byref(h)))
+        nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        out = np.zeros(self.n_voxels, dtype=dtype)
+        if np.dtype(dtype) == np.float64:
+            rc = self._lib.dmi_download_grid_f64(h, _dp(out))
+        else:
+            rc = self._lib.dmi_download_grid_f32(h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        if rc != DMI_OK:
+            raise DmiError(rc, self._lib.dmi_last_error(h).decode())
+        return out.reshape(nz, ny, nx)
 
     def local_info(self, local_index: int = 0) -> InfoC:
         h = ctypes.c_void_p()

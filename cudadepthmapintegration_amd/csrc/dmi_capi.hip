@@ -1428,6 +1428,53 @@ int dmi_point_data_device_pointer(dmi_context *ctx, void **ptr) {
   });
 }
 
+int dmi_iso_active_cells(dmi_context *ctx, double iso, uint64_t *count, int64_t *cell_ids, uint64_t capacity) {
+  return guarded(ctx, "dmi_iso_active_cells", [&]() -> int {
+  if (!ctx || !count) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_iso_active_cells: null argument");
+  if (iso != iso) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_iso_active_cells: the iso-value is a NaN");
+  *count = 0;
+  int rc = dmi_cell_to_point(ctx);  // the contour filter reads the point data (Reconstruction/main.cxx:151-173)
+  if (rc != DMI_OK) return rc;
+  const int nx = ctx->grid.cell_dims[0], ny = ctx->grid.cell_dims[1], nz = ctx->grid.cell_dims[2];
+  const size_t n_blocks = dmi::iso_block_count(nx, ny, nz);
+  if (n_blocks >= (size_t(1) << 31)) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_iso_active_cells: grid too large for one launch");
+  // scratch for this call: per-block counts (+ a trailing zero), their prefix sums, the scan's own storage, the ids
+  struct Scratch {
+    uint32_t *counts = nullptr;
+    uint64_t *bases = nullptr;
+    void *temp = nullptr;
+    int64_t *ids = nullptr;
+    ~Scratch() {
+      (void)hipFree(counts);
+      (void)hipFree(bases);
+      (void)hipFree(temp);
+      (void)hipFree(ids);
+    }
+  } sc;
+  size_t temp_bytes = 0;
+  DMI_HIP(ctx, dmi::launch_iso_count(nullptr, nx, ny, nz, iso, nullptr, nullptr, nullptr, &temp_bytes, ctx->stream));
+  DMI_HIP(ctx, hipMalloc(&sc.counts, (n_blocks + 1) * sizeof(uint32_t)));
+  DMI_HIP(ctx, hipMalloc(&sc.bases, (n_blocks + 1) * sizeof(uint64_t)));
+  DMI_HIP(ctx, hipMalloc(&sc.temp, std::max<size_t>(temp_bytes, 16)));
+  DMI_HIP(ctx, hipMemsetAsync(sc.counts + n_blocks, 0, sizeof(uint32_t), ctx->stream));
+  DMI_HIP(ctx, dmi::launch_iso_count(ctx->d_points, nx, ny, nz, iso, sc.counts, sc.bases, sc.temp, &temp_bytes, ctx->stream));
+  uint64_t total = 0;
+  DMI_HIP(ctx, hipMemcpyAsync(&total, sc.bases + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *count = total;
+  const uint64_t n_out = std::min<uint64_t>(total, cell_ids ? capacity : 0);
+  if (n_out > 0) {
+    DMI_HIP(ctx, hipMalloc(&sc.ids, (size_t)n_out * sizeof(int64_t)));
+    DMI_HIP(ctx, dmi::launch_iso_write(ctx->d_points, nx, ny, nz, iso, sc.bases, sc.ids, n_out, ctx->stream));
+    DMI_HIP(ctx, hipMemcpyAsync(cell_ids, sc.ids, (size_t)n_out * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  rc = drain_c2p(ctx);
+  if (rc != DMI_OK) return rc;
+  return drain_events(ctx);
+  });
+}
+
 int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]) {
   return guarded(ctx, "dmi_get_brick_class_histogram", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_brick_class_histogram: null argument");

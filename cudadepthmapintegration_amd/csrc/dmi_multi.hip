@@ -7,8 +7,15 @@
 // the single-GPU C ABI (dmi_create / dmi_add_views / dmi_fuse_slab ...), HIP streams and events, and RCCL, which is
 // loaded with dlopen on first use so that single-GPU users do not depend on it.
 //
+// A third exchange needs neither RCCL nor a compute unit for the transfers (DMI_EXCHANGE_PEER_COPY, ranks of one process):
+// every slab is cut into `world` chunks, rank r collects the other ranks' chunk r in a staging buffer by peer-to-peer copies
+// (hipMemcpyPeerAsync: the SDMA engines), adds them to its own in rank order with a small kernel queued behind its fusion,
+// and copies the sum back into every other rank's grid -- a direct reduce-scatter + all-gather over the point-to-point
+// xGMI links, deterministic (RCCL's ring order is not), and independent of whether a persistent fusion kernel leaves
+// wave slots for a collective's kernels.
+//
 // Streams per rank: `compute` (handed to the rank's dmi_context: uploads' consumers, classification, fusion) and
-// `comm` (RCCL).  dmi_multi_fuse fuses the grid slab by slab on `compute`; after each slab an event lets `comm` start
+// `comm` (RCCL, or the peer copies).  dmi_multi_fuse fuses the grid slab by slab on `compute`; after each slab an event lets `comm` start
 // that slab's all-reduce while `compute` goes on with the next slab; at the end `compute` waits for `comm`.
 #include "../../include/dmi.h"
 #include "fusion_kernels.h"
@@ -101,6 +108,10 @@ struct Rank {
   ncclComm_t nccl = nullptr;
   hipEvent_t slab_done[kMaxSlabs] = {};
   hipEvent_t exchanged = nullptr, step_start = nullptr, step_stop = nullptr;
+  // DMI_EXCHANGE_PEER_COPY: the other ranks' parts of this rank's chunks ((world - 1) x the chunk size, every slab its own
+  // place), and per slab: this rank's outgoing copies are done / its chunk is summed / the sum has reached every rank
+  void *staging = nullptr;
+  hipEvent_t copied[kMaxSlabs] = {}, summed[kMaxSlabs] = {}, gathered[kMaxSlabs] = {};
   int32_t z_first = 0, z_count = 0;  // cell layers of this rank's context (the whole grid under VIEWS)
   int64_t n_views = 0;               // views resident in ctx
 };
@@ -188,6 +199,34 @@ void shard(int64_t n, int32_t rank, int32_t world, int64_t *first, int64_t *coun
 size_t grid_elem(const dmi_multi_context *m) { return m->opt.grid_dtype == DMI_F64 ? 8 : 4; }
 
 bool needs_comm(const dmi_multi_options &o) { return o.partition == DMI_PARTITION_VIEWS; }
+bool needs_rccl(const dmi_multi_options &o) { return needs_comm(o) && o.exchange != DMI_EXCHANGE_PEER_COPY; }
+
+// chunk c of the element range [e0, e1) cut into `world` pieces of q elements (q a multiple of 256, the last ones may be
+// short or empty)
+struct Chunk {
+  int64_t first, count;
+};
+int64_t chunk_quantum(int64_t n, int32_t world) { return ((n + world - 1) / world + 255) / 256 * 256; }
+Chunk chunk_of(int64_t e0, int64_t e1, int32_t world, int32_t c) {
+  const int64_t q = chunk_quantum(e1 - e0, world);
+  const int64_t lo = std::min(e1, e0 + (int64_t)c * q), hi = std::min(e1, e0 + (int64_t)(c + 1) * q);
+  return Chunk{lo, hi - lo};
+}
+
+// own[i] = the sum over the ranks, IN RANK ORDER, of their values of element i: parts[j] is rank j's (the owner's entry
+// points into its own grid); one rounding per addition in the grid's type, the same on every run
+constexpr int kMaxPeerRanks = 16;
+struct PeerParts {
+  const void *p[kMaxPeerRanks];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void peer_sum_kernel(T *__restrict__ own, const PeerParts parts, int world, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  T v = static_cast<const T *>(parts.p[0])[i];
+  for (int j = 1; j < world; ++j) v += static_cast<const T *>(parts.p[j])[i];
+  own[i] = v;
+}
 
 int check_common(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dmi_multi_options &o, int32_t world) {
   if (!grid || !ray) return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: null argument");
@@ -196,7 +235,7 @@ int check_common(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const 
     return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: grid_dtype must be DMI_F32 or DMI_F64");
   if (o.partition != DMI_PARTITION_VIEWS && o.partition != DMI_PARTITION_Z_SLABS)
     return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: unknown partition");
-  if (o.exchange != DMI_EXCHANGE_ALL_REDUCE && o.exchange != DMI_EXCHANGE_REDUCE_SCATTER)
+  if (o.exchange != DMI_EXCHANGE_ALL_REDUCE && o.exchange != DMI_EXCHANGE_REDUCE_SCATTER && o.exchange != DMI_EXCHANGE_PEER_COPY)
     return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: unknown exchange");
   if (o.n_slabs < 0 || o.n_slabs > kMaxSlabs)
     return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: n_slabs must be in [0, 64]");
@@ -239,6 +278,35 @@ int init_rank(dmi_multi_context *m, Rank &r) {
   }
   int rc = dmi_create(&g, &m->ray, &o, &r.ctx);
   if (rc != DMI_OK) return mfail(m, rc, std::string("dmi_create (rank ") + std::to_string(r.rank) + "): " + dmi_last_error(nullptr));
+  return DMI_OK;
+}
+
+// DMI_EXCHANGE_PEER_COPY: staging buffers, per-slab events, peer access between the devices (best effort: without it
+// hipMemcpyPeerAsync still works, through host memory)
+int init_peer_exchange(dmi_multi_context *m) {
+  const int32_t world = m->world;
+  const int64_t plane = (int64_t)m->grid.cell_dims[0] * m->grid.cell_dims[1];
+  // every slab has its own place in the staging buffer: (world - 1) pieces of that slab's chunk size
+  int64_t elems = 0;
+  for (int s = 0; s < m->n_slab_ranges; ++s) elems += chunk_quantum((int64_t)m->slab_n[s] * plane, world) * (world - 1);
+  for (Rank &r : m->ranks) {
+    DMI_M_HIP(m, hipSetDevice(r.device));
+    if (elems > 0) DMI_M_HIP(m, hipMalloc(&r.staging, (size_t)elems * grid_elem(m)));
+    for (int s = 0; s < m->n_slab_ranges; ++s) {
+      DMI_M_HIP(m, hipEventCreateWithFlags(&r.copied[s], hipEventDisableTiming));
+      DMI_M_HIP(m, hipEventCreateWithFlags(&r.summed[s], hipEventDisableTiming));
+      DMI_M_HIP(m, hipEventCreateWithFlags(&r.gathered[s], hipEventDisableTiming));
+    }
+    for (const Rank &o : m->ranks) {
+      if (o.device == r.device) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, r.device, o.device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(o.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      }
+      (void)hipGetLastError();
+    }
+  }
   return DMI_OK;
 }
 
@@ -307,6 +375,94 @@ int drain_step(dmi_multi_context *m) {
   return DMI_OK;
 }
 
+// DMI_EXCHANGE_PEER_COPY, one step: fuse slab by slab; behind slab s every rank sends the other ranks their chunk of it
+// (peer copies on `comm`), and one slab LATER -- so that no compute stream ever waits for a copy that could still be in
+// flight -- every rank adds what it has received to its own chunk (a small kernel on `compute`, rank order) and sends
+// the sum back into everybody's grid.  grids[i]: rank i's grid pointer where the caller already asked for it.
+int peer_exchange(dmi_multi_context *m, bool by_slabs, std::vector<void *> &grids) {
+  const int32_t world = m->world;
+  const size_t esz = grid_elem(m);
+  const int64_t plane = (int64_t)m->grid.cell_dims[0] * m->grid.cell_dims[1];
+  const int n_rounds = m->n_slab_ranges;
+  std::vector<int64_t> stage_off((size_t)n_rounds + 1, 0);
+  for (int s = 0; s < n_rounds; ++s)
+    stage_off[(size_t)s + 1] = stage_off[(size_t)s] + chunk_quantum((int64_t)m->slab_n[s] * plane, world) * (world - 1);
+  auto slot_of = [](int32_t sender, int32_t owner) { return sender < owner ? sender : sender - 1; };
+
+  auto sum_and_gather = [&](int s) -> int {
+    const int64_t e0 = (int64_t)m->slab_z[s] * plane, e1 = e0 + (int64_t)m->slab_n[s] * plane;
+    const int64_t q = chunk_quantum(e1 - e0, world);
+    for (Rank &r : m->ranks) {
+      const Chunk c = chunk_of(e0, e1, world, r.rank);
+      DMI_M_HIP(m, hipSetDevice(r.device));
+      for (Rank &j : m->ranks)
+        if (j.rank != r.rank) DMI_M_HIP(m, hipStreamWaitEvent(r.compute, j.copied[s], 0));
+      if (c.count > 0) {
+        char *own = static_cast<char *>(grids[(size_t)r.rank]) + c.first * (int64_t)esz;
+        PeerParts parts{};
+        for (int32_t j = 0; j < world; ++j)
+          parts.p[j] = j == r.rank ? own : static_cast<char *>(r.staging) + (stage_off[(size_t)s] + (int64_t)slot_of(j, r.rank) * q) * (int64_t)esz;
+        const dim3 blocks((unsigned)((c.count + 255) / 256));
+        if (esz == 8)
+          hipLaunchKernelGGL(peer_sum_kernel<double>, blocks, dim3(256), 0, r.compute, reinterpret_cast<double *>(own), parts, world, c.count);
+        else
+          hipLaunchKernelGGL(peer_sum_kernel<float>, blocks, dim3(256), 0, r.compute, reinterpret_cast<float *>(own), parts, world, c.count);
+        DMI_M_HIP(m, hipGetLastError());
+      }
+      DMI_M_HIP(m, hipEventRecord(r.summed[s], r.compute));
+      DMI_M_HIP(m, hipStreamWaitEvent(r.comm, r.summed[s], 0));
+      if (c.count > 0) {
+        for (Rank &j : m->ranks) {
+          if (j.rank == r.rank) continue;
+          DMI_M_HIP(m, hipMemcpyPeerAsync(static_cast<char *>(grids[(size_t)j.rank]) + c.first * (int64_t)esz, j.device,
+                                          static_cast<char *>(grids[(size_t)r.rank]) + c.first * (int64_t)esz, r.device,
+                                          (size_t)c.count * esz, r.comm));
+        }
+      }
+      DMI_M_HIP(m, hipEventRecord(r.gathered[s], r.comm));
+    }
+    return DMI_OK;
+  };
+
+  for (int s = 0; s < n_rounds; ++s) {
+    const int64_t e0 = (int64_t)m->slab_z[s] * plane, e1 = e0 + (int64_t)m->slab_n[s] * plane;
+    const int64_t q = chunk_quantum(e1 - e0, world);
+    for (Rank &r : m->ranks) {
+      DMI_M_HIP(m, hipSetDevice(r.device));
+      if (by_slabs && r.n_views > 0) DMI_M_CTX(m, r, dmi_fuse_slab(r.ctx, m->slab_z[s], m->slab_n[s]));
+      if (!grids[(size_t)r.rank]) DMI_M_CTX(m, r, dmi_grid_device_pointer(r.ctx, &grids[(size_t)r.rank]));
+      DMI_M_HIP(m, hipEventRecord(r.slab_done[s], r.compute));
+      DMI_M_HIP(m, hipStreamWaitEvent(r.comm, r.slab_done[s], 0));
+    }
+    for (Rank &j : m->ranks) {  // rank j's chunk r of the slab into rank r's staging
+      DMI_M_HIP(m, hipSetDevice(j.device));
+      for (Rank &r : m->ranks) {
+        if (r.rank == j.rank) continue;
+        const Chunk c = chunk_of(e0, e1, world, r.rank);
+        if (c.count == 0) continue;
+        char *dst = static_cast<char *>(r.staging) + (stage_off[(size_t)s] + (int64_t)slot_of(j.rank, r.rank) * q) * (int64_t)esz;
+        DMI_M_HIP(m, hipMemcpyPeerAsync(dst, r.device, static_cast<char *>(grids[(size_t)j.rank]) + c.first * (int64_t)esz, j.device,
+                                        (size_t)c.count * esz, j.comm));
+      }
+      DMI_M_HIP(m, hipEventRecord(j.copied[s], j.comm));
+    }
+    if (s > 0) {
+      int rc = sum_and_gather(s - 1);
+      if (rc != DMI_OK) return rc;
+    }
+  }
+  int rc = sum_and_gather(n_rounds - 1);
+  if (rc != DMI_OK) return rc;
+  // whoever touches a grid next on its compute stream sees every chunk's sum
+  for (Rank &r : m->ranks) {
+    DMI_M_HIP(m, hipSetDevice(r.device));
+    for (Rank &j : m->ranks)
+      for (int s = 0; s < n_rounds; ++s)
+        if (j.rank != r.rank) DMI_M_HIP(m, hipStreamWaitEvent(r.compute, j.gathered[s], 0));
+  }
+  return DMI_OK;
+}
+
 template <typename T>
 int download_impl(dmi_multi_context *m, T *out, int64_t *owned_first, int64_t *owned_count) {
   if (!m || !out) return mfail(m, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_download_grid: null argument");
@@ -327,7 +483,7 @@ int download_impl(dmi_multi_context *m, T *out, int64_t *owned_first, int64_t *o
       n = ((int64_t)r.z_first + r.z_count) * plane - lo;
     }
     if (lo < 0) lo = 0;
-  } else if (m->opt.exchange == DMI_EXCHANGE_ALL_REDUCE || m->world == 1) {
+  } else if (m->opt.exchange != DMI_EXCHANGE_REDUCE_SCATTER || m->world == 1) {  // all-reduce, by RCCL or by peer copies
     DMI_M_CTX(m, m->ranks[0], fetch(m->ranks[0], out));
     n = m->n_voxels;
   } else {
@@ -397,6 +553,14 @@ int dmi_multi_z_slab(int32_t nz, int32_t rank, int32_t world, int32_t *z_first, 
   return DMI_OK;
 }
 
+int dmi_multi_peer_chunk(int64_t n, int32_t world, int32_t c, int64_t *first, int64_t *count) {
+  if (!first || !count || n < 0 || world < 1 || c < 0 || c >= world) return DMI_ERR_INVALID_ARGUMENT;
+  const Chunk k = chunk_of(0, n, world, c);
+  *first = k.first;
+  *count = k.count;
+  return DMI_OK;
+}
+
 int dmi_multi_slab_ranges(int32_t nz, int32_t n_slabs, int32_t *z_first, int32_t *z_count, int32_t max_slabs) {
   if (!z_first || !z_count || nz < 1 || max_slabs < 1) return 0;
   const int64_t align = DMI_SLAB_ALIGNMENT;
@@ -458,12 +622,17 @@ int dmi_multi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, co
     if (opt) o = *opt;
     int rc = check_common(grid, ray, o, n);
     if (rc != DMI_OK) return rc;
+    if (o.partition == DMI_PARTITION_VIEWS && o.exchange == DMI_EXCHANGE_PEER_COPY && n > kMaxPeerRanks)
+      return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: DMI_EXCHANGE_PEER_COPY serves at most 16 ranks");
     const int ndev = dmi_device_count();
     if (ndev <= 0) return mfail(nullptr, DMI_ERR_DEVICE, "dmi_multi_create: no HIP device available");
     for (int32_t i = 0; i < n; ++i) {
       if (devices[i] < 0 || devices[i] >= ndev) return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: device ordinal out of range");
+      // (the peer-copy exchange has no communicator that would object: several of its ranks may share a device, which is
+      // how a one-GPU box rehearses every step of it)
       for (int32_t j = 0; j < i; ++j)
-        if (devices[j] == devices[i]) return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: a device is listed twice");
+        if (devices[j] == devices[i] && !(o.partition == DMI_PARTITION_VIEWS && o.exchange == DMI_EXCHANGE_PEER_COPY))
+          return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create: a device is listed twice");
     }
     dmi_multi_context *m = new_context(grid, ray, o, n);
     if (!m) return mfail(nullptr, DMI_ERR_OUT_OF_MEMORY, "dmi_multi_create: host allocation failed");
@@ -480,7 +649,11 @@ int dmi_multi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, co
       rc = init_rank(m, m->ranks[(size_t)i]);
       if (rc != DMI_OK) return give_up(rc);
     }
-    if (needs_comm(m->opt)) {
+    if (needs_comm(m->opt) && !needs_rccl(m->opt)) {
+      rc = init_peer_exchange(m);
+      if (rc != DMI_OK) return give_up(rc);
+    }
+    if (needs_rccl(m->opt)) {
       m->rccl = load_rccl();
       if (!m->rccl->handle) {
         m->err = "dmi_multi_create: " + m->rccl->error;
@@ -511,6 +684,10 @@ int dmi_multi_create_rank(const dmi_grid_desc *grid, const dmi_ray_potential *ra
     int rc = check_common(grid, ray, o, world);
     if (rc != DMI_OK) return rc;
     if (rank < 0 || rank >= world) return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create_rank: rank out of range");
+    if (o.partition == DMI_PARTITION_VIEWS && o.exchange == DMI_EXCHANGE_PEER_COPY)
+      return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT,
+                   "dmi_multi_create_rank: DMI_EXCHANGE_PEER_COPY needs every rank in one process (dmi_multi_create); ranks in "
+                   "processes of their own would have to exchange IPC memory handles, which this library does not do");
     if (needs_comm(o) && !id) return mfail(nullptr, DMI_ERR_INVALID_ARGUMENT, "dmi_multi_create_rank: the VIEWS partition needs a unique id");
     const int ndev = dmi_device_count();
     if (ndev <= 0) return mfail(nullptr, DMI_ERR_DEVICE, "dmi_multi_create_rank: no HIP device available");
@@ -565,6 +742,12 @@ void dmi_multi_destroy(dmi_multi_context *m) {
     if (r.ctx) dmi_destroy(r.ctx);  // before its stream
     for (int s = 0; s < kMaxSlabs; ++s)
       if (r.slab_done[s]) (void)hipEventDestroy(r.slab_done[s]);
+    for (int s = 0; s < kMaxSlabs; ++s) {
+      if (r.copied[s]) (void)hipEventDestroy(r.copied[s]);
+      if (r.summed[s]) (void)hipEventDestroy(r.summed[s]);
+      if (r.gathered[s]) (void)hipEventDestroy(r.gathered[s]);
+    }
+    if (r.staging) (void)hipFree(r.staging);
     if (r.exchanged) (void)hipEventDestroy(r.exchanged);
     if (r.step_start) (void)hipEventDestroy(r.step_start);
     if (r.step_stop) (void)hipEventDestroy(r.step_stop);
@@ -626,7 +809,8 @@ int dmi_multi_fuse(dmi_multi_context *m) {
     int rc = drain_step(m);
     if (rc != DMI_OK) return rc;
     const bool exchange = needs_comm(m->opt);
-    const bool by_slabs = exchange && m->opt.exchange == DMI_EXCHANGE_ALL_REDUCE && m->n_slab_ranges > 1;
+    const bool peer = exchange && m->opt.exchange == DMI_EXCHANGE_PEER_COPY;
+    const bool by_slabs = exchange && (peer || m->opt.exchange == DMI_EXCHANGE_ALL_REDUCE) && m->n_slab_ranges > 1;
     const ncclDataType_t dtype = m->opt.grid_dtype == DMI_F64 ? ncclDouble : ncclFloat;
     const size_t esz = grid_elem(m);
     const int64_t plane = (int64_t)m->grid.cell_dims[0] * m->grid.cell_dims[1];
@@ -654,7 +838,10 @@ int dmi_multi_fuse(dmi_multi_context *m) {
       for (Rank &r : m->ranks)
         if (r.ctx && r.n_views > 0) DMI_M_CTX(m, r, dmi_fuse(r.ctx));
     }
-    if (exchange) {
+    if (peer) {
+      int rc_peer = peer_exchange(m, by_slabs, grids);
+      if (rc_peer != DMI_OK) return rc_peer;
+    } else if (exchange) {
       const int n_rounds = by_slabs ? m->n_slab_ranges : 1;
       for (int s = 0; s < n_rounds; ++s) {
         const int32_t z0 = by_slabs ? m->slab_z[s] : 0, zc = by_slabs ? m->slab_n[s] : m->grid.cell_dims[2];

@@ -287,4 +287,12 @@ hipError_t launch_order_bricks(const TileArgs &args, int wx, int wy, uint8_t *le
 hipError_t launch_cell_to_point(const void *cells, int cells_are_f64, double *points, int nx, int ny, int nz,
                                 hipStream_t stream);
 
+// Iso-value pre-pass over the point data (grid_post.hip): blocks of 256 cells of one x-row; counts / bases have
+// iso_block_count() + 1 entries (bases' last one receives the total number of active cells)
+size_t iso_block_count(int nx, int ny, int nz);
+hipError_t launch_iso_count(const double *points, int nx, int ny, int nz, double iso, uint32_t *counts, uint64_t *bases,
+                            void *scan_temp, size_t *scan_temp_bytes, hipStream_t stream);
+hipError_t launch_iso_write(const double *points, int nx, int ny, int nz, double iso, const uint64_t *bases, int64_t *ids,
+                            uint64_t capacity, hipStream_t stream);
+
 }  // namespace dmi

@@ -8,6 +8,11 @@
 // is exact and only the order of the additions matters; oracle/tsdf_oracle.c (oracle_cell_to_point) states the
 // same loop on the CPU and the GPU result is bit-identical to it.
 #include <stdlib.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
 
 #include "fusion_kernels.h"
 
@@ -106,7 +111,82 @@ void launch_typed(const GridT *cells, double *points, int nx, int ny, int nz, hi
   return launch_kz<GridT, 8, 4>(cells, points, nx, ny, nz, stream);  // profiles/r01w_cell_to_point_tuning.json, r05i
 }
 
+// ---- iso-value pre-pass ------------------------------------------------------------------------------------------
+// Reconstruction/main.cxx:169-173 contours the point data at `contour` (vtkContourFilter -> marching cubes): every cell is
+// visited and its eight corner values compared with the iso-value; only the cells whose corners are not all on one side
+// produce triangles.  This pass marks those cells on the GPU -- corner c is "inside" when value >= iso (the marching-cubes
+// case index's bit, a NaN is outside), a cell is ACTIVE when 0 < inside corners < 8 -- so that a host marching cubes can
+// visit them alone.  Cells are taken in rows of x: block b handles 256 consecutive cells of one (j, k) row, so block
+// order is the cells' linear order and the compacted list comes out ascending.
+constexpr int kIsoBlock = 256;
+
+__device__ __forceinline__ bool iso_cell_active(const double *__restrict__ points, int nx, int ny, int i, int j, int k, double iso) {
+  const int64_t prow = nx + 1, pplane = (int64_t)(nx + 1) * (ny + 1);
+  const double *p = points + (int64_t)k * pplane + (int64_t)j * prow + i;
+  int inside = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const double v = p[(c & 1) + ((c >> 1) & 1) * prow + (c >> 2) * pplane];
+    inside += v >= iso ? 1 : 0;
+  }
+  return inside != 0 && inside != 8;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kIsoBlock) void iso_cells_kernel(const double *__restrict__ points, int nx, int ny, int nz,
+                                                              int blocks_per_row, double iso, uint32_t *__restrict__ counts,
+                                                              const uint64_t *__restrict__ bases, int64_t *__restrict__ ids,
+                                                              uint64_t capacity) {
+  __shared__ uint32_t wave_counts[kIsoBlock / 64];
+  const int64_t row = blockIdx.x / blocks_per_row;  // = k * ny + j
+  const int i = (int)(blockIdx.x - row * blocks_per_row) * kIsoBlock + threadIdx.x;
+  const int k = (int)(row / ny), j = (int)(row - (int64_t)k * ny);
+  const bool active = i < nx && iso_cell_active(points, nx, ny, i, j, k, iso);
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(active);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_counts[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if constexpr (!WRITE) {
+    if (threadIdx.x == 0) {
+      uint32_t n = 0;
+      for (int w = 0; w < kIsoBlock / 64; ++w) n += wave_counts[w];
+      counts[blockIdx.x] = n;
+    }
+  } else {
+    if (!active) return;
+    uint64_t pos = bases[blockIdx.x];
+    for (int w = 0; w < wave; ++w) pos += wave_counts[w];
+    pos += (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < capacity) ids[pos] = row * nx + i;  // the cell's linear id, x fastest (cu:126-134)
+  }
+}
+
 }  // namespace
+
+size_t iso_block_count(int nx, int ny, int nz) { return (size_t)((nx + kIsoBlock - 1) / kIsoBlock) * (size_t)ny * (size_t)nz; }
+
+// counts[b] = active cells of block b, bases[b] = their exclusive prefix sum, *(bases + n_blocks) = the total
+hipError_t launch_iso_count(const double *points, int nx, int ny, int nz, double iso, uint32_t *counts, uint64_t *bases,
+                            void *scan_temp, size_t *scan_temp_bytes, hipStream_t stream) {
+  const size_t n_blocks = iso_block_count(nx, ny, nz);
+  if (!scan_temp) {  // size query
+    return rocprim::exclusive_scan(nullptr, *scan_temp_bytes, counts, bases, (uint64_t)0, n_blocks + 1, rocprim::plus<uint64_t>(), stream);
+  }
+  hipLaunchKernelGGL((iso_cells_kernel<false>), dim3((unsigned)n_blocks), dim3(kIsoBlock), 0, stream, points, nx, ny, nz,
+                     (nx + kIsoBlock - 1) / kIsoBlock, iso, counts, (const uint64_t *)nullptr, (int64_t *)nullptr, (uint64_t)0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // n_blocks + 1 inputs (the last one a zero the caller keeps there): bases[n_blocks] is the total
+  return rocprim::exclusive_scan(scan_temp, *scan_temp_bytes, counts, bases, (uint64_t)0, n_blocks + 1, rocprim::plus<uint64_t>(), stream);
+}
+
+hipError_t launch_iso_write(const double *points, int nx, int ny, int nz, double iso, const uint64_t *bases, int64_t *ids,
+                            uint64_t capacity, hipStream_t stream) {
+  const size_t n_blocks = iso_block_count(nx, ny, nz);
+  hipLaunchKernelGGL((iso_cells_kernel<true>), dim3((unsigned)n_blocks), dim3(kIsoBlock), 0, stream, points, nx, ny, nz,
+                     (nx + kIsoBlock - 1) / kIsoBlock, iso, (uint32_t *)nullptr, bases, ids, capacity);
+  return hipGetLastError();
+}
 
 hipError_t launch_cell_to_point(const void *cells, int cells_are_f64, double *points, int nx, int ny, int nz,
                                 hipStream_t stream) {

@@ -408,6 +408,10 @@ int Run(const Options &o, int argc, const char *const *argv, std::ostream &log, 
     if (rc == DMI_OK) rc = dmi_upload_grid(ctx, cells.data());
     if (rc == DMI_OK) rc = dmi_cell_to_point(ctx);
     if (rc == DMI_OK) rc = dmi_download_point_data_f64(ctx, points.data());
+    // the contour filter's pre-pass (rmain:169-173): the cells whose corners straddle --contour
+    uint64_t active = 0;
+    if (rc == DMI_OK) rc = dmi_iso_active_cells(ctx, o.contour, &active, nullptr, 0);
+    result->contourActiveCells = active;
     if (rc != DMI_OK) result->error = std::string("cell data -> point data: ") + dmi_last_error(ctx);
     if (ctx) dmi_destroy(ctx);
     if (rc != DMI_OK) return 1;
@@ -417,7 +421,10 @@ int Run(const Options &o, int argc, const char *const *argv, std::ostream &log, 
     result->error = error;
     return 1;
   }
-  say("** Compute contour... (not part of this tool: " + o.outputMeshFilename + " is not written)");
+  // Said whatever --verbose is: the reference writes a mesh here (rmain:166-187) and this tool does not.
+  log << "warning: " << o.outputMeshFilename << " is NOT written: the iso-surface (vtkContourFilter) is not part of this tool; "
+      << result->contourActiveCells << " of " << (long long)(dims[0] - 1) * (dims[1] - 1) * (dims[2] - 1)
+      << " cells straddle the contour value " << o.contour << std::endl;
   say("** Save volume...");
   if (!WriteStructuredGrid(o.outputGridFilename, dims, origin, spacing, matrix, cells.data(), ReconstructionFilter::OutputArrayName(),
                            &error)) {
@@ -432,6 +439,7 @@ int Run(const Options &o, int argc, const char *const *argv, std::ostream &log, 
     for (int i = 0; i < argc; ++i) out << " " << argv[i];
     out << "\noutput volume  " << o.outputGridFilename << "\n";
     describe(o, out, false);
+    out << "contour\n  cells straddling the value  " << result->contourActiveCells << " (no surface extracted)\n";
     out << "time\n  reconstruction  " << result->reconstructionSeconds << " s\n  total           " << result->totalSeconds << " s\n";
   }
   say("---END---");

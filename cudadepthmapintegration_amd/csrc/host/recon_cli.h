@@ -45,6 +45,8 @@ std::string HelpText();
 
 struct RunResult {
   double reconstructionSeconds = 0.0, totalSeconds = 0.0;
+  // cells of the point lattice whose corners straddle --contour (dmi_iso_active_cells): what a marching cubes would visit
+  unsigned long long contourActiveCells = 0;
   std::string error;  // empty on success
 };
 // rmain:97-213 without the contour: 0 on success.  `log` receives what --verbose prints.

@@ -153,7 +153,9 @@ class FusionDriver {
 
   int Device = 0;
   std::vector<int> Devices;
-  int Partition = DMI_PARTITION_VIEWS;
+  // several GPUs: z-slabs by default -- the reference's f64 grid, bit-identical to one GPU, no exchange; the north star's
+  // depth-map shards + f32 all-reduce (DMI_PARTITION_VIEWS: tolerance include/dmi.h states) are an explicit choice
+  int Partition = DMI_PARTITION_Z_SLABS;
   int KernelVariant = 0;
   size_t HostChunkBytes = size_t(256) << 20;
   double FuseKernelMs = 0.0;
@@ -225,7 +227,9 @@ class ReconstructionFilter {
   std::string Error;
   int Device = 0, KernelVariant = 0;
   std::vector<int> Devices;
-  int Partition = DMI_PARTITION_VIEWS;
+  // several GPUs: z-slabs by default -- the reference's f64 grid, bit-identical to one GPU, no exchange; the north star's
+  // depth-map shards + f32 all-reduce (DMI_PARTITION_VIEWS: tolerance include/dmi.h states) are an explicit choice
+  int Partition = DMI_PARTITION_Z_SLABS;
   size_t HostChunkBytes = size_t(256) << 20;
   bool FillOnCallingThread = false;
   double FuseKernelMs = 0.0;

@@ -41,6 +41,11 @@ def slab_ranges(nz: int, n_slabs: int) -> list[tuple[int, int]]:
     return capi.multi_slab_ranges(nz, n_slabs)
 
 
+def peer_chunk(n: int, world: int, c: int) -> tuple[int, int]:
+    """DMI_EXCHANGE_PEER_COPY: the piece (first, count) of an n-element slab that rank c sums, in rank order, and hands back."""
+    return capi.multi_peer_chunk(n, world, c)
+
+
 def sharded_tolerance(world: int, abs_partial_sum):
     """Bound on |all-reduced f32 grid - single-GPU f64 grid| per voxel: each rank rounds its partial to f32
     (2^-24 relative), the reduction adds world-1 f32 roundings of partial sums, fp64 reordering is

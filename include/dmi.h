@@ -202,6 +202,14 @@ int dmi_cell_to_point(dmi_context *ctx);
 int dmi_download_point_data_f64(dmi_context *ctx, double *out);
 int dmi_point_data_device_pointer(dmi_context *ctx, void **ptr);
 
+/* The pre-pass of the step after that (Reconstruction/main.cxx:169-173: vtkContourFilter at `contour` over the point data,
+ * i.e. marching cubes over every cell): which cells can produce triangles at all.  A corner is inside when its point value
+ * is >= iso (the marching-cubes case bit; a NaN is outside); a cell is ACTIVE when it has both inside and outside corners.
+ * *count receives the number of active cells; cell_ids (nullable) the first min(*count, capacity) of them as linear cell
+ * ids (k*ny + j)*nx + i in ascending order -- the cells a host marching cubes has to visit, instead of all of them.  Runs
+ * dmi_cell_to_point first if the grid changed.  Synchronises. */
+int dmi_iso_active_cells(dmi_context *ctx, double iso, uint64_t *count, int64_t *cell_ids, uint64_t capacity);
+
 /* Diagnostic: how many (8 x 8 x column brick, view) pairs of the last dmi_fuse were proven to be handled
  * uniformly.  out[0] mixed (per-voxel path), out[1] all voxels accumulate -eta*rho, out[2] all accumulate 0,
  * out[3] no voxel reaches the accumulate.  All zero when the last fuse ran the general kernel or classes
@@ -286,11 +294,19 @@ int dmi_color_get_kernel_ms(dmi_color_context *ctx, double *out);
  *                                while slab i+1 is fused; the last slab is the thinnest (its exchange is the only part
  *                                nothing hides).
  *   DMI_EXCHANGE_REDUCE_SCATTER  for when only the host consumes the grid: rank r ends with the sum of its own 1/world
- *                                of the grid (half the xGMI traffic) and downloads just that. */
+ *                                of the grid (half the xGMI traffic) and downloads just that.
+ *   DMI_EXCHANGE_PEER_COPY       the all-reduce without RCCL and without a compute unit for the transfers (ranks of ONE
+ *                                process, dmi_multi_create; at most 16): behind every slab each rank sends the others their
+ *                                1/world chunk of it with peer-to-peer copies (the SDMA engines, all xGMI links at once),
+ *                                adds what it received to its own chunk IN RANK ORDER with a small kernel queued behind its
+ *                                fusion, and copies the sum back into every grid.  Same contract as ALL_REDUCE (every rank
+ *                                ends with the whole summed grid) and the same tolerance; unlike a ring's, the order of the
+ *                                additions is fixed: the result is the same bits on every run and on every rank.  Several
+ *                                of its ranks may share a device (rehearsals on a one-GPU box). */
 typedef struct dmi_multi_context dmi_multi_context;
 
 typedef enum dmi_partition { DMI_PARTITION_VIEWS = 0, DMI_PARTITION_Z_SLABS = 1 } dmi_partition;
-typedef enum dmi_exchange { DMI_EXCHANGE_ALL_REDUCE = 0, DMI_EXCHANGE_REDUCE_SCATTER = 1 } dmi_exchange;
+typedef enum dmi_exchange { DMI_EXCHANGE_ALL_REDUCE = 0, DMI_EXCHANGE_REDUCE_SCATTER = 1, DMI_EXCHANGE_PEER_COPY = 2 } dmi_exchange;
 
 #define DMI_UNIQUE_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
 
@@ -336,6 +352,9 @@ int dmi_multi_view_shard(int64_t n, int32_t rank, int32_t world, int64_t *first,
  * may own nothing when nz is small */
 #define DMI_Z_SLAB_ALIGNMENT 16
 int dmi_multi_z_slab(int32_t nz, int32_t rank, int32_t world, int32_t *z_first, int32_t *z_count);
+/* DMI_EXCHANGE_PEER_COPY: the piece [*first, *first + *count) of an n-element slab that rank `c` sums and hands back
+ * (pieces are multiples of 256 elements; the last ranks' may be short or empty) */
+int dmi_multi_peer_chunk(int64_t n, int32_t world, int32_t c, int64_t *first, int64_t *count);
 /* the z-slabs of the overlapped exchange: writes at most max_slabs (z_first, z_count) pairs, returns how many */
 int dmi_multi_slab_ranges(int32_t nz, int32_t n_slabs, int32_t *z_first, int32_t *z_count, int32_t max_slabs);
 

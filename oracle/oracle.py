@@ -74,6 +74,9 @@ def lib() -> ctypes.CDLL:
                                         ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)]
         L.oracle_cell_to_point.restype = None
         L.oracle_cell_to_point.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
+        L.oracle_iso_active_cells.restype = ctypes.c_int64
+        L.oracle_iso_active_cells.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_int64]
         _lib = L
     return _lib
 
@@ -206,6 +209,18 @@ def color_mesh(points, colors, K4, RT4):
     lib().oracle_color_mesh(_dp(pts), nv, col.ctypes.data_as(u8), _dp(K4), _dp(RT4), n, W, H, mean.ctypes.data_as(u8),
                             median.ctypes.data_as(u8), count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     return mean, median, count
+
+
+def iso_active_cells(points, iso: float) -> np.ndarray:
+    """Linear ids (ascending) of the cells whose eight corner point values straddle `iso` -- the cells marching cubes can
+    get triangles from (Reconstruction/main.cxx:169-173).  points [nz+1,ny+1,nx+1] f64."""
+    p = _c64(points)
+    nz, ny, nx = (d - 1 for d in p.shape)
+    n = int(lib().oracle_iso_active_cells(_dp(p), nx, ny, nz, float(iso), None, 0))
+    ids = np.zeros(n, dtype=np.int64)
+    if n:
+        lib().oracle_iso_active_cells(_dp(p), nx, ny, nz, float(iso), ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n)
+    return ids
 
 
 def cell_to_point(cells) -> np.ndarray:

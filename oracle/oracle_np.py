@@ -146,3 +146,13 @@ def cell_to_point_np(cells):
         m = shifted(valid, dx, dy, dz)
         out = np.where(m, out + w * shifted(pad, dx, dy, dz), out)
     return out
+
+
+def iso_active_cells_np(points, iso):
+    """Independent restatement of oracle_iso_active_cells: eight shifted views of the point lattice, corner >= iso."""
+    p = np.asarray(points, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        ge = p >= iso
+    inside = sum(ge[dz:ge.shape[0] - 1 + dz, dy:ge.shape[1] - 1 + dy, dx:ge.shape[2] - 1 + dx].astype(np.int32)
+                 for dz in (0, 1) for dy in (0, 1) for dx in (0, 1))
+    return np.flatnonzero(((inside > 0) & (inside < 8)).reshape(-1)).astype(np.int64)

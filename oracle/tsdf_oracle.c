@@ -280,6 +280,31 @@ void oracle_cell_to_point(const double *cells, int nx, int ny, int nz, double *p
       }
 }
 
+/* Reconstruction/main.cxx:169-173: vtkContourFilter (SetValue(0, contourValue)) over the point data -- marching cubes.
+ * VTK is absent from this image; restated from its published algorithm (vtkMarchingCubes / the image-data contour path):
+ * for every cell the case index collects one bit per corner, set when `s[corner] >= value`; index 0 and index 255 produce
+ * no triangle.  So the cells that can contribute are those with 0 < (corners >= iso) < 8; a NaN corner compares false
+ * (outside).  points [(nz+1)][(ny+1)][(nx+1)] x fastest; writes the first `capacity` active cells' linear ids
+ * (k*ny + j)*nx + i in ascending order to ids (nullable) and returns how many cells are active. */
+int64_t oracle_iso_active_cells(const double *points, int nx, int ny, int nz, double iso, int64_t *ids, int64_t capacity)
+{
+  int64_t n = 0;
+  const int64_t prow = nx + 1, pplane = (int64_t)(nx + 1) * (ny + 1);
+  for (int k = 0; k < nz; ++k)
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        int inside = 0;
+        for (int c = 0; c < 8; ++c)
+          inside += points[(k + (c >> 2)) * pplane + (j + ((c >> 1) & 1)) * prow + i + (c & 1)] >= iso ? 1 : 0;
+        if (inside == 0 || inside == 8)
+          continue;
+        if (ids && n < capacity)
+          ids[n] = ((int64_t)k * ny + j) * nx + i;
+        ++n;
+      }
+  return n;
+}
+
 /* Exposed for known-answer tests of the ray-potential function alone. */
 double oracle_ray_potential(const oracle_params *p, double real_distance, double depth_map_distance)
 {

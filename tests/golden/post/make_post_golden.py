@@ -40,6 +40,18 @@ def main():
     q = oracle_np.cell_to_point_np(cells)
     assert p.tobytes() == q.tobytes(), "cell_to_point: C and numpy oracles disagree"
     np.savez_compressed(os.path.join(HERE, "cell_to_point.npz"), cells=cells, expected_points=p)
+    # iso-value pre-pass (Reconstruction/main.cxx:169-173): the cells of that point lattice whose corners straddle the
+    # iso-value; values equal to the iso-value (>= counts as inside), a NaN (outside) and both infinities among the corners
+    pts = p.copy()
+    iso = 0.25
+    pts[1, 2, 3] = iso
+    pts[2, 2, 2] = np.nan
+    pts[3, 1, 4] = np.inf
+    pts[0, 5, 8] = -np.inf
+    ids = oracle.iso_active_cells(pts, iso)
+    assert np.array_equal(ids, oracle_np.iso_active_cells_np(pts, iso)), "iso pre-pass: C and numpy oracles disagree"
+    assert 0 < ids.size < cells.size
+    np.savez_compressed(os.path.join(HERE, "iso_cells.npz"), points=pts, iso=iso, expected_ids=ids)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

@@ -147,5 +147,10 @@ def test_cli_end_to_end(tmp_path):
     dims, fields, pts = _read_mha(str(tmp_path / "meta_image_volume.mha"))
     assert dims == list(o.grid_dims)
     assert bits_equal(pts.reshape(dims[2], dims[1], dims[0]), oracle.cell_to_point(want))
-    assert os.path.exists(data / "summary.txt") and "reconstruction" in open(data / "summary.txt").read()
+    summary = open(data / "summary.txt").read()
+    assert "reconstruction" in summary
+    # no mesh: said so whatever --verbose is, with the iso-value pre-pass's count of the cells a contour filter would visit
     assert not os.path.exists(tmp_path / "mesh.vtp")
+    assert "is NOT written" in r.stdout + r.stderr
+    n_active = oracle.iso_active_cells(oracle.cell_to_point(want), float(o.contour)).size
+    assert f"cells straddling the value  {n_active} " in summary and f" {n_active} of " in r.stdout + r.stderr

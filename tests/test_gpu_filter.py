@@ -100,7 +100,7 @@ def test_filter_rejects_mismatching_view_sizes():
         assert f.Update() == 0 and "size" in f.LastError()
 
 
-@pytest.mark.parametrize("partition", ["views", "z_slabs"])
+@pytest.mark.parametrize("partition", ["views", "z_slabs", None])
 def test_filter_on_a_device_list_runs_through_the_multi_gpu_path(partition, tmp_path):
     """SetDevices([0]): the filter drives dmi_multi_* (world = 1 on this box).  z-slabs keep the reference's f64 grid
     and are bit-identical to the oracle; depth-map shards use the north star's f32 grid: exactly one f32 rounding of
@@ -116,11 +116,12 @@ def test_filter_on_a_device_list_runs_through_the_multi_gpu_path(partition, tmp_
         f.SetFilePathVTI(lv)
         f.SetFilePathKRTD(lk)
         f.SetDevices([0])
-        f.SetPartition(partition)
+        if partition is not None:   # default: z-slabs (f64, bit-identical to one GPU); depth-map shards are opted into
+            f.SetPartition(partition)
         assert f.Update() == 1, f.LastError()
         out = f.GetOutputScalars()
         assert f.GetFuseKernelMs() > 0
-    if partition == "z_slabs":
+    if partition in ("z_slabs", None):
         assert bits_equal(out, want)
     else:
         assert np.array_equal(out, want.astype(np.float32).astype(np.float64))

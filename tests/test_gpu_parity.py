@@ -501,6 +501,78 @@ def test_multi_context_with_one_rank_equals_plain_fuse(mode, exchange):
     assert np.array_equal(got64, plain.astype(np.float64))
 
 
+@pytest.mark.parametrize("world,n_slabs,grid_dtype", [(1, 3, "f32"), (2, 1, "f32"), (2, 3, "f32"), (4, 4, "f32"), (3, 2, "f64")])
+def test_peer_copy_exchange_with_ranks_sharing_this_gpu(world, n_slabs, grid_dtype):
+    """DMI_EXCHANGE_PEER_COPY (reduce-scatter + all-gather by hipMemcpyPeerAsync, the sum a kernel behind the fusion, no
+    RCCL): its ranks may share a device, so this one GPU runs the whole choreography with 2, 3 and 4 ranks -- every slab,
+    every chunk, every copy, event and sum.  The additions are in rank order, one rounding each in the grid's type, so the
+    expectation is exact: sum over the ranks, in order, of each rank's own fusion of its view shard.  Every rank must end
+    with those bits; a second step starts from zeros again."""
+    grid = scene.default_grid((40, 33, 100))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(7, 80, 60, seed=29, dense=True, dtype=np.float32)
+    np_t = np.float32 if grid_dtype == "f32" else np.float64
+    expect = None
+    for r in range(world):
+        lo, hi = capi.multi_view_shard(views.n, r, world)
+        with capi.FusionContext(grid, rp, grid_dtype=grid_dtype) as ctx:
+            if hi > lo:
+                ctx.add_views(views.subset(lo, hi))
+                ctx.fuse()
+            part = ctx.download_grid(np_t).copy()
+        expect = part if expect is None else (expect + part).astype(np_t)
+    with capi.MultiContext(grid, rp, devices=[0] * world, grid_dtype=grid_dtype, exchange="peer_copy", n_slabs=n_slabs) as m:
+        m.add_views(views)          # one batch: rank r takes multi_view_shard(7, r, world), as the expectation above does
+        for _ in range(2):
+            m.fuse()
+        got, (first, count) = m.download_grid(np_t)
+        info = m.info()
+        assert (info.world, info.n_local, info.rccl_ranks, info.rccl_version) == (world, world, 0, 0)   # RCCL never loaded
+        assert (first, count) == (0, grid.n_voxels)
+        assert bits_equal(got.astype(np.float64), expect.astype(np.float64))
+        for i in range(1, world):   # every rank holds the same bits, not only rank 0
+            ctx_i = m.local_context_grid(i, np_t)
+            assert bits_equal(ctx_i.astype(np.float64), expect.astype(np.float64)), i
+        t = m.timings()
+        assert t.steps >= 2 and t.last_step_ms > 0
+    assert np.abs(expect).max() > 0.5
+
+
+def test_peer_copy_exchange_needs_one_process():
+    grid = scene.default_grid((16, 16, 32))
+    rp = scene.default_ray_potential(grid)
+    with pytest.raises(capi.DmiError) as e:
+        capi.MultiContext(grid, rp, rank=0, world=2, unique_id=None, device=0, exchange="peer_copy")
+    assert e.value.code == 1 and "one process" in str(e.value)
+    with pytest.raises(capi.DmiError) as e:      # the RCCL exchanges keep refusing a device listed twice
+        capi.MultiContext(grid, rp, devices=[0, 0], exchange="all_reduce")
+    assert "twice" in str(e.value)
+
+
+def test_z_slab_rank_without_a_cell_layer_keeps_its_step_clock():
+    """A z-slab rank of a short grid owns nothing (nz < 16 * world) and has no context: its steps are empty, but fuse /
+    synchronize / timings / download must all work on it (one rank per process, as bench.py launches them; no GPU work
+    crosses ranks under this partition, so each rank of the would-be world can be played here in turn)."""
+    grid = scene.default_grid((24, 20, 40))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(3, 64, 48, seed=5, dense=True)
+    want, _, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4)
+    out = np.zeros(grid.n_voxels)
+    owned = 0
+    for rank in range(8):   # 40 layers = 3 units of 16: ranks 3..7 own none
+        with capi.MultiContext(grid, rp, rank=rank, world=8, device=0, grid_dtype="f64", partition="z_slabs") as m:
+            m.add_views(views)
+            for _ in range(2):
+                m.fuse()
+            m.synchronize()
+            t = m.timings()
+            assert t.steps == 2
+            _, (first, count) = m.download_grid(np.float64, out=out)
+            owned += count
+            assert (count == 0) == (rank >= 3)
+    assert owned == grid.n_voxels and bits_equal(out.reshape(want.shape), want)
+
+
 def test_multi_context_z_slab_partition_is_bit_identical():
     """DMI_PARTITION_Z_SLABS with one rank: no communicator at all, f64 grid bit-identical to the oracle."""
     grid = scene.default_grid((40, 24, 37))

@@ -89,6 +89,31 @@ def _worker(rank, world, port, out_dir):
         dist.all_reduce(g32.view(-1)[z0 * plane:(z0 + zc) * plane], op=dist.ReduceOp.SUM)
     dist.all_reduce(absum, op=dist.ReduceOp.SUM)
     dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+    # the same exchange the third way (DMI_EXCHANGE_PEER_COPY): per slab, rank c collects every rank's chunk c, adds them in
+    # rank order -- one f32 rounding each -- and hands the sum back to everybody; point-to-point messages only
+    mine = torch.from_numpy(part.astype(np.float32)).view(-1)
+    for z0, zc in sharding.slab_ranges(grid.cell_dims[2], 2):
+        e0, n = z0 * plane, zc * plane
+        first, count = sharding.peer_chunk(n, world, rank)
+        own = mine[e0 + first:e0 + first + count]
+        received = {rank: own.clone()}
+        for other in range(world):                     # send the others their chunk of my grid, receive mine from them
+            if other == rank:
+                continue
+            f2, c2 = sharding.peer_chunk(n, world, other)
+            send = dist.isend(mine[e0 + f2:e0 + f2 + c2].clone(), dst=other)
+            buf = torch.empty(count, dtype=torch.float32)
+            dist.recv(buf, src=other)
+            send.wait()
+            received[other] = buf
+        total = received[0].clone()
+        for j in range(1, world):
+            total += received[j]                       # rank order
+        own.copy_(total)
+        for owner in range(world):                     # the all-gather
+            f2, c2 = sharding.peer_chunk(n, world, owner)
+            dist.broadcast(mine[e0 + f2:e0 + f2 + c2], src=owner)
+    np.save(os.path.join(out_dir, f"peer_{rank}.npy"), mine.numpy())
     # z-slab ownership: every rank fuses all views into its own layers
     z0, z1 = sharding.z_slab(grid.cell_dims[2], rank, world)
     if rank == 0:
@@ -116,6 +141,18 @@ def test_view_shards_plus_all_reduce_match_single_fusion(tmp_path):
     tol = sharding.sharded_tolerance(world, got["absum"])
     assert np.all(np.abs(got["grid"].astype(np.float64) - want) <= tol)    # stated float tolerance
     assert np.abs(want).max() > 0.1
+    # the peer-copy exchange: both ranks hold the same bits, exactly the rank-ordered f32 sum of the f32 partials
+    peers = [np.load(tmp_path / f"peer_{r}.npy") for r in range(world)]
+    parts = []
+    for r in range(world):
+        lo, hi = sharding.view_shard(views.n, r, world)
+        parts.append(oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth[lo:hi], views.K4[lo:hi], views.RT4[lo:hi])[0]
+                     .astype(np.float32).reshape(-1))
+    expect = parts[0]
+    for r in range(1, world):
+        expect = (expect + parts[r]).astype(np.float32)
+    assert all(np.array_equal(p.view(np.uint32), expect.view(np.uint32)) for p in peers)
+    assert np.all(np.abs(expect.astype(np.float64) - want.reshape(-1)) <= tol.reshape(-1))
     slabs = [tuple(np.load(tmp_path / f"slab_{r}.npy")) for r in range(world)]
     assert slabs[0][0] == 0 and slabs[-1][1] == 72 and slabs[0][1] == slabs[1][0] and slabs[0][1] % 16 == 0
 
@@ -162,3 +199,15 @@ def test_vertex_shards_of_the_coloration_pass_concatenate_to_the_whole(tmp_path)
     assert got["bounds"].tolist() == [[0, 251], [251, 501]]
     for name, w in zip(("mean", "median", "count"), want):
         assert np.array_equal(got[name], w), name
+
+
+def test_peer_chunks_tile_a_slab_and_short_grids_leave_ranks_empty():
+    for n, world in ((1, 1), (255, 2), (256, 2), (257, 3), (40 * 33 * 36, 8), (1 << 20, 7), (100, 16)):
+        pieces = [sharding.peer_chunk(n, world, c) for c in range(world)]
+        assert pieces[0][0] == 0 and sum(c for _, c in pieces) == n
+        for (f0, c0), (f1, _) in zip(pieces, pieces[1:]):
+            assert f1 == f0 + c0 and (c0 % 256 == 0 or f0 + c0 == n)
+    # z-slab partition of a short grid: ranks beyond nz / 16 own nothing (dmi_multi_fuse must cope: test_gpu_parity.py
+    # test_z_slab_rank_without_a_cell_layer_keeps_its_step_clock)
+    owned = [sharding.z_slab(40, r, 8) for r in range(8)]
+    assert owned[:3] == [(0, 16), (16, 32), (32, 40)] and all(z0 == z1 for z0, z1 in owned[3:])

@@ -30,7 +30,7 @@ vtkCxxSetObjectMacro(vtkCudaReconstructionFilter, GridMatrix, vtkMatrix4x4);
 vtkCudaReconstructionFilter::vtkCudaReconstructionFilter()
   : GridMatrix(nullptr), RayPotentialRho(0), RayPotentialThickness(0), RayPotentialEta(0), RayPotentialDelta(0),
     ThresholdBestCost(0), ExecutionTime(0), FuseKernelMs(0), FilePathKRTD(nullptr), FilePathVTI(nullptr), Device(0),
-    Partition(DMI_PARTITION_VIEWS)
+    Partition(DMI_PARTITION_Z_SLABS)  // several GPUs: f64, bit-identical to one; DMI_PARTITION_VIEWS (f32 all-reduce) by SetPartition
 {
   this->SetNumberOfInputPorts(1);   // the vtkImageData whose geometry is the voxel grid
   this->SetNumberOfOutputPorts(1);
