@@ -464,16 +464,18 @@ def main():
     scenes = None
     if not args.no_scenes:
         scenes = {}
+        resident = args.scene
         for kind in ("dense", "speckle", "noisy"):
-            if kind != args.scene:
+            if kind != resident:
                 ctx.clear_views()
                 upload_scene(ctx, scene, kind, maps_per_gpu, W, H, spacing)
+                resident = kind
             n_steps = max(2, args.steps // 2)
             dt2, kern2 = timed(n_steps, 1)
             scenes[kind] = {"value": n_vox * maps_per_gpu * n_steps / dt2 / 1e9, "ms_per_step": dt2 / n_steps * 1e3,
                             "fuse_ms": kern2, "kernel_ms": timed.main_ms, "brick_classes": ctx.brick_class_histogram(),
                             "mixed_reasons": ctx.mixed_reason_histogram()}
-        if args.scene != "noisy":    # leave the context as the sections below expect it: the headline scene resident
+        if resident != args.scene:   # leave the context as the sections below expect it: the headline scene resident
             ctx.clear_views()
             upload_scene(ctx, scene, args.scene, maps_per_gpu, W, H, spacing)
 
@@ -609,8 +611,6 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
     ray = scene.default_ray_potential(grid)
     n_vox = grid.n_voxels
     np_grid = np.float32 if args.grid_dtype == "f32" else np.float64
-    dense = args.scene == "dense"
-
     def create(g):
         kw = dict(grid_dtype=args.grid_dtype, depth_storage="auto", kernel_variant=args.variant, partition=args.partition,
                   exchange=args.exchange, n_slabs=args.slabs)
@@ -627,15 +627,24 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
 
     my_ranks = list(range(n_ranks)) if args.one_process else [rank]
 
+    g_spacing = float(max(grid.spacing))
+
+    def scene_chunk(n_total, w, h, seed, c0, c1, sigma):
+        """(views, threshold) of views c0 .. c1-1 of the n_total-camera scene of kind args.scene, as dmi_multi_add_views takes
+        them: f32 depths, or f64 depths with best-cost values and the threshold (RD.cxx:138-167)."""
+        v, thr = scene.make_scene_views(args.scene, n_total, w, h, seed=seed, view_range=(c0, c1), noise_sigma=sigma)
+        if thr is None:
+            v = scene.Views(v.depth.astype(np.float32), v.K4, v.RT4)
+        return v, thr
+
     def upload(m, n_total, w, h, seed, shard_views: bool):
         """Views of an n_total-camera scene onto this process's ranks: each rank its share (views partition of a fixed
         problem), or every rank everything (z-slabs)."""
         for li, r in enumerate(my_ranks):
             lo, hi = capi.multi_view_shard(n_total, r, n_ranks) if shard_views else (0, n_total)
-            for c0 in range(lo, hi, 64):   # bounded host memory: 64 views at a time
-                c1 = min(hi, c0 + 64)
-                v = scene.make_views(n_total, w, h, seed=seed, dense=dense, layout="sphere", dtype=np.float32, view_range=(c0, c1))
-                m.add_views(v, local_index=li)
+            for c0 in range(lo, hi, 32):   # bounded host memory: 32 views at a time
+                c1 = min(hi, c0 + 32)
+                m.add_views(*scene_chunk(n_total, w, h, seed, c0, c1, g_spacing), local_index=li)
 
     def timed(m, steps, warmup):
         for _ in range(warmup):
@@ -683,10 +692,9 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
             got, _ = m.download_grid(np_grid)
             got = got.copy()
             with capi.FusionContext(g, ray, device=local_rank, grid_dtype=args.grid_dtype) as one:
-                for c0 in range(0, n_total, 64):
-                    c1 = min(n_total, c0 + 64)
-                    one.add_views(scene.make_views(n_total, w, h, seed=seed, dense=dense, layout="sphere", dtype=np.float32,
-                                                   view_range=(c0, c1)))
+                for c0 in range(0, n_total, 32):
+                    c1 = min(n_total, c0 + 32)
+                    one.add_views(*scene_chunk(n_total, w, h, seed, c0, c1, float(max(g.spacing))))
                 one.fuse()
                 want = one.download_grid(np_grid)
             diff = float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))))

@@ -6,8 +6,8 @@ TAG=${1:-prof}; shift || true
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
-P="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end $*"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end $* > $O.kt.log 2>&1; echo "kt rc=$?"
+P="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end --no-scenes $*"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end --no-scenes $* > $O.kt.log 2>&1; echo "kt rc=$?"
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq1 -- $P > $O.sq1.log 2>&1; echo "pmc1 rc=$?"
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq2 -- $P > $O.sq2.log 2>&1; echo "pmc2 rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/fetch -- $P > $O.fetch.log 2>&1; echo "pmc3 rc=$?"
