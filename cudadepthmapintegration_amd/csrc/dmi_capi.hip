@@ -29,7 +29,9 @@ thread_local std::string g_create_error;
 
 struct Batch {
   void *d_depth = nullptr;             // n * W * H values of the context's current storage type
-  dmi::DepthTile *d_pyramid = nullptr;  // n min/max pyramids (fusion_classify.hip)
+  dmi::DepthTile *d_pyramid = nullptr;  // n min/max pyramids (fusion_classify.hip), then the n validity maps
+  size_t valid_offset = 0;              // byte offset of the validity maps within d_pyramid
+  size_t aux_bytes = 0;                 // size of the d_pyramid allocation
   int32_t n = 0;
 };
 
@@ -262,7 +264,11 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   b.n = n;
   DMI_HIP(ctx, hipMalloc(&b.d_depth, npix * n * esz));
   ctx->device_bytes += npix * n * esz;
-  const size_t pyr_bytes = (size_t)ctx->pyramid.total_tiles * n * sizeof(dmi::DepthTile);
+  // the pyramids of the batch, and behind them its validity maps (TileMapRec::valid): one allocation
+  const size_t pyr_only = ((size_t)ctx->pyramid.total_tiles * n * sizeof(dmi::DepthTile) + 255) / 256 * 256;
+  const size_t pyr_bytes = pyr_only + (size_t)dmi::valid_map_bytes(ctx->W, ctx->H) * n;
+  b.valid_offset = pyr_only;
+  b.aux_bytes = pyr_bytes;
   {
     hipError_t pe = hipMalloc(&b.d_pyramid, pyr_bytes);
     if (pe != hipSuccess) {
@@ -304,6 +310,9 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
     if (e == hipSuccess)
       e = dmi::launch_build_pyramids(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H, ctx->pyramid, b.d_pyramid,
                                      ctx->upload_stream);
+    if (e == hipSuccess)
+      e = dmi::launch_build_valid_maps(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H,
+                                       reinterpret_cast<uint8_t *>(b.d_pyramid) + b.valid_offset, ctx->upload_stream);
     if (e == hipSuccess)
       e = hipMemcpyAsync(lossy_out, ctx->d_lossy, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->upload_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->upload_stream);
@@ -535,7 +544,7 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     // some depth is not an f32: keep every bit -> promote the whole store and redo this batch in f64
     (void)hipFree(b.d_depth);
     (void)hipFree(b.d_pyramid);
-    ctx->device_bytes -= npix * n * 4 + (size_t)ctx->pyramid.total_tiles * n * sizeof(dmi::DepthTile);
+    ctx->device_bytes -= npix * n * 4 + b.aux_bytes;
     rc = promote_to_f64(ctx);
     if (rc != DMI_OK) return rc;
     rc = upload_batch(ctx, depth64, depth32, best_cost, threshold, n, &b, &lossy);
@@ -556,7 +565,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     for (int q = 0; q < 12; ++q) finite = finite && bounded(r.k[q]) && bounded(r.rt[q]);
     const int km = classify_k(r.k, r.rt);
     if (km < ctx->k_mode) ctx->k_mode = km;
-    const TileMapRec t = make_tile_rec(ctx, r);
+    TileMapRec t = make_tile_rec(ctx, r);
+    t.valid = reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.valid_offset + (size_t)m * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H);
     ctx->h_tile_maps.push_back(t);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);
@@ -846,7 +856,7 @@ int dmi_clear_views(dmi_context *ctx) {
   for (Batch &b : ctx->batches) {
     (void)hipFree(b.d_depth);
     (void)hipFree(b.d_pyramid);
-    ctx->device_bytes -= npix * b.n * depth_elem(ctx) + (size_t)ctx->pyramid.total_tiles * b.n * sizeof(dmi::DepthTile);
+    ctx->device_bytes -= npix * b.n * depth_elem(ctx) + b.aux_bytes;
   }
   ctx->batches.clear();
   ctx->h_maps.clear();

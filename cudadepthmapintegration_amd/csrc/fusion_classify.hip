@@ -92,6 +92,27 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const DepthT *__restr
   pyr[m * P.total_tiles + P.offset[0] + t] = acc.tile();
 }
 
+// validity map (TileMapRec::valid): one thread per pixel column of a tile row, eight rows -> eight contiguous bytes
+template <typename DepthT>
+__global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict__ depth, int64_t n_maps, int W, int H,
+                                                        uint8_t *__restrict__ valid) {
+  const int tile_rows = (H + 7) / 8;
+  const int64_t per_map = (int64_t)tile_rows * W;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_map * n_maps) return;
+  const int64_t m = idx / per_map;
+  const int64_t r = idx - m * per_map;
+  const int ty = (int)(r / W), x = (int)(r - (int64_t)ty * W);
+  const DepthT *src = depth + m * (int64_t)W * H;
+  unsigned long long bits = 0;
+  for (int q = 0; q < 8; ++q) {
+    const int y = ty * 8 + q;
+    const bool has = y < H && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
+    bits |= (unsigned long long)(has ? 1 : 0) << (8 * q);
+  }
+  *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + r * 8) = bits;
+}
+
 // level l from level l-1: one thread per tile, 2 x 2 children
 __global__ __launch_bounds__(256) void pyramid_up_kernel(int64_t n_maps, int level, PyramidDesc P, DepthTile *__restrict__ pyr) {
   const int64_t tiles = (int64_t)P.width[level] * P.height[level];
@@ -686,6 +707,16 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
     e = hipGetLastError();
   }
   return e;
+}
+
+hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid, hipStream_t stream) {
+  if (n_maps <= 0) return hipSuccess;
+  const int64_t n = (int64_t)((H + 7) / 8) * W * n_maps;
+  if (depth_is_f64)
+    hipLaunchKernelGGL((valid_map_kernel<double>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const double *>(depth), n_maps, W, H, valid);
+  else
+    hipLaunchKernelGGL((valid_map_kernel<float>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const float *>(depth), n_maps, W, H, valid);
+  return hipGetLastError();
 }
 
 hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, const PyramidDesc &P, int tk, uint8_t *classes,

@@ -76,8 +76,14 @@ struct alignas(16) TileMapRec {
   float t1_erel, t1_hspan;
   int32_t t1_cidx;  // W * cyc + cxc: pixel index of the image centre
   int32_t t1_ok;
-  double pad;
+  // Validity map of the view (round 3): one byte per pixel, 1 = the pixel holds a depth (anything but the -1 sentinel), in
+  // tiles of 8 image rows: byte (x, y) at ((y >> 3) * W + x) * 8 + (y & 7), valid_map_bytes(W, H) in all.  The FREE column of
+  // the fusion kernel asks only "does my pixel hold a depth?"; an 8 x 8-lane patch of such questions touches a quarter of the
+  // cache lines in this layout and a quarter of the bytes, and costs the texture addresser half of what the same gather from
+  // the row-major f32 table costs (profiles/r06q_microbench_gather.txt).
+  const uint8_t *valid;
 };
+__host__ __device__ inline int64_t valid_map_bytes(int W, int H) { return (int64_t)((H + 7) / 8) * W * 8; }
 static_assert(sizeof(TileMapRec) == 320, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical
@@ -269,6 +275,8 @@ hipError_t launch_fp64_probe(double *out, int blocks, int iters, hipStream_t str
 PyramidDesc make_pyramid_desc(int W, int H);
 hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &desc,
                                  DepthTile *pyramids, hipStream_t stream);
+// validity maps (TileMapRec::valid) of n_maps depth tables: valid[n_maps][valid_map_bytes(W, H)]
+hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid, hipStream_t stream);
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.
 // general_k: some view of the run has a K with a general third row (the kernels then look at every view's errz)
 hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, const PyramidDesc &desc, int tk,

@@ -581,12 +581,31 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         cxc = KC(W) >> 1;
         cyc = KC(H) >> 1;
       }
+      // FREE column of tier 1: the only question per voxel is whether its pixel holds a depth: asked of the view's validity
+      // map (TileMapRec::valid: bytes in tiles of eight image rows) instead of the f32 table -- a quarter of the lines and
+      // bytes per 8 x 8-lane patch, half the texture addresser's time per gather.  Byte index of centred pixel (px'', py''),
+      // y = py'' + cyc, yt = y >> 3:  (yt * W + px'' + cxc) * 8 + (y & 7)  =  yt * (8 W - 8) + (8 px'' + py'') + (8 cxc + cyc);
+      // yt = rne((y - 3.5) / 8) exactly for y >= 0; every product and sum is an integer below 2^24 (the host admits tier 1
+      // only while (H + 2) * W < 2^24).
+      constexpr bool VMAP = T1 && FREEONLY;
+      [[maybe_unused]] __amdgpu_buffer_rsrc_t vrsrc = rsrc;
+      [[maybe_unused]] float v_c0 = 0.f, v_w8 = 0.f;
+      [[maybe_unused]] int v_base = 0;
+      if constexpr (VMAP) {
+        const kernarg_t kw = KFRESH();
+        const int W = kw->W, H = kw->H;
+        vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(cload(&rec->valid)), (short)0, (int)valid_map_bytes(W, H), 0x00020000);
+        v_c0 = ((float)(H >> 1) - 3.5f) * 0.125f;
+        v_w8 = (float)(8 * W - 8);
+        v_base = 8 * (W >> 1) + (H >> 1);
+      }
   #pragma unroll
       for (int g0 = 0; g0 < TK; g0 += kGroup) {
         double czg[kGroup];
         // Every lane starts from the "no depth" sentinel and only the lanes that are in the map load over it: phase B then
         // needs no mask from phase A (eight lane masks = sixteen SGPRs the loop does not have), cu:202 covers both.
         typename DL::raw_t dg[kGroup];
+        [[maybe_unused]] unsigned vg[kGroup];  // VMAP: the validity bytes
         // (a FREEONLY column of tier 1 never looks at c.z in fp64: neither its pixels nor its sums need it)
         if constexpr (!ROT && !(T1 && FREEONLY)) {
           // exact c.z of the group's voxels first (cu:92, cu:172; h.z == c.z for a pinhole K): r22*wz(k) comes as one
@@ -626,7 +645,13 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             const mask_t m_p1 = ballot(max_abs(t.x, t.y) < cth.y);
             // W*py'' + px'' in one fp32 operation (exact: the host admits tier 1 only while (H + 2) * W < 2^24), then the
             // centre's index; garbage on unaccepted lanes, whose loads the buffer descriptor range-checks
-            unsigned pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(rp.y, Wf, rp.x)) + cidx);
+            unsigned pix;
+            if constexpr (VMAP) {
+              const float yt = __builtin_rintf(__builtin_fmaf(rp.y, 0.125f, v_c0));
+              pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(yt, v_w8, __builtin_fmaf(rp.x, 8.0f, rp.y))) + v_base);
+            } else {
+              pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(rp.y, Wf, rp.x)) + cidx);
+            }
             mask_t m_in, m_und;
             [[maybe_unused]] mask_t m_front = 0;
             if constexpr (INTERIOR) {
@@ -657,7 +682,13 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               const double fu = ua2 - ru2, fv = va2 - rv2;
               const double chk = __builtin_fma(cload(&rec->cerrk), r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
               const mask_t m_p2 = ballot(chk < 0.5) & ballot(__builtin_fabs(e0) < tiny) & m_und;
-              const unsigned pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + cidx);
+              unsigned pix2;
+              if constexpr (VMAP) {
+                const double yt2 = __builtin_rint(__builtin_fma(rv2, 0.125, (double)v_c0));
+                pix2 = (unsigned)(cvt_saturating(__builtin_fma(yt2, (double)v_w8, __builtin_fma(ru2, 8.0, rv2))) + v_base);
+              } else {
+                pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + cidx);
+              }
               if (__builtin_amdgcn_inverse_ballot_w64(m_p2)) pix = pix2;
               if constexpr (INTERIOR) {
                 m_in |= m_p2;
@@ -667,7 +698,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               }
               m_und &= ~m_p2;
             }
-            if constexpr (UNMASKED) {
+            if constexpr (VMAP && UNMASKED) {
+              vg[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(vrsrc, (int)pix, 0, 0);  // 1: the pixel holds a depth
+              if (m_und) {  // wave-uniform branch
+                or_where(undecided, m_und, 1u << kk);
+                und_kk |= 1u << kk;
+                if (__builtin_amdgcn_inverse_ballot_w64(m_und)) vg[q] = 0u;  // the redo below adds this voxel's value
+              }
+            } else if constexpr (UNMASKED) {
               dg[q] = DL::load(rsrc, pix);
               if (m_und) {  // wave-uniform branch
                 or_where(undecided, m_und, 1u << kk);
@@ -780,6 +818,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   #pragma unroll
         for (int q = 0; q < kGroup; ++q) {
           const int kk = g0 + q;
+          if constexpr (VMAP) {
+            // proven by the classification (4b.8): every depth the footprint holds is far behind the brick
+            acc_add_s<BASE, TK>(kk, ballot(vg[q] != 0u), free_space);  // -eta*rho (cu:115) where the pixel holds a depth
+            continue;
+          }
           const typename DL::raw_t d = dg[q];  // lanes that did not load still hold the sentinel
           // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike; SURFACE: every lane has a depth
           const mask_t m_hit = SURFACE ? ~0ull : ballot(!DL::is_sentinel(d));
