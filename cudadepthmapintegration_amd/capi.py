@@ -160,8 +160,9 @@ def load() -> ctypes.CDLL:
     L.dmi_cell_to_point.argtypes = [vp]
     L.dmi_download_point_data_f64.argtypes = [vp, dp]
     L.dmi_point_data_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
-    L.dmi_iso_active_cells.argtypes = [vp, ctypes.c_double, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int64),
-                                       ctypes.c_uint64]
+    if hasattr(L, "dmi_iso_active_cells"):  # (an older build loaded for an A/B, tools/gpu_exp.py, lacks the newest entry points)
+        L.dmi_iso_active_cells.argtypes = [vp, ctypes.c_double, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int64),
+                                           ctypes.c_uint64]
     L.dmi_get_brick_class_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_mixed_reason_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
@@ -189,7 +190,8 @@ def load() -> ctypes.CDLL:
     L.dmi_multi_view_shard.argtypes = [i64, i32, i32, i64p, i64p]
     L.dmi_multi_z_slab.argtypes = [i32, i32, i32, i32p, i32p]
     L.dmi_multi_slab_ranges.argtypes = [i32, i32, i32p, i32p, i32]
-    L.dmi_multi_peer_chunk.argtypes = [i64, i32, i32, i64p, i64p]
+    if hasattr(L, "dmi_multi_peer_chunk"):
+        L.dmi_multi_peer_chunk.argtypes = [i64, i32, i32, i64p, i64p]
     L.dmi_multi_create.argtypes = [ctypes.POINTER(GridDescC), ctypes.POINTER(RayPotentialC), ctypes.POINTER(MultiOptionsC),
                                    i32p, i32, ctypes.POINTER(vp)]
     L.dmi_multi_get_unique_id.argtypes = [u8p]
@@ -211,7 +213,10 @@ def load() -> ctypes.CDLL:
     L.dmi_multi_get_info.argtypes = [vp, ctypes.POINTER(MultiInfoC)]
     L.dmi_multi_get_timings.argtypes = [vp, ctypes.POINTER(MultiTimingsC)]
     L.dmi_multi_local_context.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    from . import build as _b
     for name in ABI_SYMBOLS:
+        if _b.LIB_OVERRIDE and not hasattr(L, name):
+            continue  # an older build loaded side by side for an A/B (tools/gpu_exp.py); the shipped library has them all
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:
             fn.restype = ctypes.c_int

@@ -1032,7 +1032,11 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     // few views per brick (and classes to make most of them cheap): one workgroup per brick, see the kernel
     const bool stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
                       : (cfg.variant & VAR_PERSISTENT_NEVER) ? false
-                      : a.n_maps >= kPersistentMinViews || (cfg.variant & VAR_NO_BRICK_CLASSES);
+                      : a.n_maps >= kPersistentMinViews || (cfg.variant & VAR_NO_BRICK_CLASSES) ||
+                            // (round 3: with holes in the depth maps most pairs are per-voxel work and a brick lives long
+                            // enough from fewer views on: 256^3 x 64 views speckle 0.85 against 1.04 ms, dense 0.44 against
+                            // 0.43, profiles/r06w_exp_cfg2_forms.json; at 1024^3 the per-brick form keeps winning at 64 views)
+                            (a.n_maps >= 48 && (int64_t)a.bricks_x * a.bricks_y * a.bricks_z <= (int64_t(1) << 18));
     if (!stay) {
       if (cfg.count_hits)
         hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
