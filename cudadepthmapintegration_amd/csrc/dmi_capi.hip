@@ -567,6 +567,10 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     if (km < ctx->k_mode) ctx->k_mode = km;
     TileMapRec t = make_tile_rec(ctx, r);
     t.valid = reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.valid_offset + (size_t)m * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H);
+    t.vm_c0 = ((float)(ctx->H / 2) - 3.5f) * 0.125f;
+    t.vm_w8 = (float)(8 * ctx->W - 8);
+    t.vm_base = 8 * (ctx->W / 2) + ctx->H / 2;
+    t.vm_bytes = (int32_t)std::min<int64_t>(dmi::valid_map_bytes(ctx->W, ctx->H), 0x7fffffff);
     ctx->h_tile_maps.push_back(t);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);

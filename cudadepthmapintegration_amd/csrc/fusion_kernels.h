@@ -82,9 +82,13 @@ struct alignas(16) TileMapRec {
   // cache lines in this layout and a quarter of the bytes, and costs the texture addresser half of what the same gather from
   // the row-major f32 table costs (profiles/r06q_microbench_gather.txt).
   const uint8_t *valid;
+  // ... and what turns a centred pixel into a byte of that map (fusion_tile.hip, FREE column), the same for every view of a
+  // context but read with the record, in the same scalar loads: (cyc - 3.5) / 8, 8 W - 8, 8 cxc + cyc, valid_map_bytes
+  float vm_c0, vm_w8;
+  int32_t vm_base, vm_bytes;
 };
 __host__ __device__ inline int64_t valid_map_bytes(int W, int H) { return (int64_t)((H + 7) / 8) * W * 8; }
-static_assert(sizeof(TileMapRec) == 320, "TileMapRec layout");
+static_assert(sizeof(TileMapRec) == 336, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical
 // shortcuts proven in DESIGN.md ("K specialisation").

@@ -130,3 +130,19 @@ def test_issue_roofline_takes_the_larger_floor():
     assert abs(r["frac"] - 0.5) < 1e-9 and r["source"] == "t"
     r = bench.issue_roofline({"valu_insts": 1024 * 2.4e6, "valu_active_quad_cycles": 1024 * 3.0e6, "salu_insts": 256 * 2.4e6 * 6}, 8.0)
     assert abs(r["vector_floor_ms"] - 5.0) < 1e-9 and r["bound"] == "scalar_issue" and abs(r["frac"] - 0.75) < 1e-9
+
+
+def test_build_accepts_the_library_by_digest_and_says_what_it_did():
+    """build() on an up-to-date tree compiles nothing (the library's digest file names the present sources and flags,
+    whatever the timestamps say) and leaves a record of that; the command-line tool is keyed on the same digest and is
+    linked on demand, never as a side effect of loading the library."""
+    import json
+    from cudadepthmapintegration_amd import build as b
+    path = b.build()
+    assert os.path.exists(path) and not b.needs_build()
+    rec = json.load(open(os.path.join(b.OBJ_DIR, "build_record.json")))
+    assert rec["digest"] == b.source_digest() and rec["mode"].split(":")[0] in ("up_to_date", "rebuilt")
+    cli = capi.cli_binary()
+    assert os.path.exists(cli) and open(cli + ".digest").read().strip() == b.source_digest()
+    # no offload-bundler temporaries next to the sources (they used to be committed by accident)
+    assert not [f for f in os.listdir(b.CSRC) if ".so." in f and not f.endswith(".digest")]
