@@ -408,7 +408,8 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   const double nl = 32.0 * 0x1p-53 * M[2];  // computed c.z against its affine model along a column (roundings of cu:80-92)
   if (!(czmin > 0.0) || !std::isfinite(czmin)) return;  // the camera is inside (or too near) the grid: fp64 tier only
   const double pmax = Sc / czmin + 1.0;                 // bounds every accepted tier-1 candidate |P|
-  const bool index_exact = ((int64_t)ctx->H + 2) * (int64_t)ctx->W < (int64_t(1) << 24);  // W*py'' + px'' exact in fp32
+  // W*py'' + px'' and the validity map's byte index yt*(8W - 8) + (8 px'' + py'') (|.| <= H*W + 4W + H/2) exact in fp32
+  const bool index_exact = ((int64_t)ctx->H + 8) * (int64_t)ctx->W + ctx->H < (int64_t(1) << 24);
   // e1 = e_abs + e_rel * HB, HB = the lane's bound on |hx''|, |hy''| along its column
   double e1 = cerr + 3.0 * 0x1p-24 * Dz * pmax + 0x1p-22 * Dz + nl * (pmax + 2.0) + 0x1p-53 * std::max(Sx, Sy);
   e1 *= 1.0 + 0x1p-10;

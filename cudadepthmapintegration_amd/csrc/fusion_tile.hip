@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       // bytes per 8 x 8-lane patch, half the texture addresser's time per gather.  Byte index of centred pixel (px'', py''),
       // y = py'' + cyc, yt = y >> 3:  (yt * W + px'' + cxc) * 8 + (y & 7)  =  yt * (8 W - 8) + (8 px'' + py'') + (8 cxc + cyc);
       // yt = rne((y - 3.5) / 8) exactly for y >= 0; every product and sum is an integer below 2^24 (the host admits tier 1
-      // only while (H + 2) * W < 2^24).
+      // only while (H + 8) * W + H < 2^24).
       constexpr bool VMAP = T1 && FREEONLY;
       [[maybe_unused]] __amdgpu_buffer_rsrc_t vrsrc = rsrc;
       [[maybe_unused]] float v_c0 = 0.f, v_w8 = 0.f;
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             rp.y = __builtin_rintf(ua.y);
             const f32x2 t = pk_fnma_lo(rp, cth, h);
             const mask_t m_p1 = ballot(max_abs(t.x, t.y) < cth.y);
-            // W*py'' + px'' in one fp32 operation (exact: the host admits tier 1 only while (H + 2) * W < 2^24), then the
+            // W*py'' + px'' in one fp32 operation (exact: the host admits tier 1 only while (H + 8) * W + H < 2^24), then the
             // centre's index; garbage on unaccepted lanes, whose loads the buffer descriptor range-checks
             unsigned pix;
             if constexpr (VMAP) {
