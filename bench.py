@@ -309,8 +309,8 @@ def main():
     ap.add_argument("--one-process", action="store_true",
                     help="N > 1: one process drives all N devices (dmi_multi_create / ncclCommInitAll) instead of one process per GPU")
     ap.add_argument("--share-device", action="store_true",
-                    help="--exchange peer_copy only: every rank on device 0 (a rehearsal of the N-rank exchange on a one-GPU box; "
-                         "the figures say nothing about N GPUs)")
+                    help="--exchange peer_copy or --partition z_slabs (no communicator): every rank on device 0 -- a rehearsal of the "
+                         "N-rank run, launcher and all, on a one-GPU box; the figures say nothing about N GPUs")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling objects")
     ap.add_argument("--force-multi", action="store_true",
                     help="rehearsal on a one-GPU box: run the N > 1 code path (dmi_multi_*, RCCL with one rank) with --gpus 1")
@@ -351,7 +351,10 @@ def main():
     if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the fusion path has no CPU fallback")
     n_ranks = args.gpus  # ranks of the fusion = GPUs, however they are spread over processes
-    share = args.share_device and args.exchange == "peer_copy"
+    # rehearsals on a one-GPU box: the exchanges that need no communicator may put every rank on device 0
+    share = args.share_device and (args.exchange == "peer_copy" or args.partition == "z_slabs")
+    if share:
+        local_rank = 0
     if (n_dev < args.gpus and not share) or local_rank >= n_dev:   # one node: every rank sees every GPU, so every rank decides alike
         raise SystemExit(f"bench.py: {args.gpus} GPUs asked for, {n_dev} visible")
     have_torch_gpu = torch.cuda.is_available()
@@ -766,7 +769,7 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
             "rccl_ranks": int(info.rccl_ranks),
             "rccl_version": int(info.rccl_version),
             "launched_by": os.environ.get("DMI_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "bench.py --one-process"),
-            "ranks_share_device_0": bool(args.share_device and args.exchange == "peer_copy"),
+            "ranks_share_device_0": bool(args.share_device and (args.exchange == "peer_copy" or args.partition == "z_slabs")),
         },
         "roofline": top["roofline"],
         "weak": weak,
