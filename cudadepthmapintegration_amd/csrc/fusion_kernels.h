@@ -19,7 +19,13 @@ struct alignas(16) DepthTile {
   uint32_t flags;  // TILE_* bits
   uint32_t pad;
 };
-enum TileFlags : uint32_t { TILE_HAS_SENTINEL = 1, TILE_HAS_VALID = 2, TILE_HAS_NAN = 4 };
+// TILE_PART_HOLE_FREE / TILE_PART_NO_VALID: some 8 x 8 tile under this one holds no "no depth" pixel / no valid depth (set at
+// the finest level, OR-ed upwards like the others).  With neither over a box's footprint, holes and depths are mingled
+// everywhere in it (a depth map after the best-cost threshold): what the coarse classification asks before it lets a box's
+// bricks inherit a per-voxel class.
+enum TileFlags : uint32_t { TILE_HAS_SENTINEL = 1, TILE_HAS_VALID = 2, TILE_HAS_NAN = 4, TILE_PART_HOLE_FREE = 8, TILE_PART_NO_VALID = 16 };
+// coarse class table only: the box's bricks already hold the (BRICK_MIXED) class of the byte's low bits
+constexpr uint8_t COARSE_CHILDREN_WRITTEN = 0x80;
 
 constexpr int kPyramidMinLevel = 3;   // finest level kept: 8 x 8 pixel tiles
 constexpr int kPyramidMaxLevels = 13; // up to 2^15 pixels per axis

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-from bench import parse_workload  # noqa: E402
+from bench import parse_workload, upload_scene  # noqa: E402
 from cudadepthmapintegration_amd import capi, scene  # noqa: E402
 
 
@@ -34,9 +34,8 @@ def main():
     cells, n_maps, W, H = parse_workload(args.workload)
     grid = scene.default_grid(cells)
     ray = scene.default_ray_potential(grid)
-    views = scene.make_views(n_maps, W, H, seed=1000, dense=(args.scene == "dense"), dtype=np.float32)
     with capi.FusionContext(grid, ray, grid_dtype="f32", kernel_variant=args.variant) as ctx:
-        ctx.add_views(views)
+        upload_scene(ctx, scene, args.scene, n_maps, W, H, float(max(grid.spacing)))
         for _ in range(3):
             ctx.reset_grid()
             ctx.fuse()
@@ -67,20 +66,42 @@ def main():
     below90 = float(dt[level < 0.9 * peak].sum())
     below50 = float(dt[level < 0.5 * peak].sum())
     # resident workgroups (share of the peak) sampled every 0.25 ms, whole chip and per XCD
-    grid_t = np.arange(0.0, total, 0.25)
+    step = 0.25 if total > 2.5 else total / 16
+    grid_t = np.arange(0.0, total, step)
     def resident(sel):
         return [int(((start[sel] <= x) & (end[sel] > x)).sum()) for x in grid_t]
     curve = {"t_ms": [round(float(x), 2) for x in grid_t], "all": resident(np.ones_like(start, dtype=bool))}
     for x in sorted(set(xcc.tolist())):
         curve[f"xcc{x}"] = resident(xcc == x)
     # mean duration of the workgroups that START in each quarter millisecond (what kind of brick is being started when)
-    curve["mean_wg_ms_started"] = [float(dur[(start >= x) & (start < x + 0.25)].mean()) if ((start >= x) & (start < x + 0.25)).any() else 0.0 for x in grid_t]
+    curve["mean_wg_ms_started"] = [float(dur[(start >= x) & (start < x + step)].mean()) if ((start >= x) & (start < x + step)).any() else 0.0 for x in grid_t]
     per_xcd = []
     for x in sorted(set(xcc.tolist())):
         sel = xcc == x
         per_xcd.append({"xcc": int(x), "workgroups": int(sel.sum()), "last_end_ms": float(end[sel].max()),
                         "work_ms": float(dur[sel].sum()), "blockidx_mod8": sorted(set((block[ran][sel] % 8).tolist()))})
-    rec = {"workload": args.workload, "scene": args.scene, "variant": args.variant, "kernel_ms_by_events": kernel_ms,
+    # persistent workgroups: what lies between a brick's end stamp (taken before its sums are stored) and the same workgroup's
+    # next start stamp (taken when it has found its next brick): the stores, the counter's round trip, the order entry
+    gaps = []
+    blk = block[ran]
+    order_ = np.lexsort((start, blk))
+    sb, ss, se = blk[order_], start[order_], end[order_]
+    same = sb[1:] == sb[:-1]
+    gaps = (ss[1:] - se[:-1])[same]
+    between = {"n": int(gaps.size)}
+    if gaps.size:
+        between.update({"median_us": float(np.median(gaps) * 1e3), "mean_us": float(gaps.mean() * 1e3), "p90_us": float(np.percentile(gaps, 90) * 1e3),
+                        "sum_over_workgroup_time": float(gaps.sum() / (dur.sum() + gaps.sum()))})
+    # the bricks that end last: position in the order (heaviest level first), start and duration
+    uid = np.nonzero(ran)[0]
+    last = np.argsort(end)[-24:]
+    late = [{"order_pos": int(uid[x]), "of": int(ran.size), "start_us": round(float(start[x]) * 1e3, 1), "dur_us": round(float(dur[x]) * 1e3, 1)} for x in last]
+    # duration by position in the order, twenty equal parts
+    parts = np.array_split(np.arange(uid.size), 20)
+    by_pos = [{"median_us": round(float(np.median(dur[q])) * 1e3, 1), "max_us": round(float(dur[q].max()) * 1e3, 1),
+               "median_start_us": round(float(np.median(start[q])) * 1e3, 1)} for q in parts]
+    brick_us = {f"p{q}": float(np.percentile(dur, q) * 1e3) for q in (1, 10, 25, 50, 75, 90, 99)}
+    rec = {"late_bricks": late, "by_order_position": by_pos, "between_bricks": between, "brick_us": brick_us, "workload": args.workload, "scene": args.scene, "variant": args.variant, "kernel_ms_by_events": kernel_ms,
            "span_ms_by_memrealtime": float(total), "bricks_fused": int(ran.sum()), "workgroups_that_fused_a_brick": int(len(set(block[ran].tolist()))), "peak_resident_workgroups": int(peak),
            "ms_below_90pct_of_peak": below90, "ms_below_50pct_of_peak": below50,
            "workgroup_ms": {"median": float(np.median(dur)), "p99": float(np.percentile(dur, 99)), "max": float(dur.max())},
