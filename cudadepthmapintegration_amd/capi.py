@@ -29,6 +29,7 @@ VARIANT_XCD_RUNS = 8192  # tiled kernel: ordered bricks dealt to the XCDs in run
 VARIANT_ZMAJOR_SLOTS = 16384  # tiled kernel: super-bricks enumerated x, y, z (until r03h) instead of in Z-order
 VARIANT_PERSISTENT_ALWAYS = 32768  # tiled kernel: persistent one-wave workgroups whatever the number of views (default: from 96 on)
 VARIANT_PERSISTENT_NEVER = 65536  # tiled kernel: one workgroup per brick whatever the number of views
+VARIANT_BRICK_CLASSES_ALWAYS = 131072  # tiled kernel: brick classes for tiny grids too (default: none up to 1024 bricks per launch)
 VARIANT_FIXED_TILE_SHAPE = 4096  # tile-shape bits 0 mean shape 0 (tk16_w5) whatever the grid size; without it grids
                                  # below 512^3 pick tk8_w7 on their own
 VARIANT_SPATIAL_ORDER = 512  # tiled kernel: workgroups in spatial order instead of heaviest bricks first

@@ -1157,6 +1157,13 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // brick classes: one byte per (8 x 8 x column wave brick, resident view)
     t.wbricks_x = (a.nx + 7) / 8;
     t.wbricks_y = (a.ny + 7) / 8;
+    // A launch of no more bricks than the chip has SIMDs (64^3 voxels in 8-voxel columns) fuses without classes: every brick
+    // has a SIMD to itself, and the seven launches that classify and order the bricks take longer than the per-voxel work
+    // they would save (64^3: 79 -> 49 us at 4 views, 278 -> 192 us at 64; from 96^3 on the classes win;
+    // profiles/r07o_small_fusions_classes_on_off.txt).
+    if (!(cfg.variant & (dmi::VAR_NO_BRICK_CLASSES | dmi::VAR_BRICK_CLASSES_ALWAYS)) &&
+        (int64_t)t.wbricks_x * t.wbricks_y * ((int64_t)t.super_z * 2) <= dmi::kNoClassesMaxBricks)
+      cfg.variant |= dmi::VAR_NO_BRICK_CLASSES;
     // row pitch of the class tables: a power of two >= 64 views, so that views arriving in chunks (add, fuse, add,
     // fuse ...) change the layout -- and force a reallocation, which waits for the device -- only at doublings
     t.class_pitch = 64;

@@ -24,6 +24,8 @@ struct alignas(16) DepthTile {
 // everywhere in it (a depth map after the best-cost threshold): what the coarse classification asks before it lets a box's
 // bricks inherit a per-voxel class.
 enum TileFlags : uint32_t { TILE_HAS_SENTINEL = 1, TILE_HAS_VALID = 2, TILE_HAS_NAN = 4, TILE_PART_HOLE_FREE = 8, TILE_PART_NO_VALID = 16 };
+// launches of at most this many wave bricks (the chip's SIMDs) run without brick classes (dmi_capi.hip)
+constexpr int64_t kNoClassesMaxBricks = 1024;
 // coarse class table only: the box's bricks already hold the (BRICK_MIXED) class of the byte's low bits
 constexpr uint8_t COARSE_CHILDREN_WRITTEN = 0x80;
 
@@ -246,7 +248,8 @@ enum VariantBits : int {
   VAR_XCD_RUNS = 8192,          // tiled kernel: ordered bricks dealt to the XCDs in runs (round 1) instead of one eighth of a level each
   VAR_ZMAJOR_SLOTS = 16384,     // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
   VAR_PERSISTENT_ALWAYS = 32768,  // tiled kernel, one-wave workgroups: persistent whatever the number of views (default: from 96 views on)
-  VAR_PERSISTENT_NEVER = 65536    // tiled kernel, one-wave workgroups: one workgroup per brick whatever the number of views
+  VAR_PERSISTENT_NEVER = 65536,   // tiled kernel, one-wave workgroups: one workgroup per brick whatever the number of views
+  VAR_BRICK_CLASSES_ALWAYS = 131072  // tiled kernel: classify and order the bricks of tiny grids too (default: not below 1025 bricks)
 };
 
 constexpr int kMaxColumnHeight = 16;  // the tallest column of any tile shape: what z-slab partitions must be multiples of

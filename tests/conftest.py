@@ -36,3 +36,18 @@ def golden(request):
     d = load_golden(request.param)
     d["name"] = request.param
     return d
+
+
+@pytest.fixture(autouse=True)
+def _brick_classes_on_tiny_grids(monkeypatch):
+    """See tests/helpers.py: contexts created by tests keep their brick classes whatever the grid size."""
+    from cudadepthmapintegration_amd import capi
+    from helpers import variant_for_tests
+    for cls in (capi.FusionContext, capi.MultiContext):
+        orig = cls.__init__
+
+        def init(self, *args, _orig=orig, kernel_variant=0, **kw):
+            _orig(self, *args, kernel_variant=variant_for_tests(int(kernel_variant)), **kw)
+
+        monkeypatch.setattr(cls, "__init__", init)
+    yield

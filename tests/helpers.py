@@ -32,3 +32,29 @@ def bits_equal(a, b):
         return False
     both_nan = np.isnan(a) & np.isnan(b)
     return bool(np.all(both_nan | (a.view(np.uint64) == b.view(np.uint64))))
+
+
+# ---- brick classes on the tiny grids the tests use -------------------------------------------------------------------
+# The library fuses launches of up to 1024 bricks without brick classes (dmi_capi.hip: classifying them costs more than it
+# saves).  Most GPU tests use such grids BECAUSE the oracle is quick on them, and many exist to exercise the classes: a fixture
+# in conftest.py therefore adds VARIANT_BRICK_CLASSES_ALWAYS to every context a test creates, unless the test asks for the
+# shipped behaviour with `with shipped_defaults():` (tests/test_gpu_parity.py covers the rule itself).
+import contextlib
+
+_classes_always = {"on": True}
+
+
+@contextlib.contextmanager
+def shipped_defaults():
+    _classes_always["on"] = False
+    try:
+        yield
+    finally:
+        _classes_always["on"] = True
+
+
+def variant_for_tests(kernel_variant: int) -> int:
+    from cudadepthmapintegration_amd import capi
+    if _classes_always["on"] and not (kernel_variant & capi.VARIANT_NO_BRICK_CLASSES):
+        return kernel_variant | capi.VARIANT_BRICK_CLASSES_ALWAYS
+    return kernel_variant

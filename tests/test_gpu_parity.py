@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the committed golden fixtures
 and the CPU oracle.  Bar: TSDF bit-exact in fp64 on one GPU (f64 grid), hit counts bit-exact;
 with an f32 grid |delta| <= 2^-24 |v| (one final rounding)."""
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -419,6 +421,30 @@ def test_brick_classes_cover_every_case_and_change_nothing():
             assert sum(hist.values()) == 8 * 7 * (48 // (16 if variant == FX else 8)) * views.n
         else:
             assert sum(hist.values()) == 0
+
+
+@pytest.mark.parametrize("dims,classes", [((64, 64, 64), False), ((64, 64, 128), False), ((72, 64, 128), True)])
+def test_tiny_launches_fuse_without_classes(dims, classes):
+    """The shipped rule (dmi_capi.hip): a launch of at most 1024 bricks -- one per SIMD -- skips the classification and ordering
+    launches and takes every (brick, view) pair per voxel; from 1025 bricks on the classes are built.  Bit for bit the oracle's
+    grid either way, and VARIANT_BRICK_CLASSES_ALWAYS (what the other tests run with) brings the classes back."""
+    from helpers import shipped_defaults
+    grid = scene.default_grid(dims)
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(6, 160, 120, seed=77, dense=True)
+    views.depth[np.random.default_rng(5).random(views.depth.shape) < 0.1] = -1.0
+    want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                   n_threads=oracle.max_threads())
+    for shipped in (True, False):
+        with (shipped_defaults() if shipped else contextlib.nullcontext()):
+            with capi.FusionContext(grid, rp, count_hits=True) as ctx:
+                ctx.add_views(views)
+                ctx.fuse()
+                out = ctx.download_grid()
+                vh, mh = ctx.download_hits()
+                hist = ctx.brick_class_histogram()
+        assert bits_equal(out, want) and np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w), (dims, shipped)
+        assert (sum(hist.values()) > 0) == (classes or not shipped), (dims, shipped, hist)
 
 
 def test_brick_classes_with_fuse_range_and_initial_grid():

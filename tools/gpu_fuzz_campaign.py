@@ -32,9 +32,10 @@ def main():
                     help="every n-th seed is a medium-size scene (more bricks than persistent workgroups); 0 = none")
     args = ap.parse_args()
     fx = capi.VARIANT_FIXED_TILE_SHAPE
+    SHIPPED = -1  # kernel_variant 0 as a caller passes it
     variants = [(0, True), (0, False), (fx, True), (fx, False), (fx | capi.VARIANT_NO_BRICK_CLASSES, True), (96, True),
                 (capi.VARIANT_FORCE_GENERAL, True), (capi.VARIANT_NO_INTERIOR, False), (capi.VARIANT_XCD_RUNS, False),
-                (capi.VARIANT_ZMAJOR_SLOTS, False)]
+                (capi.VARIANT_ZMAJOR_SLOTS, False), (SHIPPED, False)]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     t0 = time.time()
     done = 0
@@ -57,7 +58,10 @@ def main():
                                            init_grid=init, n_threads=oracle.max_threads())
             want_pts = oracle.cell_to_point(want)
         for variant, count in variants:
-            with capi.FusionContext(grid, rp, count_hits=count, kernel_variant=variant) as ctx:
+            # (tiny grids fuse without classes by default: the campaign is about the classes, so they stay on; the last path
+            # of the list is the shipped default)
+            kv = variant if variant == SHIPPED or (variant & capi.VARIANT_NO_BRICK_CLASSES) else variant | capi.VARIANT_BRICK_CLASSES_ALWAYS
+            with capi.FusionContext(grid, rp, count_hits=count, kernel_variant=0 if variant == SHIPPED else kv) as ctx:
                 if init is not None:
                     ctx.upload_grid(init)
                 ctx.add_views(views)
