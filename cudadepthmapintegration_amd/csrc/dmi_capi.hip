@@ -364,7 +364,7 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   t.t1_c1 = 0.5f - 0x1p-20f;
   const double cxc = (double)(ctx->W / 2), cyc = (double)(ctx->H / 2);
   t.t1_cidx = (int32_t)((int64_t)ctx->W * (ctx->H / 2) + ctx->W / 2);
-  if (general || !aligned) return;  // those launches (GENK / ROT instantiations) read px .. q0 and errk
+  if (general) return;  // those launches (GENK instantiations) read px .. q0 and errk
   double Pc[4], Qc[4];
   for (int c = 0; c < 4; ++c) {
     Pc[c] = P[c] - cxc * S[c];
@@ -379,8 +379,12 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   // |hx''_ref - hx''_kernel|: the reference's h.x carries <= 11 ulp(Sx), cxc times its c.z <= 6 ulp(cxc * M[2]); the kernel's
   // affine value the 73 ulp of DESIGN.md 4.2 on the centred magnitudes (+ 2 per coefficient for the subtraction above);
   // 512 ulp of Sx + cxc * M[2] covers the sum five times over
+  // Rotated grid: M and Sx are sums of magnitudes that also bound every intermediate of the reference's w (three products and
+  // three sums per component instead of one of each); its w at two voxels of a column differs from the real, affine one by
+  // <= 6 ulp(|w|) each, which the rows turn into <= 12 ulp of the magnitudes: twice the budget keeps the same margin.
+  const double rot = aligned ? 1.0 : 2.0;
   const double Sxc = Sx + cxc * M[2], Syc = Sy + cyc * M[2];
-  const double cerr = std::max(Sxc, Syc) * 0x1p-44;
+  const double cerr = rot * std::max(Sxc, Syc) * 0x1p-44;
   t.cerrk = cerr + 0x1p-22 * M[2] * (1.0 + 0x1p-20);
   t.t1_dhx = (float)t.cdhx;
   t.t1_dhy = (float)t.cdhy;
@@ -390,22 +394,23 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   if (!(cerr < 0x1p-14)) return;  // (such a view fails the tiled kernel's per-view test anyway)
   // c.z over the voxels of the grid: at least czmin (the real-valued minimum over the box of voxel centres, less the
   // rounding of the computed value)
-  double lo[3], hi[3];
-  voxel_world(ctx->grid, 0, 0, ctx->opt.z_first, lo);
-  voxel_world(ctx->grid, ctx->grid.cell_dims[0] - 1, ctx->grid.cell_dims[1] - 1, ctx->opt.z_first + ctx->grid.cell_dims[2] - 1, hi);
-  double czmin = r.rt[11];
-  for (int a = 0; a < 3; ++a) czmin += std::min(r.rt[8 + a] * lo[a], r.rt[8 + a] * hi[a]);
-  czmin -= 16.0 * 0x1p-52 * M[2];
-  // |hx''|, |hy''| over the grid, from the centred rows themselves (for a principal point at the image centre the cz terms
-  // of row 0 cancel: this is what keeps |u''| <= W / 2 instead of W)
-  double wmc[3];
-  for (int a = 0; a < 3; ++a) wmc[a] = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
-  const double Scx = std::fabs(Pc[0]) * wmc[0] + std::fabs(Pc[1]) * wmc[1] + std::fabs(Pc[2]) * wmc[2] + std::fabs(Pc[3]);
-  const double Scy = std::fabs(Qc[0]) * wmc[0] + std::fabs(Qc[1]) * wmc[1] + std::fabs(Qc[2]) * wmc[2] + std::fabs(Qc[3]);
+  // (affine in the voxel indices: the extremes are at the eight corner voxels of the grid, whatever its axes)
+  double czmin = std::numeric_limits<double>::infinity(), Scx = 0.0, Scy = 0.0;
+  for (int c = 0; c < 8; ++c) {
+    double w[3];
+    voxel_world(ctx->grid, (c & 1) ? ctx->grid.cell_dims[0] - 1 : 0, (c & 2) ? ctx->grid.cell_dims[1] - 1 : 0,
+                ctx->opt.z_first + ((c & 4) ? ctx->grid.cell_dims[2] - 1 : 0), w);
+    czmin = std::min(czmin, ((r.rt[8] * w[0] + r.rt[9] * w[1]) + r.rt[10] * w[2]) + r.rt[11]);
+    // |hx''|, |hy''| over the grid, from the centred rows themselves (for a principal point at the image centre the cz terms
+    // of row 0 cancel: this is what keeps |u''| <= W / 2 instead of W)
+    Scx = std::max(Scx, std::fabs(((Pc[0] * w[0] + Pc[1] * w[1]) + Pc[2] * w[2]) + Pc[3]));
+    Scy = std::max(Scy, std::fabs(((Qc[0] * w[0] + Qc[1] * w[1]) + Qc[2] * w[2]) + Qc[3]));
+  }
+  czmin -= rot * 16.0 * 0x1p-52 * M[2];
   const double Sc = (std::max(Scx, Scy) + cerr) * (1.0 + 0x1p-20);               // bounds |hx''|, |hy''| and their fp32 images
   const double D = kMaxColumn * std::max(std::fabs(t.cdhx), std::fabs(t.cdhy));  // their change over a column
   const double Dz = kMaxColumn * std::fabs(dcz);
-  const double nl = 32.0 * 0x1p-53 * M[2];  // computed c.z against its affine model along a column (roundings of cu:80-92)
+  const double nl = rot * 32.0 * 0x1p-53 * M[2];  // computed c.z against its affine model along a column (roundings of cu:80-92)
   if (!(czmin > 0.0) || !std::isfinite(czmin)) return;  // the camera is inside (or too near) the grid: fp64 tier only
   const double pmax = Sc / czmin + 1.0;                 // bounds every accepted tier-1 candidate |P|
   // W*py'' + px'' and the validity map's byte index yt*(8W - 8) + (8 px'' + py'') (|.| <= H*W + 4W + H/2) exact in fp32

@@ -271,9 +271,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   asm("" : "+v"(vW));
   asm("" : "+v"(vH));
   [[maybe_unused]] const double Wd = pinned((double)KA(W));  // the row pitch as the interior column multiplies it
-  // Tier 1 of the pixel selection (pinhole views on an axis-aligned grid): the row pitch as a float and the
+  // Tier 1 of the pixel selection (pinhole views, either kind of grid): the row pitch as a float and the
   // pixel index of the image centre, from which tier 1 counts
-  constexpr bool T1 = DMI_TIER1 != 0 && !ROT && !GENK;
+  constexpr bool T1 = DMI_TIER1 != 0 && !GENK;
   [[maybe_unused]] const float Wf = __int_as_float(pinned_word(__float_as_int((float)KA(W))));
   [[maybe_unused]] const int cidx = pinned_word(KA(W) * (KA(H) / 2) + KA(W) / 2);
   double tiny = 0x1p-20;  // the reciprocal seed's residual must stay below this; a value in registers, not a literal
@@ -509,44 +509,52 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     double sz, rz3, hx, hy;
     [[maybe_unused]] f32x2 H0 = {0.f, 0.f}, C0 = {0.f, 0.f}, DH = {0.f, 0.f}, DC = {0.f, 0.f};  // tier 1 (T1 only)
     double r20 = 0, r21 = 0, r22 = 0;  // ROT only
+    // the exact c.z of the column's first voxel and its world position, as tier 1 starts from them
+    [[maybe_unused]] double cz_first = 0, wxf = wx, wyf = wy, wzf = wz0;
     if constexpr (ROT) {
-      r20 = cload(&rec->rz0);
-      r21 = cload(&rec->rz1);
-      r22 = cload(&kv->maps[m].rt[10]);
       sz = lane_ok ? cload(&rec->rz3) : -__builtin_inf();  // r23 per lane: -inf puts lanes outside the grid behind the camera
       rz3 = 0;
       hx = hy = 0;  // set at the column's first voxel below
+      if constexpr (T1) {  // w and c.z of the first voxel in the reference's order, as the per-voxel code forms them (rot_cz)
+        const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kv->cz_table + (int64_t)k0 * 4));
+        wxf = (wx + b[0]) + KA(g)[3], wyf = (wy + b[1]) + KA(g)[7], wzf = (wz0 + b[2]) + KA(g)[11];
+        cz_first = ((cload(&rec->rz0) * wxf + cload(&rec->rz1) * wyf) + cload(&kv->maps[m].rt[10]) * wzf) + sz;
+      } else {
+        r20 = cload(&rec->rz0);
+        r21 = cload(&rec->rz1);
+        r22 = cload(&kv->maps[m].rt[10]);
+      }
     } else {
       const double sz_in = cload(&rec->rz0) * wx + cload(&rec->rz1) * wy;
       sz = lane_ok ? sz_in : -__builtin_inf();
       rz3 = cload(&rec->rz3);
-      if constexpr (T1) {
-        // pixel selection only: the centred h.x, h.y at the column's first voxel (TileMapRec::cpx ...), their fp32 images
-        // and steps, the column's first c.z and the acceptance threshold at it (tier 1, below)
-        hx = __builtin_fma(cload(&rec->cpx), wx,
-                           __builtin_fma(cload(&rec->cpy), wy, __builtin_fma(cload(&rec->cpz), wz0, cload(&rec->cp0))));
-        hy = __builtin_fma(cload(&rec->cqx), wx,
-                           __builtin_fma(cload(&rec->cqy), wy, __builtin_fma(cload(&rec->cqz), wz0, cload(&rec->cq0))));
-        const double cz_first = (sz + cload(ct)) + rz3;  // the exact c.z of the column's first voxel (cu:92); -inf off the grid
-        const float czf = (float)cz_first;
-        H0.x = (float)hx;
-        H0.y = (float)hy;
-        C0.x = czf;
-        // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column
-        const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
-        C0.y = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
-        DH.x = cload(&rec->t1_dhx);
-        DH.y = cload(&rec->t1_dhy);
-        DC.x = cload(&rec->t1_dcz);
-        DC.y = cload(&rec->t1_dthr);
-        asm volatile("" : "+v"(DH), "+v"(DC));  // wave-uniform, but VGPR operands of the packed FMAs: placed there once per view
-      } else {
+      if constexpr (T1) cz_first = (sz + cload(ct)) + rz3;  // (cu:92); -inf off the grid
+    }
+    if constexpr (T1) {
+      // pixel selection only: the centred h.x, h.y at the column's first voxel (TileMapRec::cpx ...), their fp32 images
+      // and steps, the column's first c.z and the acceptance threshold at it (tier 1, below)
+      hx = __builtin_fma(cload(&rec->cpx), wxf,
+                         __builtin_fma(cload(&rec->cpy), wyf, __builtin_fma(cload(&rec->cpz), wzf, cload(&rec->cp0))));
+      hy = __builtin_fma(cload(&rec->cqx), wxf,
+                         __builtin_fma(cload(&rec->cqy), wyf, __builtin_fma(cload(&rec->cqz), wzf, cload(&rec->cq0))));
+      const float czf = (float)cz_first;
+      H0.x = (float)hx;
+      H0.y = (float)hy;
+      C0.x = czf;
+      // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column
+      const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
+      C0.y = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
+      DH.x = cload(&rec->t1_dhx);
+      DH.y = cload(&rec->t1_dhy);
+      DC.x = cload(&rec->t1_dcz);
+      DC.y = cload(&rec->t1_dthr);
+      asm volatile("" : "+v"(DH), "+v"(DC));  // wave-uniform, but VGPR operands of the packed FMAs: placed there once per view
+    } else if constexpr (!ROT) {
       // pixel selection only: h.x, h.y at the column's first voxel, then one add per step
       hx = __builtin_fma(cload(&rec->px), wx,
                          __builtin_fma(cload(&rec->py), wy, __builtin_fma(cload(&rec->pz), wz0, cload(&rec->p0))));
       hy = __builtin_fma(cload(&rec->qx), wx,
                          __builtin_fma(cload(&rec->qy), wy, __builtin_fma(cload(&rec->qz), wz0, cload(&rec->q0))));
-      }
     }
     [[maybe_unused]] const double dhx = T1 ? 0.0 : cload(&rec->dhx), dhy = T1 ? 0.0 : cload(&rec->dhy), errk = T1 ? 0.0 : cload(&rec->errk);
     [[maybe_unused]] double hz = 0, dhz = 0, errz = 0;
@@ -558,6 +566,20 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         if (!lane_ok) hz = -__builtin_inf();  // lanes outside the grid: behind the camera (cu:177) at no cost per voxel
       }
     }
+
+    // rotated grid: the exact c.z of voxel kk of the column -- the k-dependent products g_r2*gz(k) of cu:168 (wk table, one
+    // scalar load), then w and c.z in the reference's order (cu:90-92, cu:172); -inf above the grid, as the axis-aligned
+    // grid's table says it
+    // (row 2 of [R|T] is read where it is used -- per column, or on the rare tier-2 path of a FREE column -- through a
+    // pointer the compiler cannot see through: three register pairs that would otherwise live across every column)
+    [[maybe_unused]] auto rot_cz = [&](int kk) __attribute__((always_inline)) -> double {
+      if (kk >= kcount) return -__builtin_inf();  // wave-uniform
+      const kernarg_t kr = KFRESH();
+      const TileMapRec *rr = kr->tile_maps + m;
+      const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kr->cz_table + (int64_t)(k0 + kk) * 4));
+      const double wxk = (wx + b[0]) + kr->g[3], wyk = (wy + b[1]) + kr->g[7], wzk = (wz0 + b[2]) + kr->g[11];
+      return ((cload(&rr->rz0) * wxk + cload(&rr->rz1) * wyk) + cload(&kr->maps[m].rt[10]) * wzk) + sz;
+    };
 
     uint32_t undecided = 0;  // per lane: bit kk set = voxel kk of this map is redone after the column (tier 2, then exactly)
     uint32_t und_kk = 0;     // wave-uniform: the voxels kk for which some lane is
@@ -617,6 +639,19 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           for (int q = 0; q < kGroup; ++q) czg[q] = (sz + ctg[q]) + rz3;
           __builtin_amdgcn_sched_barrier(0);  // here, not sunk into the projections: that would keep ctg's SGPRs alive
         }
+        if constexpr (ROT && T1 && !FREEONLY) {
+          const double c20 = cload(&rec->rz0), c21 = cload(&rec->rz1), c22 = cload(&kv->maps[m].rt[10]);
+  #pragma unroll
+          for (int q = 0; q < kGroup; ++q) {
+            const int kk = g0 + q;
+            czg[q] = -__builtin_inf();
+            if (kk < kcount) {  // wave-uniform
+              const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kv->cz_table + (int64_t)(k0 + kk) * 4));
+              const double wxk = (wx + b[0]) + KA(g)[3], wyk = (wy + b[1]) + KA(g)[7], wzk = (wz0 + b[2]) + KA(g)[11];
+              czg[q] = ((c20 * wxk + c21 * wyk) + c22 * wzk) + sz;
+            }
+          }
+        }
         // ---- phase A: project the group's voxels and issue their depth loads
   #pragma unroll
         for (int q = 0; q < kGroup; ++q) {
@@ -672,8 +707,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               const double kd = (double)kk;
               const double hxk = __builtin_fma(kd, cload(&rec->cdhx), hx), hyk = __builtin_fma(kd, cload(&rec->cdhy), hy);
               double cz2;
-              if constexpr (FREEONLY)
-                cz2 = (sz + cload(ct + kk)) + rz3;  // the exact c.z (cu:92), which this column does not keep
+              if constexpr (FREEONLY)  // the exact c.z (cu:92), which this column does not keep
+                cz2 = ROT ? rot_cz(kk) : (sz + cload(ct + kk)) + rz3;
               else
                 cz2 = czg[q];
               const double r0 = __builtin_amdgcn_rcp(cz2);
