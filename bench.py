@@ -352,7 +352,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the fusion path has no CPU fallback")
     n_ranks = args.gpus  # ranks of the fusion = GPUs, however they are spread over processes
     # rehearsals on a one-GPU box: the exchanges that need no communicator may put every rank on device 0
-    share = args.share_device and (args.exchange == "peer_copy" or args.partition == "z_slabs")
+    # (with an RCCL exchange the communicator refuses two ranks on one device: that rehearses the fallback of multi_gpu)
+    share = args.share_device
     if share:
         local_rank = 0
     if (n_dev < args.gpus and not share) or local_rank >= n_dev:   # one node: every rank sees every GPU, so every rank decides alike
@@ -645,6 +646,28 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
             unique_id = box[0]
         return capi.MultiContext(g, ray, rank=rank, world=world, unique_id=unique_id, device=local_rank, **kw)
 
+    notes = []
+
+    def create_agreed(g):
+        """create(g) on every rank, or -- when the communicator of the views partition cannot be set up on some rank (RCCL
+        missing or refusing the topology) -- the z-slab partition, which needs none, on all of them.  The switch is reported
+        (`config.fallback`, and `config.parallelism` names what ran), never silent; a failure of the z-slab partition itself, or
+        with --one-process, is raised."""
+        m, err = None, None
+        try:
+            m = create(g)
+        except Exception as e:  # noqa: BLE001 - reported below
+            err = repr(e)
+        if max_over_ranks(1.0 if err else 0.0) == 0.0:
+            return m
+        if m is not None:
+            m.close()
+        if args.partition != "views" or args.one_process:
+            raise RuntimeError(err or "another rank could not create its context")
+        notes.append(f"views partition unavailable ({err or 'on another rank'}): z-slab partition instead")
+        args.partition = "z_slabs"
+        return create(g)
+
     my_ranks = list(range(n_ranks)) if args.one_process else [rank]
 
     g_spacing = float(max(grid.spacing))
@@ -687,7 +710,7 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
 
     def measure(name, cells_, n_total, w, h, seed, steps, warmup, check: bool):
         g = scene.default_grid(cells_)
-        m = create(g)
+        m = create_agreed(g)
         upload(m, n_total, w, h, seed, shard_views=(args.partition == "views"))
         dt, step_ms, fuse_ms = timed(m, steps, warmup)
         info = m.info()
@@ -769,12 +792,14 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
             "rccl_ranks": int(info.rccl_ranks),
             "rccl_version": int(info.rccl_version),
             "launched_by": os.environ.get("DMI_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "bench.py --one-process"),
-            "ranks_share_device_0": bool(args.share_device and (args.exchange == "peer_copy" or args.partition == "z_slabs")),
+            "ranks_share_device_0": bool(args.share_device),
         },
         "roofline": top["roofline"],
         "weak": weak,
         "strong": strong,
     }
+    if notes:
+        out["config"]["fallback"] = notes[0]
     return out
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """From a rocprofv3 --kernel-trace directory: the launches of the last fusion step (from the last cz_table_kernel on), each with
 its start relative to the step's first launch, its duration and the gap to the launch before it.  usage: step_timeline.py DIR"""
-import csv, glob, sys
+import csv, glob, re, sys
 
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
@@ -20,7 +20,7 @@ t0 = rows[lo][0]
 prev_end = None
 busy = 0
 for s, e, n in rows[lo:hi + 1]:
-    short = n.split("(")[0].split("::")[-1][:40]
+    short = re.sub(r"<.*", "", n.replace("(anonymous namespace)::", "").replace("void ", "")).split("(")[0].split("::")[-1][:40]
     gap = 0 if prev_end is None else (s - prev_end) / 1e3
     print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  gap {gap:6.1f}  {short}")
     prev_end = e
