@@ -10,7 +10,7 @@ OUT=gpurun_out/configs_$TAG.jsonl
 run() {  # name, extra args...
   local name=$1; shift
   echo "== $name $*" >&2
-  timeout -k 10 600 python bench.py --steps 5 --warmup 2 --no-ablation --no-coloration --no-end-to-end "$@" 2> gpurun_out/configs_$TAG.$name.err | tail -1 > gpurun_out/configs_$TAG.$name.json
+  timeout -k 10 600 python bench.py --steps 5 --warmup 2 --no-ablation --no-coloration --no-end-to-end --no-scenes "$@" 2> gpurun_out/configs_$TAG.$name.err | tail -1 > gpurun_out/configs_$TAG.$name.json
   local rc=$?
   if [ -s gpurun_out/configs_$TAG.$name.json ]; then
     python - "$name" gpurun_out/configs_$TAG.$name.json >> $OUT <<'PY'
@@ -34,6 +34,13 @@ run cfg3_dense_f64grid --workload cfg3 --scene dense --grid-dtype f64 --no-cpu-b
 run cfg4_share_dense --workload 512x128@640x480 --scene dense --no-cpu-baseline || exit 1
 run cfg5_share_dense --workload 1024x64@1920x1080 --scene dense --no-cpu-baseline || exit 1
 run cfg5_share_sparse --workload 1024x64@1920x1080 --scene sparse --no-cpu-baseline || exit 1
+# the same with depth maps as a best-cost threshold leaves them (10 % of the pixels invalid, scattered)
+run cfg1_speckle --workload cfg1 --scene speckle --no-cpu-baseline || exit 1
+run cfg2_speckle --workload cfg2 --scene speckle --no-cpu-baseline || exit 1
+run cfg3_speckle --workload cfg3 --scene speckle --no-cpu-baseline || exit 1
+run cfg3vga_speckle --workload cfg3vga --scene speckle --no-cpu-baseline || exit 1
+run cfg4_share_speckle --workload 512x128@640x480 --scene speckle --no-cpu-baseline || exit 1
+run cfg5_share_speckle --workload 1024x64@1920x1080 --scene speckle --no-cpu-baseline || exit 1
 python - $OUT <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
