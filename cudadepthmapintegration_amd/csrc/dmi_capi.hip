@@ -414,7 +414,9 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   if (!(czmin > 0.0) || !std::isfinite(czmin)) return;  // the camera is inside (or too near) the grid: fp64 tier only
   const double pmax = Sc / czmin + 1.0;                 // bounds every accepted tier-1 candidate |P|
   // W*py'' + px'' and the validity map's byte index yt*(8W - 8) + (8 px'' + py'') (|.| <= H*W + 4W + H/2) exact in fp32
-  const bool index_exact = ((int64_t)ctx->H + 8) * (int64_t)ctx->W + ctx->H < (int64_t(1) << 24);
+  // (of the padded image: every pixel the FREE column may ask for lies within the margin, 4b.9)
+  const bool index_exact = ((int64_t)ctx->H + 2 * dmi::kValidMargin + 8) * ((int64_t)ctx->W + 2 * dmi::kValidMargin) + ctx->H +
+                               2 * dmi::kValidMargin < (int64_t(1) << 24);
   // e1 = e_abs + e_rel * HB, HB = the lane's bound on |hx''|, |hy''| along its column
   double e1 = cerr + 3.0 * 0x1p-24 * Dz * pmax + 0x1p-22 * Dz + nl * (pmax + 2.0) + 0x1p-53 * std::max(Sx, Sy);
   e1 *= 1.0 + 0x1p-10;
@@ -573,9 +575,9 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     if (km < ctx->k_mode) ctx->k_mode = km;
     TileMapRec t = make_tile_rec(ctx, r);
     t.valid = reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.valid_offset + (size_t)m * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H);
-    t.vm_c0 = ((float)(ctx->H / 2) - 3.5f) * 0.125f;
-    t.vm_w8 = (float)(8 * ctx->W - 8);
-    t.vm_base = 8 * (ctx->W / 2) + ctx->H / 2;
+    t.vm_c0 = ((float)(ctx->H / 2 + dmi::kValidMargin) - 3.5f) * 0.125f;
+    t.vm_w8 = (float)(8 * (ctx->W + 2 * dmi::kValidMargin) - 8);
+    t.vm_base = 8 * (ctx->W / 2 + dmi::kValidMargin) + ctx->H / 2 + dmi::kValidMargin;
     t.vm_bytes = (int32_t)std::min<int64_t>(dmi::valid_map_bytes(ctx->W, ctx->H), 0x7fffffff);
     ctx->h_tile_maps.push_back(t);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max

@@ -97,23 +97,27 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const DepthT *__restr
   pyr[m * P.total_tiles + P.offset[0] + t] = acc.base_tile();
 }
 
-// validity map (TileMapRec::valid): one thread per pixel column of a tile row, eight rows -> eight contiguous bytes
+// validity map (TileMapRec::valid): one thread per pixel column of a tile row of the padded image, eight rows -> eight
+// contiguous bytes; the margin holds zeros ("no depth")
 template <typename DepthT>
 __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict__ depth, int64_t n_maps, int W, int H,
                                                         uint8_t *__restrict__ valid) {
-  const int tile_rows = (H + 7) / 8;
-  const int64_t per_map = (int64_t)tile_rows * W;
+  const int Wp = W + 2 * kValidMargin;
+  const int tile_rows = (H + 2 * kValidMargin + 7) / 8;
+  const int64_t per_map = (int64_t)tile_rows * Wp;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= per_map * n_maps) return;
   const int64_t m = idx / per_map;
   const int64_t r = idx - m * per_map;
-  const int ty = (int)(r / W), x = (int)(r - (int64_t)ty * W);
+  const int ty = (int)(r / Wp), x = (int)(r - (int64_t)ty * Wp) - kValidMargin;
   const DepthT *src = depth + m * (int64_t)W * H;
   unsigned long long bits = 0;
-  for (int q = 0; q < 8; ++q) {
-    const int y = ty * 8 + q;
-    const bool has = y < H && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
-    bits |= (unsigned long long)(has ? 1 : 0) << (8 * q);
+  if (x >= 0 && x < W) {
+    for (int q = 0; q < 8; ++q) {
+      const int y = ty * 8 + q - kValidMargin;
+      const bool has = y >= 0 && y < H && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
+      bits |= (unsigned long long)(has ? 1 : 0) << (8 * q);
+    }
   }
   *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + r * 8) = bits;
 }
@@ -166,6 +170,10 @@ __device__ __forceinline__ TileAcc pyramid_query(const DepthTile *__restrict__ p
 struct BoxFootprint {
   uint8_t cls;
   bool query;
+  // the footprint sticks out of the image: [x0, x1] x [y0, y1] is its part inside (cls stays MIXED_IMAGE_BORDER unless the depth
+  // bounds over that part prove the pair unobservable, border_class)
+  bool partial;
+  bool in_margin;  // partial: the whole footprint lies within kValidMargin pixels of the image
   int x0, x1, y0, y1;
   double czmin, czmax;
 };
@@ -176,6 +184,8 @@ __device__ __forceinline__ BoxFootprint box_footprint_k(const TileArgs &a, const
                                                       int k1) {
   BoxFootprint fp;
   fp.query = false;
+  fp.partial = false;
+  fp.in_margin = false;
   fp.x0 = fp.x1 = fp.y0 = fp.y1 = 0;
   double czmin = __builtin_inf(), czmax = -__builtin_inf();
   double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
@@ -310,6 +320,13 @@ __device__ __forceinline__ BoxFootprint box_footprint_k(const TileArgs &a, const
         fp.x1 = x1;
         fp.y0 = y0;
         fp.y1 = y1;
+      } else {  // partly inside: every voxel's pixel is outside the map (cu:192-197) or in the clipped rectangle
+        fp.partial = true;
+        fp.in_margin = x0 >= -kValidMargin && y0 >= -kValidMargin && x1 < a.W + kValidMargin && y1 < a.H + kValidMargin;
+        fp.x0 = max(x0, 0);
+        fp.x1 = min(x1, a.W - 1);
+        fp.y0 = max(y0, 0);
+        fp.y1 = min(y1, a.H - 1);
       }
     }
   }
@@ -351,11 +368,32 @@ __device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const Ti
   return BRICK_MIXED | ((holes ? MIXED_SENTINEL_AND_DEPTH : MIXED_NEAR_SURFACE) << 2);
 }
 
+// A box whose footprint sticks out of the image (4b.9): its voxels return at cu:192-197, or select a pixel of the clipped
+// rectangle, whose depth bounds are `d`.
+//  * No valid depth there: every voxel returns (cu:202 for those inside): skip.
+//  * All valid depths far in front of the box: a voxel adds +0 (cu:115) or returns -- unobservable when no sum can be -0.0 and
+//    hits are not counted (behind_mask, 4b.6): skip.
+//  * All valid depths far behind the box: a voxel whose pixel is inside the map and holds a depth adds -eta*rho, every other
+//    voxel returns.  That is what MIXED_FREE_OR_NODEPTH says when "outside the map" reads as "no depth" -- and the validity maps
+//    the FREE column asks say exactly that up to kValidMargin pixels outside (`map_serves`: the footprint lies within the margin,
+//    the launch's FREE column reads the maps -- tier-1 instantiations only -- and is used at all -- not with hit counters).
+//  * Anything else stays MIXED_IMAGE_BORDER (BRICK_FREE / BRICK_BEHIND would add to, or count, the voxels outside the map too).
+template <bool GK>
+__device__ __forceinline__ uint8_t border_class(const TileArgs &a, const BoxFootprint &fp, const TileAcc &d) {
+  const uint8_t c = class_from_bounds(a, d, fp.czmin, fp.czmax);
+  if (c == BRICK_SKIP || (c == BRICK_BEHIND && a.behind_mask)) return BRICK_SKIP;
+  const bool map_serves = DMI_TIER1 != 0 && !GK && fp.in_margin && a.behind_mask != 0;
+  if (map_serves && (c == BRICK_FREE || c == (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2))))
+    return BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2);
+  return BRICK_MIXED | (MIXED_IMAGE_BORDER << 2);
+}
+
 template <int kQueryTiles, bool ROT, bool GK>
 __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec *__restrict__ mr,
                                                 const TileMapRec *__restrict__ tr, const PyramidDesc &P, int i0, int i1,
                                                 int j0, int j1, int k0, int k1) {
   const BoxFootprint fp = box_footprint<ROT, GK>(a, mr, tr, i0, i1, j0, j1, k0, k1);
+  if (fp.partial) return border_class<GK>(a, fp, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1));
   if (!fp.query) return fp.cls;
   return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
 }
@@ -388,6 +426,8 @@ __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, 
     const TileAcc d = pyramid_query<5>(maps[m].pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1);
     cls = class_from_bounds(a, d, fp.czmin, fp.czmax);
     speckled = !(d.flags & (TILE_PART_HOLE_FREE | TILE_PART_NO_VALID));
+  } else if (fp.partial) {
+    cls = border_class<GK>(a, fp, pyramid_query<5>(maps[m].pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1));
   }
   // "Free space or no depth" with holes AND depths in every 8 x 8 tile the box's footprint touches (depth maps after the
   // best-cost threshold): the class holds for every brick of the box (its footprint and c.z range lie inside the
@@ -461,6 +501,8 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
     const MapRec *__restrict__ mr = maps + m;
     BoxFootprint fp;
     fp.query = false;
+    fp.partial = false;
+    fp.in_margin = false;
     fp.cls = BRICK_SKIP;
     MapRec mr_u;      // one view per wave: the camera records arrive through scalar loads, once, instead of ~35 vector
     TileMapRec tr_u;  // loads of the same address per lane
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
     } else {
       if (mine) fp = box_footprint<ROT, GK>(a, mr, a.tile_maps + m, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
     }
-    const bool query = mine && fp.query;
+    const bool query = mine && (fp.query || fp.partial);  // depth bounds over the footprint (its part inside the image)
     uint8_t cls = fp.cls;
     const int li = query ? query_level<kQueryTiles>(P, max(fp.x1 - fp.x0, fp.y1 - fp.y0) + 1) : 0x7fff;
     bool from_window = false;
@@ -523,7 +565,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
             TileAcc d;
             for (int ty = ty0; ty <= ty1; ++ty)
               for (int tx = tx0; tx <= tx1; ++tx) d.add_tile(win[(ty - wy0) * kWindow + (tx - wx0)]);
-            cls = class_from_bounds(a, d, fp.czmin, fp.czmax);
+            cls = fp.partial ? border_class<GK>(a, fp, d) : class_from_bounds(a, d, fp.czmin, fp.czmax);
             from_window = true;
           }
           // the next view of this wave stages into the same window: every lane's reads above come first
@@ -532,8 +574,10 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
         }
       }
     }
-    if (query && !from_window)
-      cls = class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
+    if (query && !from_window) {
+      const TileAcc d = pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1);
+      cls = fp.partial ? border_class<GK>(a, fp, d) : class_from_bounds(a, d, fp.czmin, fp.czmax);
+    }
     if (mine) out[m] = cls;
   }
 }
@@ -730,7 +774,7 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 
 hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid, hipStream_t stream) {
   if (n_maps <= 0) return hipSuccess;
-  const int64_t n = (int64_t)((H + 7) / 8) * W * n_maps;
+  const int64_t n = valid_map_bytes(W, H) / 8 * n_maps;
   if (depth_is_f64)
     hipLaunchKernelGGL((valid_map_kernel<double>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const double *>(depth), n_maps, W, H, valid);
   else

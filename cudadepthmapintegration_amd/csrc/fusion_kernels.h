@@ -85,17 +85,26 @@ struct alignas(16) TileMapRec {
   int32_t t1_cidx;  // W * cyc + cxc: pixel index of the image centre
   int32_t t1_ok;
   // Validity map of the view (round 3): one byte per pixel, 1 = the pixel holds a depth (anything but the -1 sentinel), in
-  // tiles of 8 image rows: byte (x, y) at ((y >> 3) * W + x) * 8 + (y & 7), valid_map_bytes(W, H) in all.  The FREE column of
+  // tiles of 8 image rows over the image and its margin (kValidMargin): with X = x + margin, Y = y + margin and Wp = W + 2 margin,
+  // byte (x, y) at ((Y >> 3) * Wp + X) * 8 + (Y & 7), valid_map_bytes(W, H) in all.  The FREE column of
   // the fusion kernel asks only "does my pixel hold a depth?"; an 8 x 8-lane patch of such questions touches a quarter of the
   // cache lines in this layout and a quarter of the bytes, and costs the texture addresser half of what the same gather from
   // the row-major f32 table costs (profiles/r06q_microbench_gather.txt).
   const uint8_t *valid;
   // ... and what turns a centred pixel into a byte of that map (fusion_tile.hip, FREE column), the same for every view of a
-  // context but read with the record, in the same scalar loads: (cyc - 3.5) / 8, 8 W - 8, 8 cxc + cyc, valid_map_bytes
+  // context but read with the record, in the same scalar loads: (cyc + margin - 3.5) / 8, 8 Wp - 8, 8 (cxc + margin) + cyc + margin, valid_map_bytes
   float vm_c0, vm_w8;
   int32_t vm_base, vm_bytes;
 };
-__host__ __device__ inline int64_t valid_map_bytes(int W, int H) { return (int64_t)((H + 7) / 8) * W * 8; }
+#ifndef DMI_TIER1
+#define DMI_TIER1 1  // 0: every instantiation selects its pixels in fp64 only (A/B builds, tools/exp_list*.txt)
+#endif
+// The maps carry a margin of kValidMargin pixels of "no depth" on every side: a pixel that far outside the image reads as a
+// hole, so the FREE column, which has no range test, also serves pairs whose footprint sticks out of the image by less (4b.9).
+constexpr int kValidMargin = 32;  // a multiple of 8 (whole tile rows)
+__host__ __device__ inline int64_t valid_map_bytes(int W, int H) {
+  return (int64_t)((H + 2 * kValidMargin + 7) / 8) * (W + 2 * kValidMargin) * 8;
+}
 static_assert(sizeof(TileMapRec) == 336, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical

@@ -91,9 +91,6 @@ __device__ __forceinline__ int cvt_saturating(double x) {
 }
 
 // ---- tier 1 of the pixel selection: packed fp32 (two floats per lane in a register pair), see the kernel --------------
-#ifndef DMI_TIER1
-#define DMI_TIER1 1  // 0: every instantiation selects its pixels in fp64 only (A/B builds, tools/exp_list*.txt)
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // a * b + c on both halves, a = the float in the low dword of a wave-uniform 64-bit value (an SGPR pair)
 __device__ __forceinline__ f32x2 pk_fma_s(unsigned long long a_bits, f32x2 b, f32x2 c) {
@@ -611,7 +608,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       // map (TileMapRec::valid: bytes in tiles of eight image rows) instead of the f32 table -- a quarter of the lines and
       // bytes per 8 x 8-lane patch, half the texture addresser's time per gather.  Byte index of centred pixel (px'', py''),
       // y = py'' + cyc, yt = y >> 3:  (yt * W + px'' + cxc) * 8 + (y & 7)  =  yt * (8 W - 8) + (8 px'' + py'') + (8 cxc + cyc);
-      // yt = rne((y - 3.5) / 8) exactly for y >= 0; every product and sum is an integer below 2^24 (the host admits tier 1
+      // (x, y, W counted in the map's padded image: fusion_kernels.h)  yt = rne((y - 3.5) / 8) exactly for y >= 0; every product and sum is an integer below 2^24 (the host admits tier 1
       // only while (H + 8) * W + H < 2^24).
       constexpr bool VMAP = T1 && FREEONLY;
       [[maybe_unused]] __amdgpu_buffer_rsrc_t vrsrc = rsrc;
@@ -901,8 +898,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       if constexpr (!COUNT) {
         if (cbyte == ((unsigned)MIXED_FREE_OR_NODEPTH << 2 | BRICK_MIXED))
           column(std::true_type{}, std::false_type{}, std::true_type{});
+#ifndef DMI_EXP_NO_SURFACE_COLUMN  // (code-size experiment, tools/exp_list_codesize.txt)
         else if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
           column(std::true_type{}, std::true_type{}, std::false_type{});
+#endif
         else
           column(std::true_type{}, std::false_type{}, std::false_type{});
       } else {
