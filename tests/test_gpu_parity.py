@@ -447,6 +447,39 @@ def test_tiny_launches_fuse_without_classes(dims, classes):
         assert (sum(hist.values()) > 0) == (classes or not shipped), (dims, shipped, hist)
 
 
+@pytest.mark.parametrize("focal_scale,wh", [(2.5, (96, 72)), (6.0, (48, 36)), (1.4, (160, 120))])
+@pytest.mark.parametrize("speckle", [False, True])
+def test_footprints_that_stick_out_of_the_image(focal_scale, wh, speckle):
+    """Long focal lengths and small images: most bricks project across the image border, many by more than the 32-pixel
+    margin of the validity maps.  Pairs whose part inside the image proves them unobservable are skipped,
+    those in free space within the margin take the FREE column (where "outside" reads as "no depth"), the rest the full
+    column: the grid is the oracle's bit for bit either way, with and without hit counters (which switch both off), and
+    the classes really occur."""
+    grid = scene.default_grid((96, 80, 72))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(9, wh[0], wh[1], seed=41, dense=True, focal_scale=focal_scale)
+    views.K4[:, 0, 2] += 3.25   # principal point off the centre
+    views.K4[:, 1, 2] -= 2.5
+    if speckle:
+        views.depth[np.random.default_rng(3).random(views.depth.shape) < 0.12] = -1.0
+    want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
+                                   n_threads=oracle.max_threads())
+    for count_hits in (False, True):
+        with capi.FusionContext(grid, rp, count_hits=count_hits) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            out = ctx.download_grid()
+            why = ctx.mixed_reason_histogram()
+            if count_hits:
+                vh, mh = ctx.download_hits()
+                assert np.array_equal(vh, vh_w) and np.array_equal(mh, mh_w)
+        assert bits_equal(out, want), (focal_scale, wh, speckle, count_hits)
+        if count_hits:   # hit counters: border pairs stay IMAGE_BORDER; without holes nothing is "free or no depth"
+            assert why["image_border"] > 0 and (speckle or why["free_or_no_depth"] == 0), why
+        else:
+            assert why["free_or_no_depth"] > 0, why   # border pairs in free space (and, with speckle, the holes' pairs)
+
+
 def test_brick_classes_with_fuse_range_and_initial_grid():
     """Classes are indexed by absolute view id: fusing sub-ranges onto a non-zero grid stays bit-exact."""
     grid = scene.default_grid((40, 40, 40))

@@ -9,26 +9,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
+from bench import upload_scene  # noqa: E402
 from cudadepthmapintegration_amd import capi, scene  # noqa: E402
 
 grid = scene.default_grid(512)
 ray = scene.default_ray_potential(grid)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 res = []
-for sc in ("dense", "sparse"):
-    views = scene.make_views(n, 1280, 720, seed=1000, dense=(sc == "dense"), dtype=np.float32)
+for sc in ("dense", "speckle"):
     for storage in ("f32", "f64"):
-        for variant in (0, 224):
-            with capi.FusionContext(grid, ray, grid_dtype="f32", depth_storage=storage, kernel_variant=variant) as c:
-                c.add_views(views)
-                ts = []
-                for r in range(4):
-                    c.reset_grid()
-                    c.fuse()
-                    c.synchronize()
-                    ts.append(c.timings().last_fuse_kernel_ms)
-                rec = {"scene": sc, "views": n, "depth_storage": storage, "variant": variant, "ms": float(np.median(ts[1:])),
-                       "gproj_per_s": grid.n_voxels * n / np.median(ts[1:]) / 1e6, "hist": c.brick_class_histogram()}
-                res.append(rec)
-                print(json.dumps(rec), flush=True)
+        with capi.FusionContext(grid, ray, grid_dtype="f32", depth_storage=storage) as c:
+            upload_scene(c, scene, sc, n, 1280, 720, float(max(grid.spacing)))
+            ts = []
+            for r in range(4):
+                c.reset_grid()
+                c.fuse()
+                c.synchronize()
+                ts.append(c.timings().last_fuse_kernel_ms)
+            rec = {"scene": sc, "views": n, "depth_storage": storage, "ms": float(np.median(ts[1:])),
+                   "gproj_per_s": grid.n_voxels * n / np.median(ts[1:]) / 1e6, "hist": c.brick_class_histogram()}
+            res.append(rec)
+            print(json.dumps(rec), flush=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "f64_depth.json"), "w"), indent=1)
