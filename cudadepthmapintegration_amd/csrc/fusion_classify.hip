@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict
     for (int q = 0; q < 8; ++q) {
       const int y = ty * 8 + q - kValidMargin;
       const bool has = y >= 0 && y < H && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
-      bits |= (unsigned long long)(has ? 1 : 0) << (8 * q);
+      bits |= (unsigned long long)(has ? kValidByte : 0) << (8 * q);
     }
   }
   *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + r * 8) = bits;
@@ -359,8 +359,14 @@ __device__ __forceinline__ uint8_t class_from_bounds(const TileArgs &a, const Ti
   if (d.flags & TILE_HAS_NAN) return BRICK_MIXED | (MIXED_NAN_DEPTH << 2);
   if (!(d.flags & TILE_HAS_VALID)) return BRICK_SKIP;  // only "no depth" pixels (cu:202)
   const bool holes = (d.flags & TILE_HAS_SENTINEL) != 0;
-  if ((czmax - (double)d.dmin) < -a.delta)  // cu:114-115: |diff| > delta and diff < 0 for every voxel with a depth
-    return holes ? (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2)) : (uint8_t)BRICK_FREE;
+  if ((czmax - (double)d.dmin) < -a.delta) {  // cu:114-115: |diff| > delta and diff < 0 for every voxel with a depth
+    if (!holes) return BRICK_FREE;
+    // The FREE column adds fma(m, -eta*rho, sum) with m = 1.0 or +0.0 per lane: a lane without a depth adds a zero of the
+    // constant's sign, which leaves every sum alone if that zero is -0.0 -- or if no sum can be -0.0 (behind_mask, 4b.6).  A
+    // positive constant (eta and rho of opposite signs) on a grid that may hold -0.0 takes the general column instead.
+    const bool free_column_exact = a.behind_mask != 0 || __builtin_signbit(a.free_space);
+    return free_column_exact ? (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2)) : (uint8_t)(BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2));
+  }
   if ((czmin - (double)d.dmax) > a.delta) {  // cu:114-115: diff > delta for every voxel with a depth
     if (!holes) return BRICK_BEHIND;
     return a.behind_mask ? (uint8_t)BRICK_SKIP : (uint8_t)(BRICK_MIXED | (MIXED_SENTINEL_AND_DEPTH << 2));

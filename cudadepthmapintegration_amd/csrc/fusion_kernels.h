@@ -102,6 +102,9 @@ struct alignas(16) TileMapRec {
 // The maps carry a margin of kValidMargin pixels of "no depth" on every side: a pixel that far outside the image reads as a
 // hole, so the FREE column, which has no range test, also serves pairs whose footprint sticks out of the image by less (4b.9).
 constexpr int kValidMargin = 32;  // a multiple of 8 (whole tile rows)
+// A pixel with a depth holds this byte, one without 0: ((1 << byte) - 1) << 20 (one v_bfm_b32) is then the high word of the
+// double 1.0 or +0.0 that the FREE column multiplies its constant with (fusion_tile.hip, phase B)
+constexpr unsigned kValidByte = 10;
 __host__ __device__ inline int64_t valid_map_bytes(int W, int H) {
   return (int64_t)((H + 2 * kValidMargin + 7) / 8) * (W + 2 * kValidMargin) * 8;
 }

@@ -626,7 +626,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // Every lane starts from the "no depth" sentinel and only the lanes that are in the map load over it: phase B then
         // needs no mask from phase A (eight lane masks = sixteen SGPRs the loop does not have), cu:202 covers both.
         typename DL::raw_t dg[kGroup];
-        [[maybe_unused]] unsigned vg[kGroup];  // VMAP: the validity bytes
+        // VMAP: the validity bytes in 16-bit registers, as the load leaves them (widened to 32 bits in C they cost a mask each;
+        // v_bfm_b32 reads five bits)
+        [[maybe_unused]] unsigned short vg[kGroup];
         // (a FREEONLY column of tier 1 never looks at c.z in fp64: neither its pixels nor its sums need it)
         if constexpr (!ROT && !(T1 && FREEONLY)) {
           // exact c.z of the group's voxels first (cu:92, cu:172; h.z == c.z for a pinhole K): r22*wz(k) comes as one
@@ -733,11 +735,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               m_und &= ~m_p2;
             }
             if constexpr (VMAP && UNMASKED) {
-              vg[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(vrsrc, (int)pix, 0, 0);  // 1: the pixel holds a depth
+              vg[q] = __builtin_amdgcn_raw_buffer_load_b8(vrsrc, (int)pix, 0, 0);  // kValidByte: the pixel holds a depth
               if (m_und) {  // wave-uniform branch
                 or_where(undecided, m_und, 1u << kk);
                 und_kk |= 1u << kk;
-                if (__builtin_amdgcn_inverse_ballot_w64(m_und)) vg[q] = 0u;  // the redo below adds this voxel's value
+                if (__builtin_amdgcn_inverse_ballot_w64(m_und)) vg[q] = 0;  // the redo below adds this voxel's value
               }
             } else if constexpr (UNMASKED) {
               dg[q] = DL::load(rsrc, pix);
@@ -853,8 +855,18 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         for (int q = 0; q < kGroup; ++q) {
           const int kk = g0 + q;
           if constexpr (VMAP) {
-            // proven by the classification (4b.8): every depth the footprint holds is far behind the brick
-            acc_add_s<BASE, TK>(kk, ballot(vg[q] != 0u), free_space);  // -eta*rho (cu:115) where the pixel holds a depth
+            // proven by the classification (4b.8): every depth the footprint holds is far behind the brick: -eta*rho (cu:115)
+            // where the pixel holds a depth.  The map's byte there is kValidByte = 10 (else 0, also on lanes whose redo comes
+            // later), and a field of that many bits at bit 20 is the high word of 1.0: sum = fma(1.0 or +0.0, -eta*rho, sum) is
+            // the reference's add on the lanes with a depth and leaves the others alone (class_from_bounds sees to the zero's
+            // sign) -- two vector instructions and nothing for the scalar unit, where the masked add took a compare, the add and
+            // two EXEC moves
+            static_assert(kValidByte == 10, "((1 << 10) - 1) << 20 == 0x3ff00000");
+            unsigned one_or_zero_hi;  // ((1 << byte) - 1) << 20 (hipcc builds the expression from three instructions)
+            // (the byte travels as a 16-bit float: an integer operand of an asm statement is widened first, a mask per voxel;
+            // the instruction reads bits 0..4 of the register and nothing else)
+            asm("v_bfm_b32 %0, %1, 20" : "=v"(one_or_zero_hi) : "v"(__builtin_bit_cast(_Float16, vg[q])));
+            acc_fma_vs<BASE, TK>(kk, __hiloint2double((int)one_or_zero_hi, 0), free_space);
             continue;
           }
           const typename DL::raw_t d = dg[q];  // lanes that did not load still hold the sentinel
