@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const DepthT *__restr
 // contiguous bytes; the margin holds zeros ("no depth")
 template <typename DepthT>
 __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict__ depth, int64_t n_maps, int W, int H,
-                                                        uint8_t *__restrict__ valid) {
+                                                        uint8_t *__restrict__ valid, unsigned long long *__restrict__ n_holes) {
   const int Wp = W + 2 * kValidMargin;
   const int tile_rows = (H + 2 * kValidMargin + 7) / 8;
   const int64_t per_map = (int64_t)tile_rows * Wp;
@@ -112,14 +112,20 @@ __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict
   const int ty = (int)(r / Wp), x = (int)(r - (int64_t)ty * Wp) - kValidMargin;
   const DepthT *src = depth + m * (int64_t)W * H;
   unsigned long long bits = 0;
+  int holes = 0;  // pixels of the image (not of its margin) without a depth
   if (x >= 0 && x < W) {
     for (int q = 0; q < 8; ++q) {
       const int y = ty * 8 + q - kValidMargin;
-      const bool has = y >= 0 && y < H && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
+      const bool inside = y >= 0 && y < H;
+      const bool has = inside && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
       bits |= (unsigned long long)(has ? kValidByte : 0) << (8 * q);
+      holes += inside && !has ? 1 : 0;
     }
   }
   *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + r * 8) = bits;
+  // (how many there are tells the host which launch form the fusion takes, fusion_tile.hip: launch_shape)
+  for (int off = 32; off > 0; off >>= 1) holes += __shfl_xor(holes, off, 64);
+  if (n_holes && (threadIdx.x & 63) == 0 && holes) atomicAdd(n_holes, (unsigned long long)holes);
 }
 
 // level l from level l-1: one thread per tile, 2 x 2 children
@@ -778,13 +784,14 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
   return e;
 }
 
-hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid, hipStream_t stream) {
+hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid,
+                                   unsigned long long *n_holes, hipStream_t stream) {
   if (n_maps <= 0) return hipSuccess;
   const int64_t n = valid_map_bytes(W, H) / 8 * n_maps;
   if (depth_is_f64)
-    hipLaunchKernelGGL((valid_map_kernel<double>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const double *>(depth), n_maps, W, H, valid);
+    hipLaunchKernelGGL((valid_map_kernel<double>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const double *>(depth), n_maps, W, H, valid, n_holes);
   else
-    hipLaunchKernelGGL((valid_map_kernel<float>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const float *>(depth), n_maps, W, H, valid);
+    hipLaunchKernelGGL((valid_map_kernel<float>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const float *>(depth), n_maps, W, H, valid, n_holes);
   return hipGetLastError();
 }
 

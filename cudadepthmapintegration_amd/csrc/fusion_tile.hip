@@ -1085,7 +1085,9 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
                             // (round 3: with holes in the depth maps most pairs are per-voxel work and a brick lives long
                             // enough from fewer views on: 256^3 x 64 views speckle 0.85 against 1.04 ms, dense 0.44 against
                             // 0.43, profiles/r06w_exp_cfg2_forms.json; at 1024^3 the per-brick form keeps winning at 64 views)
-                            (a.n_maps >= 48 && (int64_t)a.bricks_x * a.bricks_y * a.bricks_z <= (int64_t(1) << 18));
+                            // With holes on a larger grid too: 1024^3 x 64 views speckle 27.0 against 29.7 ms -- and dense, where
+                            // most bricks are light, 8.7 against 6.9 (profiles/r08q_exp_cfg5_forms_by_scene.json).
+                            (a.n_maps >= 48 && (cfg.holes || (int64_t)a.bricks_x * a.bricks_y * a.bricks_z <= (int64_t(1) << 18)));
     if (!stay) {
       if (cfg.count_hits)
         hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
