@@ -64,7 +64,7 @@ class InfoC(ctypes.Structure):
     _fields_ = [("n_voxels", ctypes.c_int64), ("n_views", ctypes.c_int32), ("depth_width", ctypes.c_int32),
                 ("depth_height", ctypes.c_int32), ("depth_storage_in_use", ctypes.c_int32),
                 ("grid_dtype", ctypes.c_int32), ("k_mode", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
-                ("tiled_kernel", ctypes.c_int32), ("device_bytes", ctypes.c_uint64)]
+                ("tiled_kernel", ctypes.c_int32), ("device_bytes", ctypes.c_uint64), ("pixels_without_depth", ctypes.c_uint64)]
 
 
 class MultiOptionsC(ctypes.Structure):

@@ -1583,6 +1583,7 @@ int dmi_get_info(dmi_context *ctx, dmi_info *out) {
   for (uint8_t ok : ctx->view_tile_ok) all_tiled = all_tiled && ok;
   out->tiled_kernel = all_tiled ? 1 : 0;
   out->device_bytes = ctx->device_bytes;
+  for (const Batch &bt : ctx->batches) out->pixels_without_depth += bt.holes;
   return DMI_OK;
   });
 }

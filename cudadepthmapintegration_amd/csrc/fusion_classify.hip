@@ -123,9 +123,15 @@ __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict
     }
   }
   *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + r * 8) = bits;
-  // (how many there are tells the host which launch form the fusion takes, fusion_tile.hip: launch_shape)
-  for (int off = 32; off > 0; off >>= 1) holes += __shfl_xor(holes, off, 64);
-  if (n_holes && (threadIdx.x & 63) == 0 && holes) atomicAdd(n_holes, (unsigned long long)holes);
+  // (how many there are tells the host which launch form the fusion takes, fusion_tile.hip: launch_shape.  One atomic per
+  // lane with holes in its eight pixels would be ~10 % of the lanes on thresholded maps: one per wave, over the lanes that are
+  // here -- the last wave of the launch may have lost some to the bound check above)
+  if (n_holes) {
+    const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+    int total = 0;
+    for (int q = 1; q <= 8; ++q) total += q * __builtin_popcountll(__builtin_amdgcn_ballot_w64(holes == q));
+    if (total && (int)__builtin_ctzll(here) == (int)(threadIdx.x & 63)) atomicAdd(n_holes, (unsigned long long)total);
+  }
 }
 
 // level l from level l-1: one thread per tile, 2 x 2 children

@@ -700,6 +700,23 @@ def test_diagnostics_and_layer_tracking():
             ctx.download_grid(np.float64, out=np.zeros(5))
 
 
+def test_info_counts_the_pixels_without_depth():
+    """dmi_info::pixels_without_depth: the -1 pixels of the resident tables as the kernel sees them (after the best-cost
+    threshold; a NaN is not one), counted on the device while the validity maps are built -- over several batches, odd image
+    sizes (the last wave of that kernel is a partial one) and f64 storage."""
+    grid = scene.default_grid((32, 32, 32))
+    rp = scene.default_ray_potential(grid)
+    for wh, storage in (((161, 119), "auto"), ((64, 48), "f64")):
+        views = scene.make_views(5, wh[0], wh[1], seed=12, dense=True, with_best_cost=True)
+        views.depth[1, 7, 9] = np.nan
+        views.depth[2, :5, :] = -1.0
+        want = int((oracle.apply_depth_threshold(views.depth, views.best_cost, 0.8).reshape(views.depth.shape) == -1.0).sum())
+        with capi.FusionContext(grid, rp, depth_storage=storage) as ctx:
+            ctx.add_views(scene.Views(views.depth[:2], views.K4[:2], views.RT4[:2], views.best_cost[:2]), threshold=0.8)
+            ctx.add_views(scene.Views(views.depth[2:], views.K4[2:], views.RT4[2:], views.best_cost[2:]), threshold=0.8)
+            assert int(ctx.info().pixels_without_depth) == want > 0
+
+
 def test_pcie_probe_reports_plausible_rates():
     """dmi_pcie_probe: the pinned copy rates bench.py uses as the floor of its PCIe-inclusive figures."""
     h2d, d2h = capi.pcie_probe(0, 64 << 20)
