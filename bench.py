@@ -730,7 +730,7 @@ def multi_gpu(args, capi, scene, dist, barrier, device_sync, max_over_ranks, wor
                             "kernel": "dmi::fuse_tile_kernel" if li.tiled_kernel else "dmi::fuse_kernel", "kernel_ms": main_ms,
                             "algorithmic_bytes_per_launch": b_alg,
                             "note": "rank 0's fusion kernel (all slabs of one step) over the algorithmic bytes of its own "
-                                    "views and grid; the path is bound by fp64 VALU issue, not HBM (DESIGN.md)"}}
+                                    "views and grid; the path is bound by instruction issue and the texture addresser, not HBM (DESIGN.md 9)"}}
         if check and rank == 0 and args.partition == "views" and args.exchange in ("all_reduce", "peer_copy"):
             # the N-rank grid against this GPU's own fusion of ALL views (same views whatever N is)
             got, _ = m.download_grid(np_grid)
