@@ -565,7 +565,8 @@ def main():
             "algorithmic_bytes_per_launch": b_alg,
             "note": "kernel_ms = hipEvent time of the fusion kernel alone (the launch rocprofv3 lists under this name), "
                     "fuse_ms = all launches of one dmi_fuse (+ cz table, two classification passes, ordering); the path "
-                    "is bound by fp64 VALU issue, not HBM: see roofline_valu and DESIGN.md",
+                    "is bound by instruction issue (vector and scalar) and, with holes in the depth maps, the texture "
+                    "addresser -- not by HBM: see roofline_issue, roofline_valu and DESIGN.md 9",
         },
         "roofline_valu": {
             "bound": "valu_fp64",
