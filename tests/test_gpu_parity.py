@@ -700,6 +700,30 @@ def test_diagnostics_and_layer_tracking():
             ctx.download_grid(np.float64, out=np.zeros(5))
 
 
+@pytest.mark.parametrize("eta", [0.03, -0.2])
+def test_free_column_leaves_negative_zero_alone(eta):
+    """A grid uploaded as -0.0 everywhere, depth maps with holes, and a free-space constant -eta*rho of either sign: a voxel whose
+    pixel holds no depth keeps its -0.0 (cu:202 returns before the add).  The FREE column's multiply-add would turn it into +0.0
+    when the constant is positive, so that class is not given then (class_from_bounds); with a negative constant the product
+    on such a lane is -0.0 and the sum is untouched.  Bit for bit the oracle's grid, signs of zeros included."""
+    grid = scene.default_grid((64, 64, 48))
+    rp = scene.RayPotential(thickness=0.05, rho=0.8, eta=eta, delta=0.2)
+    views = scene.make_views(7, 160, 120, seed=23, dense=True)
+    views.depth[np.random.default_rng(8).random(views.depth.shape) < 0.15] = -1.0
+    init = np.full((48, 64, 64), -0.0)
+    want, _, _ = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, init_grid=init,
+                             n_threads=oracle.max_threads())
+    assert np.signbit(want[want == 0]).any()          # some voxel is never added to and keeps its -0.0
+    with capi.FusionContext(grid, rp) as ctx:
+        ctx.upload_grid(init)
+        ctx.add_views(views)
+        ctx.fuse()
+        out = ctx.download_grid()
+        why = ctx.mixed_reason_histogram()
+    assert np.array_equal(np.ascontiguousarray(out).view(np.uint64), np.ascontiguousarray(want).view(np.uint64))
+    assert (why["free_or_no_depth"] > 0) == (eta > 0), why   # -eta*rho < 0: the class is given; > 0 on this grid: it is not
+
+
 def test_info_counts_the_pixels_without_depth():
     """dmi_info::pixels_without_depth: the -1 pixels of the resident tables as the kernel sees them (after the best-cost
     threshold; a NaN is not one), counted on the device while the validity maps are built -- over several batches, odd image
