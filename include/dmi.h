@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DMI_ABI_VERSION 2
+#define DMI_ABI_VERSION 3 /* 3: dmi_info grew (pixels_without_depth); dmi_iso_active_cells, DMI_EXCHANGE_PEER_COPY, dmi_multi_peer_chunk */
 
 typedef struct dmi_context dmi_context;
 
