@@ -126,11 +126,18 @@ __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict
   // (how many there are tells the host which launch form the fusion takes, fusion_tile.hip: launch_shape.  One atomic per
   // lane with holes in its eight pixels would be ~10 % of the lanes on thresholded maps: one per wave, over the lanes that are
   // here -- the last wave of the launch may have lost some to the bound check above)
+  // n_holes[1]: the lanes' strips of eight pixels (all inside the image) that hold both a hole and a depth -- scattered holes,
+  // as a best-cost threshold leaves them, make most strips such; a silhouette against an empty background hardly any
   if (n_holes) {
     const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
     int total = 0;
     for (int q = 1; q <= 8; ++q) total += q * __builtin_popcountll(__builtin_amdgcn_ballot_w64(holes == q));
-    if (total && (int)__builtin_ctzll(here) == (int)(threadIdx.x & 63)) atomicAdd(n_holes, (unsigned long long)total);
+    const bool whole = x >= 0 && x < W && ty * 8 - kValidMargin >= 0 && ty * 8 - kValidMargin + 7 < H;
+    const int mingled = __builtin_popcountll(__builtin_amdgcn_ballot_w64(whole && holes > 0 && holes < 8));
+    if ((int)__builtin_ctzll(here) == (int)(threadIdx.x & 63)) {
+      if (total) atomicAdd(n_holes, (unsigned long long)total);
+      if (mingled) atomicAdd(n_holes + 1, (unsigned long long)mingled);
+    }
   }
 }
 

@@ -242,7 +242,8 @@ struct FuseConfig {
   int variant;   // tuning variant bits, see launch_fuse / launch_fuse_tiled
   int use_tile;  // host decision: the tiled kernel's preconditions hold
   int general_k; // tiled kernel: some view of the fused range has a K whose third row is not 0 0 1 0 (GENK instantiation)
-  int holes;     // tiled kernel: more than 1 % of the resident views' pixels hold no depth (launch form, launch_shape)
+  int holes;     // tiled kernel: holes scattered all over the resident views (an eighth of their 8-pixel strips hold both a hole
+                 // and a depth: maps after a best-cost threshold) -- column height and launch form (dmi_capi.hip, launch_shape)
 };
 
 // tuning-variant bits (dmi_options::kernel_variant)
@@ -302,7 +303,8 @@ PyramidDesc make_pyramid_desc(int W, int H);
 hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &desc,
                                  DepthTile *pyramids, hipStream_t stream);
 // validity maps (TileMapRec::valid) of n_maps depth tables: valid[n_maps][valid_map_bytes(W, H)]
-// *n_holes (device, nullable) += the pixels without a depth
+// n_holes (device, nullable): [0] += the pixels without a depth, [1] += the strips of 8 pixels (one column of a tile row inside
+// the image) that hold both a hole and a depth
 hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid,
                                    unsigned long long *n_holes, hipStream_t stream);
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.

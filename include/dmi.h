@@ -122,7 +122,7 @@ typedef struct dmi_info {
                            kernel (axis-aligned grid matrix, pinhole K), 0: the general kernel runs */
   uint64_t device_bytes; /* HBM held by the context */
   uint64_t pixels_without_depth; /* of the resident depth tables, after the best-cost threshold (cu:202's -1; counted on the
-                                    device at upload).  More than 1 % of them tilts the choice of the fusion kernel's launch form */
+                                    device at upload) */
 } dmi_info;
 
 /* Fills *opt with the defaults: device 0, f64 grid, AUTO depth storage, no hit counters. */
