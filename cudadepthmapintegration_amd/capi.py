@@ -29,6 +29,8 @@ VARIANT_XCD_RUNS = 8192  # tiled kernel: ordered bricks dealt to the XCDs in run
 VARIANT_ZMAJOR_SLOTS = 16384  # tiled kernel: super-bricks enumerated x, y, z (until r03h) instead of in Z-order
 VARIANT_PERSISTENT_ALWAYS = 32768  # tiled kernel: persistent one-wave workgroups whatever the number of views (default: from 96 on)
 VARIANT_PERSISTENT_NEVER = 65536  # tiled kernel: one workgroup per brick whatever the number of views
+VARIANT_NO_WINDOWS = 262144  # tiled kernel: the FREE column always gathers from the validity maps (no bit windows)
+VARIANT_WINDOWS_ALWAYS = 524288  # tiled kernel: bit windows whatever the depth maps look like (default: maps with scattered holes)
 VARIANT_BRICK_CLASSES_ALWAYS = 131072  # tiled kernel: brick classes for tiny grids too (default: none up to 1024 bricks per launch)
 VARIANT_FIXED_TILE_SHAPE = 4096  # tile-shape bits 0 mean shape 0 (tk16_w5) whatever the grid size; without it grids
                                  # below 512^3 pick tk8_w7 on their own
@@ -96,7 +98,7 @@ ABI_SYMBOLS = [
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_fp64_probe", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
-    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram",
+    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram", "dmi_get_window_pair_count",
     "dmi_color_set_scratch_budget", "dmi_color_set_vertex_reorder", "dmi_iso_active_cells",
     "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_peer_chunk", "dmi_multi_create",
     "dmi_multi_get_unique_id", "dmi_multi_create_rank", "dmi_multi_destroy", "dmi_multi_last_error", "dmi_multi_add_views",
@@ -166,6 +168,8 @@ def load() -> ctypes.CDLL:
                                            ctypes.c_uint64]
     L.dmi_get_brick_class_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_mixed_reason_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    if hasattr(L, "dmi_get_window_pair_count"):  # (absent from an older prebuilt library loaded for an A/B timing, tools/gpu_exp.py)
+        L.dmi_get_window_pair_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -425,6 +429,14 @@ class FusionContext:
         names = ["unspecified", "degenerate", "camera_plane", "image_border", "nan_depth", "sentinel_and_depth", "near_surface",
                  "free_or_no_depth"]
         return {n: int(h[i]) for i, n in enumerate(names)}
+
+    def window_pair_count(self) -> int:
+        """How many "free_or_no_depth" pairs of the last fuse were served from a window of validity bits (diagnostic)."""
+        n = ctypes.c_uint64(0)
+        if not hasattr(self._lib, "dmi_get_window_pair_count"):
+            return 0
+        self._check(self._lib.dmi_get_window_pair_count(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def timings(self) -> TimingsC:
         t = TimingsC()

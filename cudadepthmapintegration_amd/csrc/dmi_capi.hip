@@ -31,6 +31,7 @@ struct Batch {
   void *d_depth = nullptr;             // n * W * H values of the context's current storage type
   dmi::DepthTile *d_pyramid = nullptr;  // n min/max pyramids (fusion_classify.hip), then the n validity maps
   size_t valid_offset = 0;              // byte offset of the validity maps within d_pyramid
+  size_t bits_offset = 0;               // ... and of the validity bits (TileMapRec::vbits) behind them
   size_t aux_bytes = 0;                 // size of the d_pyramid allocation
   int32_t n = 0;
   unsigned long long holes = 0;         // pixels without a depth among the n * W * H (counted while the validity maps are built)
@@ -268,8 +269,10 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
   ctx->device_bytes += npix * n * esz;
   // the pyramids of the batch, and behind them its validity maps (TileMapRec::valid): one allocation
   const size_t pyr_only = ((size_t)ctx->pyramid.total_tiles * n * sizeof(dmi::DepthTile) + 255) / 256 * 256;
-  const size_t pyr_bytes = pyr_only + (size_t)dmi::valid_map_bytes(ctx->W, ctx->H) * n;
+  const size_t maps_end = (pyr_only + (size_t)dmi::valid_map_bytes(ctx->W, ctx->H) * n + 255) / 256 * 256;
+  const size_t pyr_bytes = maps_end + (size_t)dmi::valid_bits_bytes(ctx->W, ctx->H) * n;
   b.valid_offset = pyr_only;
+  b.bits_offset = maps_end;
   b.aux_bytes = pyr_bytes;
   {
     hipError_t pe = hipMalloc(&b.d_pyramid, pyr_bytes);
@@ -315,6 +318,9 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
     if (e == hipSuccess)
       e = dmi::launch_build_valid_maps(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H,
                                        reinterpret_cast<uint8_t *>(b.d_pyramid) + b.valid_offset, ctx->d_lossy + 1, ctx->upload_stream);
+    if (e == hipSuccess)
+      e = dmi::launch_build_valid_bits(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H,
+                                       reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(b.d_pyramid) + b.bits_offset), ctx->upload_stream);
     unsigned long long counters[3] = {0, 0, 0};
     if (e == hipSuccess)
       e = hipMemcpyAsync(counters, ctx->d_lossy, sizeof(counters), hipMemcpyDeviceToHost, ctx->upload_stream);
@@ -585,6 +591,12 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     t.vm_w8 = (float)(8 * (ctx->W + 2 * dmi::kValidMargin) - 8);
     t.vm_base = 8 * (ctx->W / 2 + dmi::kValidMargin) + ctx->H / 2 + dmi::kValidMargin;
     t.vm_bytes = (int32_t)std::min<int64_t>(dmi::valid_map_bytes(ctx->W, ctx->H), 0x7fffffff);
+    t.vbits = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.bits_offset +
+                                                 (size_t)m * (size_t)dmi::valid_bits_bytes(ctx->W, ctx->H));
+    t.vb_bytes = (int32_t)std::min<int64_t>(dmi::valid_bits_bytes(ctx->W, ctx->H), 0x7fffffff);
+    t.vb_rowskip = (dmi::valid_bits_tiles_x(ctx->W) - 1) * 128;
+    t.vb_mx = 0x4B400000 + dmi::kValidMargin + ctx->W / 2;
+    t.vb_my = 0x4B400000 + dmi::kValidMargin + ctx->H / 2;
     ctx->h_tile_maps.push_back(t);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);
@@ -1213,7 +1225,13 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     } else {
       const size_t fine_bytes = ((size_t)t.wbricks_x * t.wbricks_y * t.bricks_z * (size_t)t.class_pitch + 255) / 256 * 256;
       // the coarse table (one row per box of 32^3 voxels) lives behind the brick table in the same allocation
-      const size_t cbytes = fine_bytes + (size_t)dmi::coarse_class_bytes(t, sh.tk);
+      const size_t coarse_end = (fine_bytes + (size_t)dmi::coarse_class_bytes(t, sh.tk) + 255) / 256 * 256;
+      // ... and behind that the window origins of the FREE column (TileArgs::win_origin), one word per class byte
+      // (for depth maps with holes scattered all over them -- cfg.holes: what makes the FREE column the busiest one -- ; the
+      // launch then runs the kernel's WIN instantiation, which pays for the window code in every column, fusion_tile.hip)
+      const bool windows = !cfg.general_k && !cfg.count_hits && !(cfg.variant & (dmi::VAR_NO_WINDOWS | dmi::VAR_NO_INTERIOR)) &&
+                           (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS));
+      const size_t cbytes = coarse_end + (windows ? fine_bytes * 4 : 0);
       ctx->coarse_offset = fine_bytes;
       if (ctx->classes_capacity < cbytes) {
         if (ctx->d_classes) {
@@ -1230,6 +1248,10 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
         ctx->device_bytes += cbytes;
       }
       t.classes = ctx->d_classes;
+      if (windows) {
+        t.win_origin = reinterpret_cast<uint32_t *>(ctx->d_classes + coarse_end);
+        t.win_delta = (int64_t)reinterpret_cast<intptr_t>(t.win_origin) - 4 * (int64_t)reinterpret_cast<intptr_t>(t.classes);
+      }
       if (!(cfg.variant & dmi::VAR_SPATIAL_ORDER)) {
         const size_t n_slots = (size_t)t.super_x * t.super_y * t.super_z * 32;
         if (ctx->order_capacity < n_slots) {
@@ -1556,6 +1578,25 @@ int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]) {
     const uint8_t *row = host.data() + (size_t)b * ctx->last_class_pitch + ctx->last_first;
     for (int32_t m = 0; m < ctx->last_count; ++m)
       if ((row[m] & 3) == dmi::BRICK_MIXED) out[(row[m] >> 2) & 7] += 1;
+  }
+  return DMI_OK;
+  });
+}
+
+int dmi_get_window_pair_count(dmi_context *ctx, uint64_t *out) {
+  return guarded(ctx, "dmi_get_window_pair_count", [&]() -> int {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_window_pair_count: null argument");
+  *out = 0;
+  if (!ctx->last_fuse_classes) return DMI_OK;
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  const size_t bytes = (size_t)ctx->last_class_bricks * ctx->last_class_pitch;
+  std::vector<uint8_t> host(bytes);
+  DMI_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_classes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t b = 0; b < ctx->last_class_bricks; ++b) {
+    const uint8_t *row = host.data() + (size_t)b * ctx->last_class_pitch + ctx->last_first;
+    for (int32_t m = 0; m < ctx->last_count; ++m)
+      if ((row[m] & 3) == dmi::BRICK_MIXED && (row[m] & dmi::CLASS_HAS_WINDOW)) *out += 1;
   }
   return DMI_OK;
   });

@@ -141,6 +141,26 @@ __global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict
   }
 }
 
+// validity bits (TileMapRec::vbits): one wave per 64 consecutive pixels of a row of the padded image -> two dwords, one in each
+// of two neighbouring 32 x 32 tiles.  A block is four consecutive rows of the same 64 columns.
+template <typename DepthT>
+__global__ __launch_bounds__(256) void valid_bits_kernel(const DepthT *__restrict__ depth, int W, int H, uint32_t *__restrict__ bits) {
+  const int tiles_x = valid_bits_tiles_x(W), tiles_y = valid_bits_tiles_y(H);
+  const int lane = threadIdx.x & 63;
+  const int X = blockIdx.x * 64 + lane;                   // padded-image column; the grid covers tiles_x * 32 of them (rounded up to 64)
+  const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);      // padded-image row
+  const int64_t m = blockIdx.z;
+  if (Y >= tiles_y * 32) return;                          // wave-uniform
+  const int x = X - kValidMargin, y = Y - kValidMargin;
+  bool has = false;
+  if (x >= 0 && x < W && y >= 0 && y < H) has = !(depth[(m * H + y) * (int64_t)W + x] == (DepthT)-1);  // cu:202: anything but the sentinel
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+  uint32_t *out = bits + m * (valid_bits_bytes(W, H) / 4);
+  const int tx = X >> 5;  // lane 0: the left tile, lane 32: the right one
+  if ((lane & 31) == 0 && tx < tiles_x)
+    out[((int64_t)(Y >> 5) * tiles_x + tx) * 32 + (Y & 31)] = (uint32_t)(mask >> (lane & 32));
+}
+
 // level l from level l-1: one thread per tile, 2 x 2 children
 __global__ __launch_bounds__(256) void pyramid_up_kernel(int64_t n_maps, int level, PyramidDesc P, DepthTile *__restrict__ pyr) {
   const int64_t tiles = (int64_t)P.width[level] * P.height[level];
@@ -194,6 +214,7 @@ struct BoxFootprint {
   bool partial;
   bool in_margin;  // partial: the whole footprint lies within kValidMargin pixels of the image
   int x0, x1, y0, y1;
+  int rx0, rx1, ry0, ry1;  // query or partial: the footprint as proven, before it is clipped to the image
   double czmin, czmax;
 };
 
@@ -206,6 +227,7 @@ __device__ __forceinline__ BoxFootprint box_footprint_k(const TileArgs &a, const
   fp.partial = false;
   fp.in_margin = false;
   fp.x0 = fp.x1 = fp.y0 = fp.y1 = 0;
+  fp.rx0 = fp.rx1 = fp.ry0 = fp.ry1 = 0;
   double czmin = __builtin_inf(), czmax = -__builtin_inf();
   double umin = __builtin_inf(), umax = -__builtin_inf(), vmin = __builtin_inf(), vmax = -__builtin_inf();
   // General K (third row not 0 0 1 0, cu:176): the divisor of cu:183-184 and the subject of cu:177 is h.z, an affine
@@ -331,6 +353,10 @@ __device__ __forceinline__ BoxFootprint box_footprint_k(const TileArgs &a, const
       const int x0 = (int)ceil(umin - 0.5 - e), x1 = (int)floor(umax + 0.5 + e);
       const int y0 = (int)ceil(vmin - 0.5 - e), y1 = (int)floor(vmax + 0.5 + e);
       cls = BRICK_MIXED | (MIXED_IMAGE_BORDER << 2);
+      fp.rx0 = x0;
+      fp.rx1 = x1;
+      fp.ry0 = y0;
+      fp.ry1 = y1;
       if (x1 < 0 || y1 < 0 || x0 >= a.W || y0 >= a.H) {
         cls = BRICK_SKIP;  // every voxel projects outside the map (cu:192-197)
       } else if (x0 >= 0 && y0 >= 0 && x1 < a.W && y1 < a.H) {
@@ -607,6 +633,41 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   }
 }
 
+// Windows of the FREE column (fusion_tile.hip): for every pair of class MIXED_FREE_OR_NODEPTH the footprint of the BRICK (the
+// class may have come down from its box unrefined), as proven by box_footprint (4b.2, 4b.9): every voxel's reference pixel lies
+// in [rx0, rx1] x [ry0, ry1], inside the image or its margin.  Where that rectangle fits a window of kWindowCols x kWindowRows
+// pixels and the view runs tier 1, the pair's origin is written and its class byte marked; every other pair keeps the gathering
+// column.  One thread per (brick, view): threadIdx.x over 64 consecutive views (coalesced class bytes and origins).
+template <bool ROT>
+__global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, const MapRec *__restrict__ maps, int tk,
+                                                            uint8_t *__restrict__ classes, uint32_t *__restrict__ origins) {
+  const int bz_first = 2 * a.sbz_first;
+  const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
+  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
+  const int64_t local = (int64_t)blockIdx.x * 4 + threadIdx.y;
+  const int mm = blockIdx.y * 64 + threadIdx.x;
+  if (local >= n_bricks || mm >= a.n_maps) return;
+  const int m = a.first_map + mm;
+  const int bx = (int)(local % a.wbricks_x);
+  const int64_t t = local / a.wbricks_x;
+  const int by = (int)(t % a.wbricks_y), bz = (int)(t / a.wbricks_y) + bz_first;
+  const int64_t at = (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m;
+  const uint8_t c = classes[at];
+  if ((c & 0x1f) != (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2))) return;
+  const TileMapRec *__restrict__ tr = a.tile_maps + m;
+  uint8_t out = c & 0x1f;
+  // (a brick that sticks out of the top of the grid takes the column with every test, fusion_tile.hip: no window for it)
+  if (tr->t1_ok && bz * tk + tk <= a.nz) {
+    const BoxFootprint fp = box_footprint_k<ROT, false>(a, maps + m, tr, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+    const bool inside = fp.query || (fp.partial && fp.in_margin);
+    if (inside && fp.rx1 - fp.rx0 < kWindowCols && fp.ry1 - fp.ry0 < kWindowRows) {
+      origins[at] = (uint32_t)(fp.rx0 + kValidMargin) | ((uint32_t)(fp.ry0 + kValidMargin) << 16);
+      out |= CLASS_HAS_WINDOW;
+    }
+  }
+  if (out != c) classes[at] = out;
+}
+
 // ---- heavy bricks first -------------------------------------------------------------------------------
 // A workgroup whose brick is near a surface in every map runs the per-voxel path 256 times; one in free space
 // only adds constants.  Dispatched in spatial order, the heavy ones that start late run on an almost empty chip
@@ -805,6 +866,32 @@ hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t 
     hipLaunchKernelGGL((valid_map_kernel<double>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const double *>(depth), n_maps, W, H, valid, n_holes);
   else
     hipLaunchKernelGGL((valid_map_kernel<float>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const float *>(depth), n_maps, W, H, valid, n_holes);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_valid_bits(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint32_t *bits,
+                                   hipStream_t stream) {
+  if (n_maps <= 0) return hipSuccess;
+  if (n_maps > 65535) return hipErrorInvalidConfiguration;
+  const dim3 grid((unsigned)((valid_bits_tiles_x(W) * 32 + 63) / 64), (unsigned)(valid_bits_tiles_y(H) * 8), (unsigned)n_maps);
+  if (depth_is_f64)
+    hipLaunchKernelGGL((valid_bits_kernel<double>), grid, dim3(256), 0, stream, static_cast<const double *>(depth), W, H, bits);
+  else
+    hipLaunchKernelGGL((valid_bits_kernel<float>), grid, dim3(256), 0, stream, static_cast<const float *>(depth), W, H, bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_origins(const TileArgs &a, const MapRec *maps_dev, int tk, uint8_t *classes, int general_k,
+                                 hipStream_t stream) {
+  if (general_k || !a.win_origin || a.n_maps <= 0) return hipSuccess;  // (GENK launches have no tier 1: no window column)
+  const int bz_count = std::min(2 * a.super_z, a.bricks_z - 2 * a.sbz_first);
+  const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
+  if (n_bricks <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((n_bricks + 3) / 4), (unsigned)((a.n_maps + 63) / 64));
+  if (a.rotated)
+    hipLaunchKernelGGL((window_origin_kernel<true>), grid, dim3(64, 4), 0, stream, a, maps_dev, tk, classes, a.win_origin);
+  else
+    hipLaunchKernelGGL((window_origin_kernel<false>), grid, dim3(64, 4), 0, stream, a, maps_dev, tk, classes, a.win_origin);
   return hipGetLastError();
 }
 

@@ -95,6 +95,15 @@ struct alignas(16) TileMapRec {
   // context but read with the record, in the same scalar loads: (cyc + margin - 3.5) / 8, 8 Wp - 8, 8 (cxc + margin) + cyc + margin, valid_map_bytes
   float vm_c0, vm_w8;
   int32_t vm_base, vm_bytes;
+  // Validity BITS of the view (round 4): one bit per pixel of the padded image (the same margin), in tiles of 32 x 32 pixels =
+  // 32 dwords = one 128-byte line: bit (X & 31) of dword ((Y >> 5) * tiles_x + (X >> 5)) * 32 + (Y & 31), valid_bits_bytes(W, H)
+  // in all.  The FREE column's window form (fusion_tile.hip) fetches, per (brick, view), the 32 x 64 pixel window that holds
+  // every voxel's pixel -- one row per lane, two dword loads from one or two lines each -- and asks it with ds_bpermute_b32.
+  const uint32_t *vbits;
+  int32_t vb_bytes;    // valid_bits_bytes(W, H): the buffer range of one view's bits
+  int32_t vb_rowskip;  // (tiles_x - 1) * 128: what a step to the next tile row adds beyond the 128 bytes of the tile itself
+  int32_t vb_mx, vb_my;  // 0x4B400000 + margin + W / 2 (H / 2): the bits of the float 1.5 * 2^23 + (centre of the padded image)
+  int32_t vb_pad[2];
 };
 #ifndef DMI_TIER1
 #define DMI_TIER1 1  // 0: every instantiation selects its pixels in fp64 only (A/B builds, tools/exp_list*.txt)
@@ -108,7 +117,16 @@ constexpr unsigned kValidByte = 10;
 __host__ __device__ inline int64_t valid_map_bytes(int W, int H) {
   return (int64_t)((H + 2 * kValidMargin + 7) / 8) * (W + 2 * kValidMargin) * 8;
 }
-static_assert(sizeof(TileMapRec) == 336, "TileMapRec layout");
+// the same image in bits (TileMapRec::vbits): tiles of 32 x 32 pixels, one column of tiles more than the padded image needs (a
+// window's second dword may lie in it)
+__host__ __device__ inline int valid_bits_tiles_x(int W) { return (W + 2 * kValidMargin + 31) / 32 + 1; }
+__host__ __device__ inline int valid_bits_tiles_y(int H) { return (H + 2 * kValidMargin + 31) / 32; }
+__host__ __device__ inline int64_t valid_bits_bytes(int W, int H) { return (int64_t)valid_bits_tiles_x(W) * valid_bits_tiles_y(H) * 128; }
+// the window of the FREE column: kWindowCols x kWindowRows pixels (a dword per lane); a class byte with CLASS_HAS_WINDOW says
+// that TileArgs::win_origin holds the window's first pixel for the pair
+constexpr int kWindowCols = 32, kWindowRows = 64;
+constexpr uint8_t CLASS_HAS_WINDOW = 0x20;
+static_assert(sizeof(TileMapRec) == 368, "TileMapRec layout");
 
 // How much of K's structure the uploaded views share; checked on the host, value-identical
 // shortcuts proven in DESIGN.md ("K specialisation").
@@ -196,6 +214,12 @@ struct TileArgs {
   int64_t wg_times_n;
   // brick counters of the persistent workgroups, one per XCD at [16 * xcd]; zeroed by the table kernel of every launch
   int32_t *queue_heads;
+  // Windows of the FREE column (round 4): for a pair whose class byte carries CLASS_HAS_WINDOW, win_origin[brick * class_pitch +
+  // view] = x0 | y0 << 16, the first pixel (padded-image coordinates) of a kWindowCols x kWindowRows window that holds the
+  // reference's pixel of every voxel of the brick (window_origin_kernel, fusion_classify.hip).  The fusion kernel reaches the
+  // entry from the brick's class row: (uint32_t *)(win_delta + 4 * (intptr_t)row) + view, win_delta = win_origin - 4 * classes.
+  uint32_t *win_origin;
+  int64_t win_delta;
 };
 constexpr int kFreeSumsMax = 4096;
 // an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)
@@ -263,7 +287,9 @@ enum VariantBits : int {
   VAR_ZMAJOR_SLOTS = 16384,     // tiled kernel: super-bricks enumerated x fastest, then y, then z (until r03h) instead of in Z-order
   VAR_PERSISTENT_ALWAYS = 32768,  // tiled kernel, one-wave workgroups: persistent whatever the number of views (default: from 96 views on)
   VAR_PERSISTENT_NEVER = 65536,   // tiled kernel, one-wave workgroups: one workgroup per brick whatever the number of views
-  VAR_BRICK_CLASSES_ALWAYS = 131072  // tiled kernel: classify and order the bricks of tiny grids too (default: not below 1025 bricks)
+  VAR_BRICK_CLASSES_ALWAYS = 131072,  // tiled kernel: classify and order the bricks of tiny grids too (default: not below 1025 bricks)
+  VAR_NO_WINDOWS = 262144,           // tiled kernel: the FREE column always gathers from the validity maps (no bit windows)
+  VAR_WINDOWS_ALWAYS = 524288        // tiled kernel: bit windows whatever the depth maps look like (default: maps with scattered holes)
 };
 
 constexpr int kMaxColumnHeight = 16;  // the tallest column of any tile shape: what z-slab partitions must be multiples of
@@ -307,6 +333,13 @@ hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_
 // the image) that hold both a hole and a depth
 hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid,
                                    unsigned long long *n_holes, hipStream_t stream);
+// validity bits (TileMapRec::vbits) of n_maps depth tables: bits[n_maps][valid_bits_bytes(W, H) / 4]
+hipError_t launch_build_valid_bits(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint32_t *bits,
+                                   hipStream_t stream);
+// window origins of the FREE column for the pairs of class MIXED_FREE_OR_NODEPTH of maps [first_map, first_map + n_maps): fills
+// args.win_origin and marks the class bytes (CLASS_HAS_WINDOW); after launch_classify_bricks
+hipError_t launch_window_origins(const TileArgs &args, const MapRec *maps_dev, int tk, uint8_t *classes, int general_k,
+                                 hipStream_t stream);
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.
 // general_k: some view of the run has a K with a general third row (the kernels then look at every view's errz)
 hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, const PyramidDesc &desc, int tk,

@@ -110,6 +110,18 @@ __device__ __forceinline__ f32x2 pk_fnma_lo(f32x2 a, f32x2 b, f32x2 c) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// a * b.x + c on both halves, c = a wave-uniform pair of floats (an SGPR pair)
+__device__ __forceinline__ f32x2 pk_fma_lo_s(f32x2 a, f32x2 b, unsigned long long c_bits) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "s"(c_bits));
+  return d;
+}
+// a - c on both halves, c = a wave-uniform pair of floats (an SGPR pair)
+__device__ __forceinline__ f32x2 pk_sub_s(f32x2 a, unsigned long long c_bits) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "s"(c_bits));
+  return d;
+}
 // max(|a|, |b|) as ONE instruction (a C expression may pay a canonicalising v_max first)
 __device__ __forceinline__ float max_abs(float a, float b) {
   float d;
@@ -234,10 +246,14 @@ constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw
 // (cu:177) is proven from h.z -+ errz, and whatever is not proven goes through the exact expression as before.  c.z
 // -- what enters the ray potential -- is exact in every instantiation.  Pinhole views run through the same code: for
 // them h.z restates c.z and errz is 0.
+// WIN: the launch has window origins (TileArgs::win_origin: depth maps with holes scattered all over them); pairs marked
+// CLASS_HAS_WINDOW take the window form of the FREE column.  An instantiation of its own: the other launches run the kernel
+// without a trace of it (its code costs every column scalar registers, i.e. spill traffic, whether or not a pair uses it).
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false, bool GENK = false,
-          bool STAY = (WX * WY == 1)>
+          bool STAY = (WX * WY == 1), bool WIN = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
+  static_assert(!WIN || (DMI_TIER1 != 0 && !GENK && !COUNT && WX * WY == 1), "the window column is a tier-1 column without hit counters");
   // The argument block is read where it is needed, straight from the kernarg segment (scalar loads), instead of through
   // the by-value parameter: the view loop below has no scalar registers to spare, and what it does not use must not stay
   // live across it.  KA(f): a plain load (the compiler may keep it); KC(f): a load the compiler cannot hoist or merge
@@ -421,7 +437,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     acc_set<BASE, TK>(kk, v0);
   }
 
-  const mask_t m_lane_ok = ballot(lane_ok);
+  const mask_t m_lane_ok_brick = ballot(lane_ok);
 
   // brick classes of this wave's brick: one byte per map (fusion_classify.hip), eight maps per scalar load
   // (a fuse without classes points every brick at one all-BRICK_MIXED row: class_pitch 0)
@@ -442,7 +458,20 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // (`fr`) are two byte-granular masks, derived once per word and carried across the per-voxel body; a view costs an s_ff1, a
   // count of the free views before it and the clearing of its bit instead of the whole derivation (round 3: ~45 -> ~18 scalar
   // instructions per view with work, and no kernarg load at the loop head).
+  // window origins of this brick's views (TileArgs::win_origin), 64 views at a time: lane l holds the entry of view
+  // 64 * org_block + l -- one coalesced load per 64 views instead of a dependent scalar load per view (the table is read
+  // once: every entry comes from HBM)
+  [[maybe_unused]] uint32_t org_vec = 0;
   for (int wbase = first_map & ~7; wbase < m_end; wbase += 8) {
+    if constexpr (WIN) {
+      if ((wbase & 56) == 0 || wbase == (first_map & ~7)) {  // wave-uniform: the first word of a block of 64 views, or of the fusion
+        const kernarg_t ko = KFRESH();
+        if (ko->win_origin) {
+          const uint32_t *row = reinterpret_cast<const uint32_t *>(ko->win_delta + 4 * (int64_t)reinterpret_cast<intptr_t>(crow));
+          org_vec = row[(wbase & ~63) + lane];
+        }
+      }
+    }
     // fetched one word ahead: its latency hides behind this word's views.  behind_mask turns BEHIND (2) into SKIP (3)
     // when x + 0.0 == x for every running sum: sums that start at +0.0 never become -0.0
     const unsigned long long cword = cnext | ((cnext >> 1) & KC(behind_mask));
@@ -479,7 +508,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       for (int q = 0; q < TK; ++q) acc_set<BASE, TK>(q, v);
       n_uniform = -1;
     }
-    const unsigned cbyte = (unsigned)(cword >> vbit) & 0x1fu;  // class in bits 0..1, MixedReason above it
+    const unsigned cbyte = (unsigned)(cword >> vbit) & 0x3fu;  // class in bits 0..1, MixedReason above it, CLASS_HAS_WINDOW
     const unsigned cls = cbyte & 3u;
     if (cls != BRICK_MIXED) {
       // BEHIND: +0 (cu:115; adding 0 turns -0.0 into +0.0 as the reference does); FREE when hits are counted
@@ -489,17 +518,180 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       if (COUNT) {
 #pragma unroll
         for (int q = 0; q < TK; ++q) nh[q] += lane_ok ? 1u : 0u;
-        const uint32_t hits = (uint32_t)__popcll(m_lane_ok) * (uint32_t)kcount;
+        const uint32_t hits = (uint32_t)__popcll(m_lane_ok_brick) * (uint32_t)kcount;
         if (hits != 0 && lane == 0) atomicAdd(&KC(map_hits)[m], (unsigned long long)hits);
       }
       continue;
     }
+    // ---- A pair with a WINDOW of validity bits (round 4): the FREE column without a gather per voxel.  The
+    // pair's class byte carries CLASS_HAS_WINDOW: window_origin_kernel has proven that every voxel's reference pixel lies in
+    // the 32 x 64 pixels that start at (x0, y0) = TileArgs::win_origin[brick][view] (padded-image coordinates).  Lane r fetches
+    // row y0 + r of the view's validity bits (two dwords from one or two 128-byte tiles, funnel-shifted to start at x0): two
+    // coalesced loads per (brick, view), in flight while the column is set up.  A voxel asks the lane that holds its row with
+    // ds_bpermute_b32.  The candidate is formed WITH the window's origin: rpm = fl32(h'' * rcp + (1.5 * 2^23 - origin)) is an
+    // integer-valued float whose low mantissa bits are the pixel's column / row within the window (v_bfe_u32 and
+    // ds_bpermute_b32 read only those bits), and P = rpm - (1.5 * 2^23 - origin), exact, is the candidate that the verification
+    // of tier 1 accepts or not (4d.3: any candidate will do).  What it does not accept is redone after the column, in fp64
+    // (tier 2), then with the reference's expression.  The whole view is handled here, apart from the other columns, so that
+    // nothing of it stays live across them.
+    if constexpr (WIN) {
+      if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
+        const kernarg_t kw = KFRESH();
+        const TileMapRec *rec = kw->tile_maps + m;
+        const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)org_vec, m & 63);
+        const int x0p = (int)(org & 0xffffu), y0p = (int)(org >> 16);
+        const __amdgpu_buffer_rsrc_t brsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cload(&rec->vbits)), (short)0, cload(&rec->vb_bytes), 0x00020000);
+        // byte offset of row Y's dword in tile column tx: ((Y >> 5) * tiles_x + tx) * 128 + (Y & 31) * 4
+        const unsigned lin = ((unsigned)lane << 2) + ((unsigned)y0p << 2);
+        const unsigned off = __umul24(lin >> 7, (unsigned)cload(&rec->vb_rowskip)) + lin + (((unsigned)x0p >> 5) << 7);
+        const uint32_t w_lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)off, 0, 0);
+        const uint32_t w_hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)(off + 128u), 0, 0);
+        // the floats 1.5 * 2^23 - (origin - centre), x in the low word, y in the high one
+        const unsigned long long M2 =
+            (unsigned long long)(unsigned)(cload(&rec->vb_mx) - x0p) | ((unsigned long long)(unsigned)(cload(&rec->vb_my) - y0p) << 32);
+        // fp64 values at the column's first voxel: the centred h.x, h.y (TileMapRec::cpx ...) and the exact c.z (cu:92, cu:172),
+        // as every tier-1 column starts from them; formed again by the redo below, so that they do not stay live
+        auto first_voxel = [&](double &hxf, double &hyf, double &czf64) __attribute__((always_inline)) {
+          const kernarg_t kf = KFRESH();
+          const TileMapRec *rf = kf->tile_maps + m;
+          double wxf = wx, wyf = wy, wzf = wz0;
+          if constexpr (ROT) {
+            const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kf->cz_table + (int64_t)k0 * 4));
+            wxf = (wx + b[0]) + kf->g[3], wyf = (wy + b[1]) + kf->g[7], wzf = (wz0 + b[2]) + kf->g[11];
+            czf64 = ((cload(&rf->rz0) * wxf + cload(&rf->rz1) * wyf) + cload(&kf->maps[m].rt[10]) * wzf) + cload(&rf->rz3);
+          } else {
+            czf64 = ((cload(&rf->rz0) * wx + cload(&rf->rz1) * wy) + cload(kf->cz_table + (int64_t)m * kf->kpad + k0)) + cload(&rf->rz3);
+          }
+          hxf = __builtin_fma(cload(&rf->cpx), wxf, __builtin_fma(cload(&rf->cpy), wyf, __builtin_fma(cload(&rf->cpz), wzf, cload(&rf->cp0))));
+          hyf = __builtin_fma(cload(&rf->cqx), wxf, __builtin_fma(cload(&rf->cqy), wyf, __builtin_fma(cload(&rf->cqz), wzf, cload(&rf->cq0))));
+        };
+        f32x2 H0, C0, DH, DC;
+        {
+          double hxf, hyf, czf64;
+          first_voxel(hxf, hyf, czf64);
+          const float czf = (float)czf64;
+          H0.x = (float)hxf;
+          H0.y = (float)hyf;
+          // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column (4d)
+          const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
+          const float thr = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
+          // lanes outside the grid own no voxel (their sums are never stored): with c.z = 1 and an infinite threshold they accept
+          // whatever candidate they form, so "not accepted" needs no mask of the lanes that count
+          C0.x = lane_ok ? czf : 1.0f;
+          C0.y = lane_ok ? thr : __builtin_inff();
+        }
+        DH.x = cload(&rec->t1_dhx);
+        DH.y = cload(&rec->t1_dhy);
+        DC.x = cload(&rec->t1_dcz);
+        DC.y = cload(&rec->t1_dthr);
+        asm volatile("" : "+v"(DH), "+v"(DC));  // wave-uniform, but VGPR operands of the packed FMAs: placed there once per view
+        uint32_t undecided = 0, und_kk = 0;  // per lane / wave-uniform: bit kk = voxel kk is redone after the column
+        uint32_t window = 0;                 // this lane's row of the window
+        constexpr int WG = 4;                // look-ups in flight
+  #pragma unroll
+        for (int g0 = 0; g0 < TK; g0 += WG) {
+          uint32_t wg[WG], cg[WG];
+          // ---- the group's candidates and their verification (the window's loads are still in flight during the first group's)
+  #pragma unroll
+          for (int q = 0; q < WG; ++q) {
+            const int kk = g0 + q;
+            f32x2 h = H0, cth = C0;
+            if (kk > 0) {
+              const unsigned long long kbits = (unsigned long long)(unsigned)__float_as_int((float)kk);
+              h = pk_fma_s(kbits, DH, H0);
+              cth = pk_fma_s(kbits, DC, C0);
+            }
+            f32x2 rr;
+            rr.x = rcp_f32_for_asm(cth.x);
+            const f32x2 rpm = pk_fma_lo_s(h, rr, M2);
+            const f32x2 rp = pk_sub_s(rpm, M2);
+            const f32x2 t = pk_fnma_lo(rp, cth, h);
+            const mask_t m_und = ballot(!(max_abs(t.x, t.y) < cth.y));  // (a NaN is not accepted)
+            wg[q] = (unsigned)__float_as_int(rpm.y) << 2;  // the row's lane, as ds_bpermute_b32 addresses it
+            cg[q] = (uint32_t)__float_as_int(rpm.x);
+            if (m_und) {  // wave-uniform, rare
+              or_where(undecided, m_und, 1u << kk);
+              und_kk |= 1u << kk;
+            }
+          }
+          // the two dwords become the 32 columns from x0 on
+          if (g0 == 0) window = __builtin_amdgcn_alignbit(w_hi, w_lo, (unsigned)x0p & 31u);
+  #pragma unroll
+          for (int q = 0; q < WG; ++q) wg[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wg[q], (int)window);
+          if ((und_kk >> g0) & ((1u << WG) - 1u)) {  // wave-uniform, rare: some lane of the group was not accepted
+            // the redo below adds that voxel's value: here its word counts as empty
+  #pragma unroll
+            for (int q = 0; q < WG; ++q) wg[q] &= ((undecided >> (g0 + q)) & 1u) - 1u;
+          }
+  #pragma unroll
+          for (int q = 0; q < WG; ++q) {
+            // -eta*rho (cu:115) where the pixel holds a depth: sum = fma(1.0 or +0.0, -eta*rho, sum), as the gathering column
+            uint32_t bit;
+            asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(wg[q]), "v"(cg[q]));
+            acc_fma_vs<BASE, TK>(g0 + q, (double)bit, free_space);
+          }
+        }
+        // ---- the voxels in which some lane was not accepted (about 2 % of a wave's): tier 2 (DESIGN.md 4.1-4.5 in centred
+        // coordinates), then the reference's own expression for what that leaves; at most one add per voxel and view, after the
+        // column and before the next view: every voxel accumulates in view order (cu:211)
+#pragma unroll 1
+        while (und_kk) {  // wave-uniform
+          const int kk = __builtin_ctz(und_kk);
+          und_kk &= und_kk - 1;
+          const bool mine = (undecided >> kk) & 1u;
+          const kernarg_t k2 = KFRESH();
+          const TileMapRec *r2 = k2->tile_maps + m;
+          double hxf, hyf, czf64;
+          first_voxel(hxf, hyf, czf64);
+          const double kd = (double)kk;
+          const double hxk = __builtin_fma(kd, cload(&r2->cdhx), hxf), hyk = __builtin_fma(kd, cload(&r2->cdhy), hyf);
+          double cz2;  // the exact c.z of this voxel (cu:92, cu:172)
+          if constexpr (ROT) {
+            const czvec4 b = cload(reinterpret_cast<const czvec4 *>(k2->cz_table + (int64_t)(k0 + kk) * 4));
+            const double wxk = (wx + b[0]) + k2->g[3], wyk = (wy + b[1]) + k2->g[7], wzk = (wz0 + b[2]) + k2->g[11];
+            cz2 = ((cload(&r2->rz0) * wxk + cload(&r2->rz1) * wyk) + cload(&k2->maps[m].rt[10]) * wzk) + cload(&r2->rz3);
+          } else {
+            cz2 = ((cload(&r2->rz0) * wx + cload(&r2->rz1) * wy) + cload(k2->cz_table + (int64_t)m * k2->kpad + k0 + kk)) + cload(&r2->rz3);
+          }
+          const double r0 = __builtin_amdgcn_rcp(cz2);
+          const double e0 = __builtin_fma(-cz2, r0, 1.0);
+          const double r = __builtin_fma(r0, e0, r0);
+          const double ua2 = hxk * r, va2 = hyk * r;
+          const double ru2 = __builtin_rint(ua2), rv2 = __builtin_rint(va2);
+          const double fu = ua2 - ru2, fv = va2 - rv2;
+          const double chk = __builtin_fma(cload(&r2->cerrk), r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
+          const bool p2 = mine && chk < 0.5 && __builtin_fabs(e0) < tiny;
+          // a proven pixel is the reference's and lies in the window; column and row within it: the centred pixel minus the
+          // window's first one, 0x4B400000 - (a word of M2).  The other lanes' look-up is not used.
+          const int col = cvt_saturating(ru2) + ((int)(unsigned)M2 - 0x4B400000), row = cvt_saturating(rv2) + ((int)(unsigned)(M2 >> 32) - 0x4B400000);
+          const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(row << 2, (int)window);
+          double val = free_space;  // 4b.8: every voxel of the pair with a depth accumulates -eta*rho (cu:115)
+          bool hit = p2 && ((word >> (col & 31)) & 1u);
+          const bool exact = mine && !p2;
+          if (ballot(exact)) {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&r2->depth)), (short)0, k2->depth_bytes, 0x00020000);
+            double ev = 0.0;
+            const bool eh = exact ? tile_exact<DepthT>(KC(full), m, rsrc, i, j, k0 + kk, ev) : false;
+            if (exact) {
+              hit = eh;
+              val = ev;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < TK; ++q) {
+            if (kk == q) acc_add_v<BASE, TK>(q, ballot(hit), val);  // wave-uniform
+          }
+        }
+        continue;
+      }
+    }
     const kernarg_t kv = KFRESH();                              // this view's reads of the argument block
     const TileMapRec *rec = kv->tile_maps + m;                  // wave-uniform -> scalar loads
     const double *ct = kv->cz_table + (int64_t)m * kv->kpad + k0;  // r22*wz(k), wave-uniform
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&rec->depth)), (short)0, kv->depth_bytes, 0x00020000);
-
+    // (the depth table's buffer descriptor is formed where it is used -- in the column, and again on the rare exact path --: four
+    // scalar registers that would otherwise stay live from here to the end of the view)
     // exact: the part of c.z shared by the whole column, (r20*wx + r21*wy)  (cu:92).  Lanes outside
     // the grid get -inf: their c.z is -inf, i.e. "behind the camera" (cu:177), at no cost per voxel.
     // Voxels above the grid (k >= nz) get the same through a -inf entry of the cz table.
@@ -611,6 +803,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       // (x, y, W counted in the map's padded image: fusion_kernels.h)  yt = rne((y - 3.5) / 8) exactly for y >= 0; every product and sum is an integer below 2^24 (the host admits tier 1
       // only while (H + 8) * W + H < 2^24).
       constexpr bool VMAP = T1 && FREEONLY;
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&rec->depth)), (short)0, KC(depth_bytes), 0x00020000);
+      // the lanes that are voxels: a copy of the brick's mask that lives for this column only (the long-lived one may then wait
+      // in a spill slot across the column instead of being fetched from it for every voxel)
+      mask_t m_lane_ok = m_lane_ok_brick;
+      asm volatile("" : "+s"(m_lane_ok));
       [[maybe_unused]] __amdgpu_buffer_rsrc_t vrsrc = rsrc;
       [[maybe_unused]] float v_c0 = 0.f, v_w8 = 0.f;
       [[maybe_unused]] int v_base = 0;
@@ -905,13 +1103,13 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       }
     };
     // (every instantiation: the classification's proof covers rotated grids, 4b.1, and general K, 4b.7)
-    const bool interior = kcount == TK && cbyte >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
+    const bool interior = kcount == TK && (cbyte & 0x1fu) >= ((unsigned)MIXED_NAN_DEPTH << 2) && !(kv->flags & TILE_FLAG_NO_INTERIOR);
     if (interior) {
       if constexpr (!COUNT) {
-        if (cbyte == ((unsigned)MIXED_FREE_OR_NODEPTH << 2 | BRICK_MIXED))
+        if ((cbyte & 0x1fu) == ((unsigned)MIXED_FREE_OR_NODEPTH << 2 | BRICK_MIXED))
           column(std::true_type{}, std::false_type{}, std::true_type{});
 #ifndef DMI_EXP_NO_SURFACE_COLUMN  // (code-size experiment, tools/exp_list_codesize.txt)
-        else if (cbyte == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
+        else if ((cbyte & 0x1fu) == ((unsigned)MIXED_NEAR_SURFACE << 2 | BRICK_MIXED) && !keep_zero_adds)
           column(std::true_type{}, std::true_type{}, std::false_type{});
 #endif
         else
@@ -935,6 +1133,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       const bool exact = mine;
       if (ballot(exact)) {
         double ev = 0.0;
+        const kernarg_t ke = KFRESH();
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(cload(&ke->tile_maps[m].depth)), (short)0, ke->depth_bytes, 0x00020000);
         const bool eh = exact ? tile_exact<DepthT>(KC(full), m, rsrc, i, j, k0 + kk, ev) : false;
         if (exact) {
           hit = eh;
@@ -1067,7 +1268,7 @@ unsigned resident_workgroups(Kernel kernel, int threads) {
   return (unsigned)(per_cu * prop.multiProcessorCount + 7) / 8u * 8u;  // the same number for every XCD
 }
 
-template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false>
+template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false, bool WIN = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   static_assert(TK <= kMaxColumnHeight, "dmi_multi_z_slab aligns slabs to kMaxColumnHeight");
   // one workgroup per brick: super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
@@ -1076,7 +1277,7 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + 32 + per_round - 1) / per_round * per_round);
   const dim3 block(64 * WX * WY);
   const auto counted = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>;
-  const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>;
+  const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, (WX * WY == 1), WIN>;
   if constexpr (WX * WY == 1) {
     // few views per brick (and classes to make most of them cheap): one workgroup per brick, see the kernel
     const bool stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
@@ -1092,7 +1293,7 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       if (cfg.count_hits)
         hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
       else
-        hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
+        hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false, WIN>), dim3(blocks), block, 0, s, a);
       return hipGetLastError();
     }
     // persistent one-wave workgroups: as many as the chip holds (asked once per instantiation)
@@ -1116,6 +1317,16 @@ int effective_shape(int variant, bool depth_is_f64, bool rotated, bool general_k
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0, cfg.general_k != 0);
+  // a launch with window origins (dmi_capi.hip: maps with scattered holes, no hit counters, pinhole views): the WIN instantiations
+  const bool win = a.win_origin != nullptr && !cfg.count_hits && !cfg.general_k;
+#ifdef DMI_FAST_BUILD  // development builds (seconds instead of minutes): the two default shapes, axis-aligned grid, pinhole views
+  if (win) {
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, false, false, true>(a, cfg, s);
+    return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, false, true>(a, cfg, s);
+  }
+  if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
+  return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
+#else
   if (cfg.general_k) {  // a general K among the views: the two default shapes, either kind of grid
     if (a.rotated) {
       if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true, true>(a, cfg, s);
@@ -1125,6 +1336,10 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, true>(a, cfg, s);
   }
   if (a.rotated) {  // rotated grid: the two default shapes
+    if (win) {
+      if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true, false, true>(a, cfg, s);
+      return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true, false, true>(a, cfg, s);
+    }
     if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true>(a, cfg, s);
   }
@@ -1139,11 +1354,16 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       default: break;
     }
   }
+  if (win && (shape == 7 || shape == 0)) {
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, false, false, true>(a, cfg, s);
+    return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, false, true>(a, cfg, s);
+  }
   // 80 + 16 = 96 VGPRs: 5 waves; the whole column is one load group (8 gathers in flight before the first is consumed);
   // one wave per workgroup: an 8 x 8 x 8 brick is the unit of scheduling and of the heaviest-first order
   if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
   // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight); one wave per workgroup
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
+#endif
 }
 
 }  // namespace
@@ -1187,6 +1407,8 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
     const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0 || cfg.general_k != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, cfg.general_k, stream);
     if (e != hipSuccess) return e;
+    e = launch_window_origins(a, maps_dev, sh.tk, const_cast<uint8_t *>(a.classes), cfg.general_k, stream);
+    if (e != hipSuccess) return e;
 #ifdef DMI_TUNING
     if (const char *env = getenv("DMI_DEBUG_CLASS_REMAP")) {  // e.g. 0x03020300: byte c = what class c becomes
       const int64_t n = (int64_t)a.wbricks_x * a.wbricks_y * a.bricks_z * (int64_t)a.class_pitch;
@@ -1203,11 +1425,13 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
     e = hipEventRecord(before_main_kernel, stream);
     if (e != hipSuccess) return e;
   }
+#ifndef DMI_FAST_BUILD
   if (cfg.depth_is_f64) {
     if (cfg.grid_is_f64) return launch_types<double, double>(a, cfg, stream);
     return launch_types<double, float>(a, cfg, stream);
   }
   if (cfg.grid_is_f64) return launch_types<float, double>(a, cfg, stream);
+#endif
   return launch_types<float, float>(a, cfg, stream);
 }
 

@@ -221,8 +221,13 @@ int dmi_get_brick_class_histogram(dmi_context *ctx, uint64_t out[4]);
 /* Diagnostic: why the mixed pairs of the last dmi_fuse could not be proven uniform.  out[1] non-finite corner value,
  * out[2] the camera plane cuts the brick (c.z <= 0 or too small for the footprint bound), out[3] the footprint is
  * partly outside the depth map, out[4] NaN depths in the footprint, out[5] "no depth" pixels next to depths, out[6]
- * depths within delta of the brick (a surface is near); out[0], out[7] unused.  Synchronises. */
+ * depths within delta of the brick (a surface is near), out[7] every depth of the footprint far behind the brick, with "no depth"
+ * pixels among them (free space seen through holes: the FREE column); out[0] unused.  Synchronises. */
 int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]);
+
+/* Diagnostic: how many of the "free space or no depth" pairs (out[7] above) of the last dmi_fuse the fusion kernel served from a
+ * window of validity bits (one coalesced fetch per pair) instead of one gather per voxel.  Synchronises. */
+int dmi_get_window_pair_count(dmi_context *ctx, uint64_t *out);
 
 int dmi_get_timings(dmi_context *ctx, dmi_timings *out);
 int dmi_get_info(dmi_context *ctx, dmi_info *out);

@@ -82,7 +82,7 @@ def main():
             same[k] = bool(np.array_equal(g, ref_grid))
         for k in ctxs:
             rec = {"scene": sc, "lib": k[0], "variant": k[1], "brick_classes": ctxs[k].brick_class_histogram(),
-                   "mixed_reasons": ctxs[k].mixed_reason_histogram(), "fuse_ms": float(np.median(fuse[k])), "main_ms": float(np.median(main_ms[k])),
+                   "mixed_reasons": ctxs[k].mixed_reason_histogram(), "window_pairs": ctxs[k].window_pair_count(), "fuse_ms": float(np.median(fuse[k])), "main_ms": float(np.median(main_ms[k])),
                    "main_min_ms": float(np.min(main_ms[k])), "grid_bits_equal_first": same[k]}
             if ref is None:
                 ref = rec["main_ms"]

@@ -11,6 +11,8 @@ for spec in "$@"; do
   O=gpurun_out/${TAG}_${name}
   P="python3 bench.py --scene $SCENE --steps 2 --warmup 1 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end --no-scenes ${BENCH_ARGS:-}"
   timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq1 -- $P > $O.sq1.log 2>&1; echo "$name pmc1 rc=$?"
+  timeout 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM TA_TA_BUSY_sum --output-format csv -d $O/sq3 -- $P > $O.sq3.log 2>&1; echo "$name pmc3 rc=$?"
+  timeout 400 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQC_TC_INST_REQ SQC_DCACHE_MISSES SQC_DCACHE_REQ --output-format csv -d $O/sq4 -- $P > $O.sq4.log 2>&1; echo "$name pmc4 rc=$?"
   timeout 400 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d $O/sq2 -- $P > $O.sq2.log 2>&1; echo "$name pmc2 rc=$?"
 done
 python3 - "$TAG" "$@" <<'PY'
