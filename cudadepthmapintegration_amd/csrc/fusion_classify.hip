@@ -637,35 +637,65 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
 // class may have come down from its box unrefined), as proven by box_footprint (4b.2, 4b.9): every voxel's reference pixel lies
 // in [rx0, rx1] x [ry0, ry1], inside the image or its margin.  Where that rectangle fits a window of kWindowCols x kWindowRows
 // pixels and the view runs tier 1, the pair's origin is written and its class byte marked; every other pair keeps the gathering
-// column.  One thread per (brick, view): threadIdx.x over 64 consecutive views (coalesced class bytes and origins).
+// column.  A wave is 64 consecutive bricks and walks over kOriginViews views, four class bytes per load; the view is
+// wave-uniform, so its camera record arrives through scalar loads (as in the fine pass), and the lanes that have the class are
+// neighbours in space: all of them or none, mostly.
+constexpr int kOriginViews = 32;  // views per workgroup (a multiple of 4)
 template <bool ROT>
 __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, const MapRec *__restrict__ maps, int tk,
                                                             uint8_t *__restrict__ classes, uint32_t *__restrict__ origins) {
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
-  const int64_t local = (int64_t)blockIdx.x * 4 + threadIdx.y;
-  const int mm = blockIdx.y * 64 + threadIdx.x;
-  if (local >= n_bricks || mm >= a.n_maps) return;
-  const int m = a.first_map + mm;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t local = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  const bool exists = local < n_bricks;
   const int bx = (int)(local % a.wbricks_x);
   const int64_t t = local / a.wbricks_x;
   const int by = (int)(t % a.wbricks_y), bz = (int)(t / a.wbricks_y) + bz_first;
-  const int64_t at = (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch + m;
-  const uint8_t c = classes[at];
-  if ((c & 0x1f) != (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2))) return;
-  const TileMapRec *__restrict__ tr = a.tile_maps + m;
-  uint8_t out = c & 0x1f;
+  const int64_t row = (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch;
   // (a brick that sticks out of the top of the grid takes the column with every test, fusion_tile.hip: no window for it)
-  if (tr->t1_ok && bz * tk + tk <= a.nz) {
-    const BoxFootprint fp = box_footprint_k<ROT, false>(a, maps + m, tr, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
-    const bool inside = fp.query || (fp.partial && fp.in_margin);
-    if (inside && fp.rx1 - fp.rx0 < kWindowCols && fp.ry1 - fp.ry0 < kWindowRows) {
-      origins[at] = (uint32_t)(fp.rx0 + kValidMargin) | ((uint32_t)(fp.ry0 + kValidMargin) << 16);
-      out |= CLASS_HAS_WINDOW;
+  const bool eligible = exists && bz * tk + tk <= a.nz;
+  // views [m_lo, m_hi) of this workgroup, in groups of four that start at multiples of 4 (the rows are 64-byte aligned)
+  const int m_begin = a.first_map, m_end = a.first_map + a.n_maps;
+  const int g_lo = (m_begin & ~3) + blockIdx.y * kOriginViews;
+  for (int m4 = g_lo; m4 < g_lo + kOriginViews && m4 < m_end; m4 += 4) {  // wave-uniform
+    uint32_t c4 = eligible ? *reinterpret_cast<const uint32_t *>(classes + row + m4) : 0u;
+    const uint32_t before = c4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m4 + q;
+      const uint8_t c = (uint8_t)(c4 >> (8 * q));
+      const bool want = eligible && m >= m_begin && m < m_end && (c & 0x1f) == (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2));
+      if (__builtin_amdgcn_ballot_w64(want) == 0) continue;  // wave-uniform
+      const MapRec *src = maps + m;
+      const TileMapRec *tsrc = a.tile_maps + m;
+      if (!cload(&tsrc->t1_ok)) {  // the view does not run tier 1 (wave-uniform): no window, the class bits stay as they are
+        if (want) c4 &= ~((uint32_t)CLASS_HAS_WINDOW << (8 * q));
+        continue;
+      }
+      MapRec mr_u;
+      TileMapRec tr_u;
+#pragma unroll
+      for (int r = 8; r < 12; ++r) mr_u.rt[r] = cload(&src->rt[r]);
+      tr_u.px = cload(&tsrc->px); tr_u.py = cload(&tsrc->py); tr_u.pz = cload(&tsrc->pz); tr_u.p0 = cload(&tsrc->p0);
+      tr_u.qx = cload(&tsrc->qx); tr_u.qy = cload(&tsrc->qy); tr_u.qz = cload(&tsrc->qz); tr_u.q0 = cload(&tsrc->q0);
+      tr_u.err = cload(&tsrc->err);
+      tr_u.cz_err = cload(&tsrc->cz_err);
+      tr_u.errz = 0.0;
+      uint32_t flag = 0;
+      if (want) {
+        const BoxFootprint fp = box_footprint_k<ROT, false>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
+        const bool inside = fp.query || (fp.partial && fp.in_margin);
+        if (inside && fp.rx1 - fp.rx0 < kWindowCols && fp.ry1 - fp.ry0 < kWindowRows) {
+          origins[row + m] = (uint32_t)(fp.rx0 + kValidMargin) | ((uint32_t)(fp.ry0 + kValidMargin) << 16);
+          flag = CLASS_HAS_WINDOW;
+        }
+        c4 = (c4 & ~((uint32_t)CLASS_HAS_WINDOW << (8 * q))) | (flag << (8 * q));
+      }
     }
+    if (c4 != before) *reinterpret_cast<uint32_t *>(classes + row + m4) = c4;
   }
-  if (out != c) classes[at] = out;
 }
 
 // ---- heavy bricks first -------------------------------------------------------------------------------
@@ -887,11 +917,12 @@ hipError_t launch_window_origins(const TileArgs &a, const MapRec *maps_dev, int 
   const int bz_count = std::min(2 * a.super_z, a.bricks_z - 2 * a.sbz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
   if (n_bricks <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((n_bricks + 3) / 4), (unsigned)((a.n_maps + 63) / 64));
+  const int groups = (a.first_map + a.n_maps - (a.first_map & ~3) + kOriginViews - 1) / kOriginViews;
+  const dim3 grid((unsigned)((n_bricks + 255) / 256), (unsigned)groups);
   if (a.rotated)
-    hipLaunchKernelGGL((window_origin_kernel<true>), grid, dim3(64, 4), 0, stream, a, maps_dev, tk, classes, a.win_origin);
+    hipLaunchKernelGGL((window_origin_kernel<true>), grid, dim3(256), 0, stream, a, maps_dev, tk, classes, a.win_origin);
   else
-    hipLaunchKernelGGL((window_origin_kernel<false>), grid, dim3(64, 4), 0, stream, a, maps_dev, tk, classes, a.win_origin);
+    hipLaunchKernelGGL((window_origin_kernel<false>), grid, dim3(256), 0, stream, a, maps_dev, tk, classes, a.win_origin);
   return hipGetLastError();
 }
 
@@ -953,6 +984,8 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
     DMI_LAUNCH_FINE(3);
   else
 #endif
+  // (7 x 7 tiles for the 16-voxel bricks, whose footprints reach 45 pixels: 8 K of 3.2 M near-surface pairs of the speckle scene
+  // proven free, nothing measurable: profiles/r10o)
     DMI_LAUNCH_FINE(5);
 #undef DMI_LAUNCH_FINE_G
 #undef DMI_LAUNCH_FINE_R

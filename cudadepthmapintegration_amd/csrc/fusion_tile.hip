@@ -536,8 +536,15 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // nothing of it stays live across them.
     if constexpr (WIN) {
       if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
+#ifdef DMI_EXP_SKIP_WINDOW_VIEWS  // timing experiment (wrong results): what everything but the window views costs
+        continue;
+#endif
         const kernarg_t kw = KFRESH();
+#ifdef DMI_EXP_SAME_REC  // timing experiment (wrong results): every view reads the first view's record
+        const TileMapRec *rec = kw->tile_maps + first_map;
+#else
         const TileMapRec *rec = kw->tile_maps + m;
+#endif
         const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)org_vec, m & 63);
         const int x0p = (int)(org & 0xffffu), y0p = (int)(org >> 16);
         const __amdgpu_buffer_rsrc_t brsrc =
@@ -545,16 +552,26 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // byte offset of row Y's dword in tile column tx: ((Y >> 5) * tiles_x + tx) * 128 + (Y & 31) * 4
         const unsigned lin = ((unsigned)lane << 2) + ((unsigned)y0p << 2);
         const unsigned off = __umul24(lin >> 7, (unsigned)cload(&rec->vb_rowskip)) + lin + (((unsigned)x0p >> 5) << 7);
+#ifdef DMI_EXP_NO_WINDOW_LOADS  // timing experiment (wrong results): no loads, the window's bits come from the addresses
+        const uint32_t w_lo = off * 0x9e3779b9u, w_hi = ~w_lo;
+#else
         const uint32_t w_lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)off, 0, 0);
         const uint32_t w_hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)(off + 128u), 0, 0);
+#endif
         // the floats 1.5 * 2^23 - (origin - centre), x in the low word, y in the high one
         const unsigned long long M2 =
             (unsigned long long)(unsigned)(cload(&rec->vb_mx) - x0p) | ((unsigned long long)(unsigned)(cload(&rec->vb_my) - y0p) << 32);
         // fp64 values at the column's first voxel: the centred h.x, h.y (TileMapRec::cpx ...) and the exact c.z (cu:92, cu:172),
         // as every tier-1 column starts from them; formed again by the redo below, so that they do not stay live
         auto first_voxel = [&](double &hxf, double &hyf, double &czf64) __attribute__((always_inline)) {
+          // (a view of the argument block of its own: with the caller's, the record loads of the whole set-up became one batch,
+          // 40 scalar registers at once, and the kernel 1.7 % slower for the spill traffic: profiles/r10l)
           const kernarg_t kf = KFRESH();
+#ifdef DMI_EXP_SAME_REC
+          const TileMapRec *rf = kf->tile_maps + first_map;
+#else
           const TileMapRec *rf = kf->tile_maps + m;
+#endif
           double wxf = wx, wyf = wy, wzf = wz0;
           if constexpr (ROT) {
             const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kf->cz_table + (int64_t)k0 * 4));
@@ -588,11 +605,28 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         asm volatile("" : "+v"(DH), "+v"(DC));  // wave-uniform, but VGPR operands of the packed FMAs: placed there once per view
         uint32_t undecided = 0, und_kk = 0;  // per lane / wave-uniform: bit kk = voxel kk is redone after the column
         uint32_t window = 0;                 // this lane's row of the window
-        constexpr int WG = 4;                // look-ups in flight
+        constexpr int WG = 4;                // voxels per group
+        // A group's look-ups are issued after its candidates and consumed after the NEXT group's candidates: neither the
+        // window's loads nor a look-up's trip through the LDS crossbar is waited for
+        uint32_t pw[WG], pc[WG];             // the previous group's words and columns
+        auto consume = [&](int g0) __attribute__((always_inline)) {
+          if ((und_kk >> g0) & ((1u << WG) - 1u)) {  // wave-uniform, rare: some lane of the group was not accepted
+            // the redo below adds that voxel's value: here its word counts as empty
+  #pragma unroll
+            for (int q = 0; q < WG; ++q) pw[q] &= ((undecided >> (g0 + q)) & 1u) - 1u;
+          }
+  #pragma unroll
+          for (int q = 0; q < WG; ++q) {
+            // -eta*rho (cu:115) where the pixel holds a depth: sum = fma(1.0 or +0.0, -eta*rho, sum), as the gathering column
+            uint32_t bit;
+            asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(pw[q]), "v"(pc[q]));
+            acc_fma_vs<BASE, TK>(g0 + q, (double)bit, free_space);
+          }
+        };
   #pragma unroll
         for (int g0 = 0; g0 < TK; g0 += WG) {
           uint32_t wg[WG], cg[WG];
-          // ---- the group's candidates and their verification (the window's loads are still in flight during the first group's)
+          // ---- the group's candidates and their verification
   #pragma unroll
           for (int q = 0; q < WG; ++q) {
             const int kk = g0 + q;
@@ -615,23 +649,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               und_kk |= 1u << kk;
             }
           }
-          // the two dwords become the 32 columns from x0 on
-          if (g0 == 0) window = __builtin_amdgcn_alignbit(w_hi, w_lo, (unsigned)x0p & 31u);
-  #pragma unroll
-          for (int q = 0; q < WG; ++q) wg[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wg[q], (int)window);
-          if ((und_kk >> g0) & ((1u << WG) - 1u)) {  // wave-uniform, rare: some lane of the group was not accepted
-            // the redo below adds that voxel's value: here its word counts as empty
-  #pragma unroll
-            for (int q = 0; q < WG; ++q) wg[q] &= ((undecided >> (g0 + q)) & 1u) - 1u;
-          }
+          if (g0 == 0)
+            window = __builtin_amdgcn_alignbit(w_hi, w_lo, (unsigned)x0p & 31u);  // the two dwords become the 32 columns from x0 on
+          else
+            consume(g0 - WG);
   #pragma unroll
           for (int q = 0; q < WG; ++q) {
-            // -eta*rho (cu:115) where the pixel holds a depth: sum = fma(1.0 or +0.0, -eta*rho, sum), as the gathering column
-            uint32_t bit;
-            asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(wg[q]), "v"(cg[q]));
-            acc_fma_vs<BASE, TK>(g0 + q, (double)bit, free_space);
+            pw[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wg[q], (int)window);
+            pc[q] = cg[q];
           }
         }
+        consume(TK - WG);
         // ---- the voxels in which some lane was not accepted (about 2 % of a wave's): tier 2 (DESIGN.md 4.1-4.5 in centred
         // coordinates), then the reference's own expression for what that leaves; at most one add per voxel and view, after the
         // column and before the next view: every voxel accumulates in view order (cu:211)

@@ -104,7 +104,8 @@ def test_random_medium_scenes_bit_exact(seed):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        n_threads=oracle.max_threads())
     for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_NO_BRICK_CLASSES, False), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False),
-                                (capi.VARIANT_PERSISTENT_ALWAYS, False), (capi.VARIANT_PERSISTENT_ALWAYS, True)):
+                                (capi.VARIANT_PERSISTENT_ALWAYS, False), (capi.VARIANT_PERSISTENT_ALWAYS, True),
+                                (capi.VARIANT_WINDOWS_ALWAYS, False), (capi.VARIANT_WINDOWS_ALWAYS | capi.VARIANT_FIXED_TILE_SHAPE, False)):
         out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
         assert bits_equal(out, want), (seed, variant, count_hits)
         if count_hits:
@@ -121,7 +122,8 @@ def test_random_many_view_scenes_bit_exact(seed):
         want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                        n_threads=oracle.max_threads())
     for variant, count_hits in ((0, False), (0, True), (capi.VARIANT_ZMAJOR_SLOTS | capi.VARIANT_SPATIAL_ORDER, False),
-                                (capi.VARIANT_PERSISTENT_NEVER, False)):
+                                (capi.VARIANT_PERSISTENT_NEVER, False), (capi.VARIANT_WINDOWS_ALWAYS, False),
+                                (capi.VARIANT_WINDOWS_ALWAYS | capi.VARIANT_PERSISTENT_NEVER, False)):
         out, vh, mh = capi.fuse_once(grid, rp, views, count_hits=count_hits, kernel_variant=variant)
         assert bits_equal(out, want), (seed, variant, count_hits)
         if count_hits:

@@ -44,7 +44,10 @@ def test_golden_bit_exact_f64(golden, variant):
     assert bits_equal(out, golden["expected_grid"])
 
 
-@pytest.mark.parametrize("variant", [0, FX, FX | capi.VARIANT_KEEP_BEHIND_ADDS, 96, NC])
+W = capi.VARIANT_WINDOWS_ALWAYS   # the FREE column's bit windows whatever the depth maps look like (default: maps with scattered holes)
+
+
+@pytest.mark.parametrize("variant", [0, FX, FX | capi.VARIANT_KEEP_BEHIND_ADDS, 96, NC, W, FX | W, capi.VARIANT_NO_WINDOWS])
 def test_golden_bit_exact_without_hit_counters(golden, variant):
     """Without hit counters and from a zero grid the kernel skips the +0.0 adds of bricks proven to lie behind every
     surface (a sum that starts at +0.0 is never -0.0, so x + 0.0 == x): same bits, including the sign of zeros.  With
@@ -698,6 +701,80 @@ def test_diagnostics_and_layer_tracking():
     with pytest.raises(ValueError):
         with capi.FusionContext(grid, rp) as ctx:
             ctx.download_grid(np.float64, out=np.zeros(5))
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+@pytest.mark.parametrize("focal_scale,wh,fits", [(0.9, (320, 240), True), (1.8, (320, 240), None), (2.6, (640, 480), None)])
+def test_free_column_through_bit_windows(rotated, focal_scale, wh, fits):
+    """Depth maps with holes scattered all over them (what a best-cost threshold leaves): the pairs in free space take the FREE
+    column, and where the brick's footprint fits 32 x 64 pixels that column asks a window of validity bits fetched once per
+    (brick, view) instead of gathering per voxel.  Short and long focal lengths (footprints of a few pixels, of
+    tens, and -- at 9 x the image width -- wider than any window: those pairs keep the gathering column), either kind of grid,
+    8- and 16-voxel columns, an uploaded grid, windows forced on maps without scattered holes and switched off: the oracle's
+    grid bit for bit every time."""
+    grid = scene.default_grid((96, 80, 64), rotated=rotated)
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(10, wh[0], wh[1], seed=57, dense=True, focal_scale=focal_scale)
+    views.K4[:, 0, 2] -= 1.75   # principal point off the centre
+    holes = views.depth.copy()
+    holes[np.random.default_rng(11).random(holes.shape) < 0.1] = -1.0
+    speckled = scene.Views(holes, views.K4, views.RT4)
+    want = oracle.fuse(oracle_params_from_scene(grid, rp, speckled), speckled.depth, speckled.K4, speckled.RT4,
+                       n_threads=oracle.max_threads())[0]
+    counts = {}
+    for variant in (0, FX, capi.VARIANT_NO_WINDOWS, FX | capi.VARIANT_SPATIAL_ORDER):
+        with capi.FusionContext(grid, rp, kernel_variant=variant) as ctx:
+            ctx.add_views(speckled)
+            ctx.fuse()
+            out = ctx.download_grid()
+            counts[variant] = (ctx.window_pair_count(), ctx.mixed_reason_histogram()["free_or_no_depth"])
+        assert bits_equal(out, want), (rotated, focal_scale, variant)
+    assert counts[capi.VARIANT_NO_WINDOWS][0] == 0 and (counts[capi.VARIANT_NO_WINDOWS][1] > 0 or fits is not True), counts
+    for variant in (0, FX):
+        n_win, n_free = counts[variant]
+        assert n_win <= n_free, counts
+        # (a brick of 16-voxel columns spans 38 pixels and more in these views: many of its pairs keep the gathering column)
+        if fits is True:
+            assert n_win > (0.5 if variant == 0 else 0.25) * n_free, (focal_scale, counts)
+
+    # onto an uploaded grid (the sums do not start at zero: no uniform prefix, +0 adds kept)
+    init = np.random.default_rng(4).normal(size=(64, 80, 96))
+    want_init = oracle.fuse(oracle_params_from_scene(grid, rp, speckled), speckled.depth, speckled.K4, speckled.RT4, init_grid=init,
+                            n_threads=oracle.max_threads())[0]
+    with capi.FusionContext(grid, rp) as ctx:
+        ctx.upload_grid(init)
+        ctx.add_views(speckled)
+        ctx.fuse()
+        assert bits_equal(ctx.download_grid(), want_init), (rotated, focal_scale)
+        assert ctx.window_pair_count() > 0 or fits is not True
+    # maps with ONE large hole each: not "scattered", so no windows by default; forced, the border and hole pairs get them
+    views.depth[:, 60:120, 80:200] = -1.0
+    want_one = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
+    for variant, expect in ((0, False), (W, True), (FX | W, True)):
+        with capi.FusionContext(grid, rp, kernel_variant=variant) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            assert bits_equal(ctx.download_grid(), want_one), (rotated, focal_scale, variant)
+            if not expect:
+                assert ctx.window_pair_count() == 0, (variant, ctx.window_pair_count())
+            elif fits is True:
+                assert ctx.window_pair_count() > 0, (variant, ctx.mixed_reason_histogram())
+
+
+def test_footprints_wider_than_a_window_keep_the_gathering_column():
+    """A coarse grid under large images: a brick of 8 voxels spans some 80 pixels, no footprint fits a window of 32 x 64: every
+    "free space or no depth" pair keeps the gathering column, and the grid is the oracle's bit for bit."""
+    grid = scene.default_grid((48, 40, 32))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(6, 640, 480, seed=19, dense=True)
+    views.depth[np.random.default_rng(13).random(views.depth.shape) < 0.1] = -1.0
+    want = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
+    for variant in (0, FX):
+        with capi.FusionContext(grid, rp, kernel_variant=variant) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            assert bits_equal(ctx.download_grid(), want), variant
+            assert ctx.window_pair_count() == 0 and ctx.mixed_reason_histogram()["free_or_no_depth"] > 0, variant
 
 
 @pytest.mark.parametrize("eta", [0.03, -0.2])

@@ -20,6 +20,6 @@ for body in re.split(r"\n(?=_ZN3dmi\S*fuse_tile_kernel\S*:)", text):
     sz = re.search(r"; codeLenInByte = (\d+)", body)
     d = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\b(.*?)\.end_amdhsa_kernel", text, re.S).group(1)
     scr = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", d).group(1)
-    print(name[40:90], "bytes", sz.group(1) if sz else "?", "readlane", c["v_readlane_b32"], "writelane", c["v_writelane_b32"],
+    print(name[name.index("kernelI")+7:name.index("EEvNS")], "bytes", sz.group(1) if sz else "?", "readlane", c["v_readlane_b32"], "writelane", c["v_writelane_b32"],
           "scratch", scr, "scratch_ops", sum(v for k, v in c.items() if k.startswith("scratch_")), "s_nop", c["s_nop"])
 PY
