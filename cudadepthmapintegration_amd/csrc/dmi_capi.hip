@@ -64,6 +64,12 @@ struct dmi_context {
   bool own_grid = false;
   std::vector<uint8_t> layer_is_zero;  // per cell layer: known to hold +0.0 everywhere (reset, not fused since)
   bool zero_fill_pending = false;  // reset requested, memset deferred: the next fuse overwrites every voxel
+  // No voxel of the (context-owned) grid is -0.0: true after a reset and preserved by every fusion -- a sum that is not -0.0 never
+  // becomes one (x + y is -0.0 only when both are; a non-zero f64 sum does not round to zero) -- so the +0.0 adds of voxels far
+  // behind every surface stay unobservable from one dmi_fuse_range to the next, not only in the first (round 4: the chunked
+  // fusion of the drop-in filter ran its later chunks at half speed).  False once the caller has uploaded a grid, and for a
+  // caller-owned grid (whoever owns it may write anything between two calls).
+  bool grid_free_of_negative_zero = false;
   uint32_t *d_voxel_hits = nullptr;
   unsigned long long *d_map_hits = nullptr;
   size_t map_hits_capacity = 0;
@@ -302,25 +308,18 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
       if (e == hipSuccess && best_cost)
         e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->upload_stream);
       void *dst = static_cast<char *>(b.d_depth) + m0 * npix * esz;
-      if (e == hipSuccess) {
-        if (depth32)
-          e = dmi::launch_flip_depth_f32(reinterpret_cast<const float *>(ctx->d_stage_depth), dst, ctx->depth_f64 ? 1 : 0,
-                                         (int64_t)cnt, ctx->W, ctx->H, ctx->upload_stream);
-        else
-          e = dmi::launch_convert_depth(ctx->d_stage_depth, best_cost ? ctx->d_stage_cost : nullptr, threshold, dst,
-                                        ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->d_lossy, ctx->upload_stream);
-      }
+      // one pass over the staged tables: threshold, row flip, narrowing, the finest pyramid level, validity bytes and bits
+      if (e == hipSuccess)
+        e = dmi::launch_upload_views(ctx->d_stage_depth, depth32 ? 0 : 1, (!depth32 && best_cost) ? ctx->d_stage_cost : nullptr, threshold,
+                                     dst, ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->pyramid,
+                                     b.d_pyramid + m0 * (size_t)ctx->pyramid.total_tiles,
+                                     reinterpret_cast<uint8_t *>(b.d_pyramid) + b.valid_offset + m0 * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H),
+                                     reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(b.d_pyramid) + b.bits_offset +
+                                                                  m0 * (size_t)dmi::valid_bits_bytes(ctx->W, ctx->H)),
+                                     ctx->d_lossy, ctx->upload_stream);
     }
-    // depth bounds per 8x8 ... image-sized tile of every table: what the brick classification reads
-    if (e == hipSuccess)
-      e = dmi::launch_build_pyramids(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H, ctx->pyramid, b.d_pyramid,
-                                     ctx->upload_stream);
-    if (e == hipSuccess)
-      e = dmi::launch_build_valid_maps(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H,
-                                       reinterpret_cast<uint8_t *>(b.d_pyramid) + b.valid_offset, ctx->d_lossy + 1, ctx->upload_stream);
-    if (e == hipSuccess)
-      e = dmi::launch_build_valid_bits(b.d_depth, ctx->depth_f64 ? 1 : 0, n, ctx->W, ctx->H,
-                                       reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(b.d_pyramid) + b.bits_offset), ctx->upload_stream);
+    // depth bounds per 16 x 16 ... image-sized tile of every table: what the brick classification reads
+    if (e == hipSuccess) e = dmi::launch_build_pyramid_levels(n, ctx->pyramid, b.d_pyramid, ctx->upload_stream);
     unsigned long long counters[3] = {0, 0, 0};
     if (e == hipSuccess)
       e = hipMemcpyAsync(counters, ctx->d_lossy, sizeof(counters), hipMemcpyDeviceToHost, ctx->upload_stream);
@@ -780,7 +779,16 @@ int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dm
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     ctx->own_stream = true;
   }
-  e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+  {
+    // The upload stream outranks the fusion's: its one short kernel per chunk then gets the compute-unit slots that the fusion of the
+    // previous chunk frees, instead of queueing behind that fusion's waiting workgroups while the copy engine idles (round 4)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      least = greatest = 0;
+    }
+    e = hipStreamCreateWithPriority(&ctx->upload_stream, hipStreamNonBlocking, greatest);
+  }
   if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(upload)");
   if (o.external_grid) {
     hipPointerAttribute_t attr;
@@ -915,6 +923,7 @@ int dmi_reset_grid(dmi_context *ctx) {
   if (ctx->d_map_hits)
     DMI_HIP(ctx, hipMemsetAsync(ctx->d_map_hits, 0, ctx->map_hits_capacity * sizeof(unsigned long long), ctx->stream));
   ctx->layer_is_zero.assign((size_t)ctx->grid.cell_dims[2], 1);
+  ctx->grid_free_of_negative_zero = ctx->own_grid;
   ctx->points_valid = false;
   return DMI_OK;
   });
@@ -933,6 +942,7 @@ int dmi_upload_grid(dmi_context *ctx, const double *grid) {
     if (rc_ != DMI_OK) return rc_;
   }
   ctx->layer_is_zero.assign((size_t)ctx->grid.cell_dims[2], 0);
+  ctx->grid_free_of_negative_zero = false;
   ctx->points_valid = false;
   return DMI_OK;
   });
@@ -1278,7 +1288,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       }
     }
     // +0.0 adds are no-ops unless a sum can be -0.0 (only an uploaded grid can bring one) or hits are counted
-    if (!a.init_from_grid && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS))
+    if ((!a.init_from_grid || ctx->grid_free_of_negative_zero) && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS))
       t.behind_mask = 0x0101010101010101ull;
 #ifdef DMI_TUNING
     if (std::getenv("DMI_DEBUG_WG_TIMES")) {  // per-workgroup start / end / XCC (tools/gpu_wg_timeline.py)

@@ -79,86 +79,124 @@ struct TileAcc {
   }
 };
 
-// level kPyramidMinLevel from the depth tables: one thread per 8 x 8 tile
-template <typename DepthT>
-__global__ __launch_bounds__(256) void pyramid_base_kernel(const DepthT *__restrict__ depth, int64_t n_maps, int W, int H,
-                                                           PyramidDesc P, DepthTile *__restrict__ pyr) {
-  const int64_t tiles = (int64_t)P.width[0] * P.height[0];
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= tiles * n_maps) return;
-  const int64_t m = idx / tiles;
-  const int t = (int)(idx - m * tiles);
-  const int ty = t / P.width[0], tx = t - ty * P.width[0];
-  const DepthT *src = depth + m * (int64_t)W * H;
-  constexpr int S = 1 << kPyramidMinLevel;
-  TileAcc acc;
-  for (int y = ty * S; y < ty * S + S && y < H; ++y)
-    for (int x = tx * S; x < tx * S + S && x < W; ++x) acc.add_value((double)src[(int64_t)y * W + x]);
-  pyr[m * P.total_tiles + P.offset[0] + t] = acc.base_tile();
-}
-
-// validity map (TileMapRec::valid): one thread per pixel column of a tile row of the padded image, eight rows -> eight
-// contiguous bytes; the margin holds zeros ("no depth")
-template <typename DepthT>
-__global__ __launch_bounds__(256) void valid_map_kernel(const DepthT *__restrict__ depth, int64_t n_maps, int W, int H,
-                                                        uint8_t *__restrict__ valid, unsigned long long *__restrict__ n_holes) {
-  const int Wp = W + 2 * kValidMargin;
-  const int tile_rows = (H + 2 * kValidMargin + 7) / 8;
-  const int64_t per_map = (int64_t)tile_rows * Wp;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= per_map * n_maps) return;
-  const int64_t m = idx / per_map;
-  const int64_t r = idx - m * per_map;
-  const int ty = (int)(r / Wp), x = (int)(r - (int64_t)ty * Wp) - kValidMargin;
-  const DepthT *src = depth + m * (int64_t)W * H;
-  unsigned long long bits = 0;
-  int holes = 0;  // pixels of the image (not of its margin) without a depth
-  if (x >= 0 && x < W) {
-    for (int q = 0; q < 8; ++q) {
-      const int y = ty * 8 + q - kValidMargin;
-      const bool inside = y >= 0 && y < H;
-      const bool has = inside && !(src[(int64_t)y * W + x] == (DepthT)-1);  // cu:202: anything but the sentinel (a NaN too)
-      bits |= (unsigned long long)(has ? kValidByte : 0) << (8 * q);
-      holes += inside && !has ? 1 : 0;
-    }
-  }
-  *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + r * 8) = bits;
-  // (how many there are tells the host which launch form the fusion takes, fusion_tile.hip: launch_shape.  One atomic per
-  // lane with holes in its eight pixels would be ~10 % of the lanes on thresholded maps: one per wave, over the lanes that are
-  // here -- the last wave of the launch may have lost some to the bound check above)
-  // n_holes[1]: the lanes' strips of eight pixels (all inside the image) that hold both a hole and a depth -- scattered holes,
-  // as a best-cost threshold leaves them, make most strips such; a silhouette against an empty background hardly any
-  if (n_holes) {
-    const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
-    int total = 0;
-    for (int q = 1; q <= 8; ++q) total += q * __builtin_popcountll(__builtin_amdgcn_ballot_w64(holes == q));
-    const bool whole = x >= 0 && x < W && ty * 8 - kValidMargin >= 0 && ty * 8 - kValidMargin + 7 < H;
-    const int mingled = __builtin_popcountll(__builtin_amdgcn_ballot_w64(whole && holes > 0 && holes < 8));
-    if ((int)__builtin_ctzll(here) == (int)(threadIdx.x & 63)) {
-      if (total) atomicAdd(n_holes, (unsigned long long)total);
-      if (mingled) atomicAdd(n_holes + 1, (unsigned long long)mingled);
-    }
-  }
-}
-
-// validity bits (TileMapRec::vbits): one wave per 64 consecutive pixels of a row of the padded image -> two dwords, one in each
-// of two neighbouring 32 x 32 tiles.  A block is four consecutive rows of the same 64 columns.
-template <typename DepthT>
-__global__ __launch_bounds__(256) void valid_bits_kernel(const DepthT *__restrict__ depth, int W, int H, uint32_t *__restrict__ bits) {
-  const int tiles_x = valid_bits_tiles_x(W), tiles_y = valid_bits_tiles_y(H);
-  const int lane = threadIdx.x & 63;
-  const int X = blockIdx.x * 64 + lane;                   // padded-image column; the grid covers tiles_x * 32 of them (rounded up to 64)
-  const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);      // padded-image row
+// ---- the upload pass (round 4): ONE kernel per chunk of views reads every value of the host's table once -- f64 or f32, vtk row
+// order (row 0 = the bottom row, cu:141-149), with the best-cost values beside it (RD.cxx:138-167: cost > thr => -1) -- and
+// writes everything the fusion reads: the depth table (top row first, f32 or f64, with the count of lossy narrowings), the
+// finest level of the min/max pyramid, the validity bytes and the validity bits, and counts the holes.  (Round 3 made four
+// passes over the table: convert, pyramid base, validity map -- which alone took 0.73 ms per 32 views for its two same-address
+// atomics per wave -- and, this round, the bits.)
+// A workgroup is 8 waves = 8 consecutive rows of the PADDED image (the maps' margin of kValidMargin pixels on every side) x 512
+// columns: wave w takes row 8 by + w, lane l of pass k column 512 bx + 64 k + l -- every load and store of the table is a run
+// of 64 consecutive values.  A pass's ballot is two dwords of the bit tiles.  The 8 x 8-pixel pyramid tiles and the byte map's
+// strips (8 rows at one column) span the 8 waves: they are put together through LDS by 64 (one per tile) and 512 (one per
+// column) threads.  One atomic per workgroup and counter.
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(512) void upload_views_kernel(const InT *__restrict__ in, const double *__restrict__ best_cost, double thr,
+                                                           OutT *__restrict__ out, int W, int H, PyramidDesc P,
+                                                           DepthTile *__restrict__ pyr, uint8_t *__restrict__ valid,
+                                                           uint32_t *__restrict__ bits, unsigned long long *__restrict__ counters) {
+  __shared__ unsigned long long masks[8][8];   // [row][pass]: the lanes whose pixel holds a depth
+  __shared__ float part_min[8][64], part_max[8][64];
+  __shared__ uint32_t part_flags[8][64];
+  __shared__ unsigned int block_counts[2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t m = blockIdx.z;
-  if (Y >= tiles_y * 32) return;                          // wave-uniform
-  const int x = X - kValidMargin, y = Y - kValidMargin;
-  bool has = false;
-  if (x >= 0 && x < W && y >= 0 && y < H) has = !(depth[(m * H + y) * (int64_t)W + x] == (DepthT)-1);  // cu:202: anything but the sentinel
-  const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
-  uint32_t *out = bits + m * (valid_bits_bytes(W, H) / 4);
-  const int tx = X >> 5;  // lane 0: the left tile, lane 32: the right one
-  if ((lane & 31) == 0 && tx < tiles_x)
-    out[((int64_t)(Y >> 5) * tiles_x + tx) * 32 + (Y & 31)] = (uint32_t)(mask >> (lane & 32));
+  const int Wp = W + 2 * kValidMargin;
+  const int tiles_x = valid_bits_tiles_x(W), tiles_y = valid_bits_tiles_y(H);
+  const int tile_rows = (H + 2 * kValidMargin + 7) / 8;   // of the byte map
+  const int Y = blockIdx.y * 8 + w, y = Y - kValidMargin;  // padded / image row of this wave
+  const bool row_inside = y >= 0 && y < H;
+  const int64_t npix = (int64_t)W * H;
+  const InT *src = in + m * npix + (int64_t)(H - 1 - y) * W;   // the host's row: vtk order (only read when row_inside)
+  const double *cost = best_cost ? best_cost + m * npix + (int64_t)(H - 1 - y) * W : nullptr;
+  OutT *dst = out + m * npix + (int64_t)y * W;
+  if (threadIdx.x < 2) block_counts[threadIdx.x] = 0;
+  unsigned int lossy = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int X = blockIdx.x * 512 + 64 * k + lane, x = X - kValidMargin;
+    const bool inside = row_inside && x >= 0 && x < W;
+    bool has = false;
+    TileAcc acc;
+    if (inside) {
+      double d = (double)src[x];
+      if (cost != nullptr && cost[x] > thr) d = -1.0;  // RD.cxx:159-166
+      const OutT o = (OutT)d;
+      if (sizeof(OutT) == 4 && sizeof(InT) == 8) {  // bit compare, so that a NaN round-trips instead of counting as lossy
+        const double back = (double)o;
+        lossy += (__double_as_longlong(back) != __double_as_longlong(d)) && !(d != d);
+      }
+      dst[x] = o;
+      has = !(o == (OutT)-1);  // cu:202: anything but the sentinel (a NaN too)
+      acc.add_value((double)o);
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+    if (lane == 0) masks[w][k] = mask;
+    // validity bits: two dwords of row Y, in neighbouring 32 x 32 tiles
+    const int tx = X >> 5;
+    if ((lane & 31) == 0 && tx < tiles_x && Y < tiles_y * 32)
+      bits[m * (valid_bits_bytes(W, H) / 4) + ((int64_t)(Y >> 5) * tiles_x + tx) * 32 + (Y & 31)] = (uint32_t)(mask >> (lane & 32));
+    // this row's part of the 8 x 8 tiles: over the 8 lanes of a tile column
+    float dmin = acc.dmin, dmax = acc.dmax;
+    uint32_t flags = acc.flags;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      dmin = fminf(dmin, __shfl_xor(dmin, off, 64));
+      dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+      flags |= (uint32_t)__shfl_xor((int)flags, off, 64);
+    }
+    if ((lane & 7) == 0) {
+      part_min[w][k * 8 + (lane >> 3)] = dmin;
+      part_max[w][k * 8 + (lane >> 3)] = dmax;
+      part_flags[w][k * 8 + (lane >> 3)] = flags;
+    }
+  }
+  if (sizeof(OutT) == 4 && sizeof(InT) == 8) {
+    for (int off = 32; off > 0; off >>= 1) lossy += __shfl_xor((int)lossy, off, 64);
+    if (lane == 0 && lossy != 0) atomicAdd(counters, (unsigned long long)lossy);
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 64) {  // the finest pyramid level: tile column t of this stripe, rows 8 by .. 8 by + 7
+    const int ptx = blockIdx.x * 64 + t - kValidMargin / 8, pty = (int)blockIdx.y - kValidMargin / 8;
+    if (ptx >= 0 && ptx < P.width[0] && pty >= 0 && pty < P.height[0]) {
+      TileAcc a;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        a.dmin = fminf(a.dmin, part_min[r][t]);
+        a.dmax = fmaxf(a.dmax, part_max[r][t]);
+        a.flags |= part_flags[r][t];
+      }
+      pyr[m * P.total_tiles + P.offset[0] + pty * P.width[0] + ptx] = a.base_tile();
+    }
+  }
+  {  // the byte map: column X of tile row by, eight rows -> eight contiguous bytes; and the hole counts
+    const int X = blockIdx.x * 512 + t, x = X - kValidMargin;
+    unsigned long long bytes = 0;
+    int have = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const bool has = (masks[r][t >> 6] >> (t & 63)) & 1ull;
+      bytes |= (unsigned long long)(has ? kValidByte : 0) << (8 * r);
+      have += has ? 1 : 0;
+    }
+    if (X < Wp && (int)blockIdx.y < tile_rows) *reinterpret_cast<unsigned long long *>(valid + m * valid_map_bytes(W, H) + ((int64_t)blockIdx.y * Wp + X) * 8) = bytes;
+    // pixels of the image (not of its margin) without a depth; strips (all eight rows inside the image) with both a hole and a depth
+    const int y0 = (int)blockIdx.y * 8 - kValidMargin;
+    const int rows_inside = max(0, min(H, y0 + 8) - max(0, y0));
+    const bool col_inside = x >= 0 && x < W;
+    const int holes = col_inside ? rows_inside - have : 0;
+    const bool mingled = col_inside && rows_inside == 8 && holes > 0 && holes < 8;
+    int hsum = holes;
+    for (int off = 32; off > 0; off >>= 1) hsum += __shfl_xor(hsum, off, 64);
+    const int msum = __builtin_popcountll(__builtin_amdgcn_ballot_w64(mingled));
+    if (lane == 0) {
+      if (hsum) atomicAdd(&block_counts[0], (unsigned int)hsum);
+      if (msum) atomicAdd(&block_counts[1], (unsigned int)msum);
+    }
+  }
+  __syncthreads();
+  if (t < 2 && block_counts[t] != 0) atomicAdd(counters + 1 + t, (unsigned long long)block_counts[t]);
 }
 
 // level l from level l-1: one thread per tile, 2 x 2 children
@@ -869,46 +907,40 @@ PyramidDesc make_pyramid_desc(int W, int H) {
   return P;
 }
 
-hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &P,
-                                 DepthTile *pyramids, hipStream_t stream) {
+hipError_t launch_upload_views(const void *in, int in_is_f64, const double *best_cost, double threshold, void *out, int out_is_f64,
+                               int64_t n_maps, int W, int H, const PyramidDesc &P, DepthTile *pyramids, uint8_t *valid, uint32_t *bits,
+                               unsigned long long *counters, hipStream_t stream) {
   if (n_maps <= 0) return hipSuccess;
-  const int64_t base = (int64_t)P.width[0] * P.height[0] * n_maps;
-  if (depth_is_f64)
-    hipLaunchKernelGGL((pyramid_base_kernel<double>), dim3(blocks_of(base)), dim3(256), 0, stream,
-                       static_cast<const double *>(depth), n_maps, W, H, P, pyramids);
-  else
-    hipLaunchKernelGGL((pyramid_base_kernel<float>), dim3(blocks_of(base)), dim3(256), 0, stream,
-                       static_cast<const float *>(depth), n_maps, W, H, P, pyramids);
-  hipError_t e = hipGetLastError();
+  if (n_maps > 65535) return hipErrorInvalidConfiguration;
+  const int cover_x = std::max(W + 2 * kValidMargin, valid_bits_tiles_x(W) * 32);
+  const int cover_y = std::max(((H + 2 * kValidMargin + 7) / 8) * 8, valid_bits_tiles_y(H) * 32);
+  const dim3 grid((unsigned)((cover_x + 511) / 512), (unsigned)((cover_y + 7) / 8), (unsigned)n_maps);
+#define DMI_UPLOAD(IN, OUT)                                                                                                      \
+  hipLaunchKernelGGL((upload_views_kernel<IN, OUT>), grid, dim3(512), 0, stream, static_cast<const IN *>(in), best_cost, threshold, \
+                     static_cast<OUT *>(out), W, H, P, pyramids, valid, bits, counters)
+  if (in_is_f64) {
+    if (out_is_f64)
+      DMI_UPLOAD(double, double);
+    else
+      DMI_UPLOAD(double, float);
+  } else {
+    if (out_is_f64)
+      DMI_UPLOAD(float, double);
+    else
+      DMI_UPLOAD(float, float);
+  }
+#undef DMI_UPLOAD
+  return hipGetLastError();
+}
+
+hipError_t launch_build_pyramid_levels(int64_t n_maps, const PyramidDesc &P, DepthTile *pyramids, hipStream_t stream) {
+  hipError_t e = hipSuccess;
   for (int li = 1; e == hipSuccess && li < P.n_levels; ++li) {
     const int64_t n = (int64_t)P.width[li] * P.height[li] * n_maps;
     hipLaunchKernelGGL(pyramid_up_kernel, dim3(blocks_of(n)), dim3(256), 0, stream, n_maps, li, P, pyramids);
     e = hipGetLastError();
   }
   return e;
-}
-
-hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid,
-                                   unsigned long long *n_holes, hipStream_t stream) {
-  if (n_maps <= 0) return hipSuccess;
-  const int64_t n = valid_map_bytes(W, H) / 8 * n_maps;
-  if (depth_is_f64)
-    hipLaunchKernelGGL((valid_map_kernel<double>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const double *>(depth), n_maps, W, H, valid, n_holes);
-  else
-    hipLaunchKernelGGL((valid_map_kernel<float>), dim3(blocks_of(n)), dim3(256), 0, stream, static_cast<const float *>(depth), n_maps, W, H, valid, n_holes);
-  return hipGetLastError();
-}
-
-hipError_t launch_build_valid_bits(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint32_t *bits,
-                                   hipStream_t stream) {
-  if (n_maps <= 0) return hipSuccess;
-  if (n_maps > 65535) return hipErrorInvalidConfiguration;
-  const dim3 grid((unsigned)((valid_bits_tiles_x(W) * 32 + 63) / 64), (unsigned)(valid_bits_tiles_y(H) * 8), (unsigned)n_maps);
-  if (depth_is_f64)
-    hipLaunchKernelGGL((valid_bits_kernel<double>), grid, dim3(256), 0, stream, static_cast<const double *>(depth), W, H, bits);
-  else
-    hipLaunchKernelGGL((valid_bits_kernel<float>), grid, dim3(256), 0, stream, static_cast<const float *>(depth), W, H, bits);
-  return hipGetLastError();
 }
 
 hipError_t launch_window_origins(const TileArgs &a, const MapRec *maps_dev, int tk, uint8_t *classes, int general_k,

@@ -309,14 +309,6 @@ hipError_t launch_fuse_tiled(const TileArgs &args, const MapRec *maps_dev, const
                              hipStream_t stream);
 
 // depth upload helpers ------------------------------------------------------------------
-// out[row-flipped i] = (best_cost && best_cost[i] > thr) ? -1 : in[i], stored as f32 or f64, n_maps
-// tables of W x H; *lossy += number of values whose f32 rounding is not exact (only when storing f32).
-hipError_t launch_convert_depth(const double *in, const double *best_cost, double threshold, void *out,
-                                int out_is_f64, int64_t n_maps, int W, int H, unsigned long long *lossy,
-                                hipStream_t stream);
-// f32 host tables: row flip, optionally widened to f64.
-hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int64_t n_maps, int W, int H,
-                                 hipStream_t stream);
 hipError_t launch_widen_depth(const float *in, double *out, int64_t n, hipStream_t stream);
 // n grid elements f64 -> f32 (in_is_f64) or f32 -> f64, device to device
 hipError_t launch_convert_grid(const void *in, int in_is_f64, void *out, int64_t n, hipStream_t stream);
@@ -324,18 +316,15 @@ hipError_t launch_convert_grid(const void *in, int in_is_f64, void *out, int64_t
 // dmi_fp64_probe: `iters` rounds of eight independent fp64 FMAs per lane; out[thread] keeps the chains alive
 hipError_t launch_fp64_probe(double *out, int blocks, int iters, hipStream_t stream);
 
-// min/max pyramids of n_maps depth tables (device, top-down rows) into pyramids[n_maps][desc.total_tiles]
 PyramidDesc make_pyramid_desc(int W, int H);
-hipError_t launch_build_pyramids(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, const PyramidDesc &desc,
-                                 DepthTile *pyramids, hipStream_t stream);
-// validity maps (TileMapRec::valid) of n_maps depth tables: valid[n_maps][valid_map_bytes(W, H)]
-// n_holes (device, nullable): [0] += the pixels without a depth, [1] += the strips of 8 pixels (one column of a tile row inside
-// the image) that hold both a hole and a depth
-hipError_t launch_build_valid_maps(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint8_t *valid,
-                                   unsigned long long *n_holes, hipStream_t stream);
-// validity bits (TileMapRec::vbits) of n_maps depth tables: bits[n_maps][valid_bits_bytes(W, H) / 4]
-hipError_t launch_build_valid_bits(const void *depth, int depth_is_f64, int64_t n_maps, int W, int H, uint32_t *bits,
-                                   hipStream_t stream);
+// The upload pass in one kernel (fusion_classify.hip): n_maps host tables (f64 or f32, vtk row order, optionally with best-cost
+// values and their threshold) -> depth tables (top row first, f32 or f64), the finest pyramid level, validity bytes and bits;
+// counters[0] += lossy narrowings, [1] += pixels without a depth, [2] += 8-pixel strips with both a hole and a depth.  The upper
+// pyramid levels follow with launch_build_pyramid_levels.
+hipError_t launch_upload_views(const void *in, int in_is_f64, const double *best_cost, double threshold, void *out, int out_is_f64,
+                               int64_t n_maps, int W, int H, const PyramidDesc &desc, DepthTile *pyramids, uint8_t *valid, uint32_t *bits,
+                               unsigned long long *counters, hipStream_t stream);
+hipError_t launch_build_pyramid_levels(int64_t n_maps, const PyramidDesc &desc, DepthTile *pyramids, hipStream_t stream);
 // window origins of the FREE column for the pairs of class MIXED_FREE_OR_NODEPTH of maps [first_map, first_map + n_maps): fills
 // args.win_origin and marks the class bytes (CLASS_HAS_WINDOW); after launch_classify_bricks
 hipError_t launch_window_origins(const TileArgs &args, const MapRec *maps_dev, int tk, uint8_t *classes, int general_k,

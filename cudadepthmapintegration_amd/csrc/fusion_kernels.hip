@@ -133,44 +133,6 @@ hipError_t launch_kmode(const FuseArgs &a, const FuseConfig &cfg, dim3 grid, dim
 }
 
 // ---- depth upload: threshold + row flip + optional narrowing ---------------------------------------
-// Storage order: image row 0 (top) first.  The reference keeps vtk order (row 0 = bottom) and flips
-// in the kernel's index (cu:141-149); flipping once here removes a subtract from every projection.
-__device__ __forceinline__ int64_t flipped_index(int64_t i, int W, int H) {
-  const int64_t npix = (int64_t)W * H;
-  const int64_t m = i / npix;
-  const int64_t rem = i - m * npix;
-  const int64_t row = rem / W;
-  const int64_t col = rem - row * W;
-  return m * npix + (int64_t)(H - 1 - row) * W + col;
-}
-
-template <typename OutT>
-__global__ __launch_bounds__(256) void convert_depth_kernel(const double *__restrict__ in,
-                                                            const double *__restrict__ best_cost, double thr,
-                                                            OutT *__restrict__ out, int64_t n, int W, int H,
-                                                            unsigned long long *__restrict__ lossy) {
-  unsigned int bad = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double d = in[i];
-    if (best_cost != nullptr && best_cost[i] > thr) d = -1.0;  // RD.cxx:159-166
-    const OutT o = (OutT)d;
-    // bit compare so that a NaN depth round-trips instead of flagging a lossy conversion forever
-    if (sizeof(OutT) == 4) {
-      const double back = (double)o;
-      bad += (__double_as_longlong(back) != __double_as_longlong(d)) && !(d != d);
-    }
-    out[flipped_index(i, W, H)] = o;
-  }
-  if (sizeof(OutT) == 4 && bad != 0) atomicAdd(lossy, (unsigned long long)bad);
-}
-
-template <typename OutT>
-__global__ __launch_bounds__(256) void flip_depth_f32_kernel(const float *__restrict__ in, OutT *__restrict__ out,
-                                                             int64_t n, int W, int H) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[flipped_index(i, W, H)] = (OutT)in[i];
-}
-
 __global__ __launch_bounds__(256) void widen_depth_kernel(const float *__restrict__ in, double *__restrict__ out,
                                                           int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -209,33 +171,6 @@ hipError_t launch_fuse(const FuseArgs &a, const FuseConfig &cfg, hipStream_t str
   }
   if (cfg.grid_is_f64) return launch_kmode<float, double>(a, cfg, grid, block, stream);
   return launch_kmode<float, float>(a, cfg, grid, block, stream);
-}
-
-hipError_t launch_convert_depth(const double *in, const double *best_cost, double threshold, void *out,
-                                int out_is_f64, int64_t n_maps, int W, int H, unsigned long long *lossy,
-                                hipStream_t stream) {
-  const int64_t n = n_maps * W * H;
-  if (n <= 0) return hipSuccess;
-  if (out_is_f64)
-    hipLaunchKernelGGL((convert_depth_kernel<double>), dim3(blocks_for(n)), dim3(256), 0, stream, in, best_cost,
-                       threshold, static_cast<double *>(out), n, W, H, lossy);
-  else
-    hipLaunchKernelGGL((convert_depth_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, stream, in, best_cost,
-                       threshold, static_cast<float *>(out), n, W, H, lossy);
-  return hipGetLastError();
-}
-
-hipError_t launch_flip_depth_f32(const float *in, void *out, int out_is_f64, int64_t n_maps, int W, int H,
-                                 hipStream_t stream) {
-  const int64_t n = n_maps * W * H;
-  if (n <= 0) return hipSuccess;
-  if (out_is_f64)
-    hipLaunchKernelGGL((flip_depth_f32_kernel<double>), dim3(blocks_for(n)), dim3(256), 0, stream, in,
-                       static_cast<double *>(out), n, W, H);
-  else
-    hipLaunchKernelGGL((flip_depth_f32_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, stream, in,
-                       static_cast<float *>(out), n, W, H);
-  return hipGetLastError();
 }
 
 // eight independent chains per lane: enough to cover the FMA latency at any occupancy
