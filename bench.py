@@ -405,6 +405,7 @@ def main():
     t_up = time.perf_counter()
     views = upload_scene(ctx, scene, args.scene, maps_per_gpu, W, H, spacing, keep_host=True)
     upload_s = time.perf_counter() - t_up
+    upload_kernels_ms = ctx.upload_kernel_ms()[1]
     info = ctx.info()
     depth_bytes = 8 if info.depth_storage_in_use == capi.DMI_DEPTH_F64 else 4
 
@@ -544,6 +545,9 @@ def main():
             "parallelism": "single GPU",
             "rccl_ranks": 0,
             "host_upload_s": round(upload_s, 3),
+            # hipEvent time of the upload pass's kernels over all the views (one kernel per chunk: threshold, row flip, narrowing,
+            # pyramid, validity bytes and bits), outside the timed region by the metric's definition
+            "upload_kernels_ms": round(upload_kernels_ms, 3),
         },
         "roofline": {
             "bound": "hbm",
@@ -564,9 +568,9 @@ def main():
             "fuse_ms": kern_ms,
             "algorithmic_bytes_per_launch": b_alg,
             "note": "kernel_ms = hipEvent time of the fusion kernel alone (the launch rocprofv3 lists under this name), "
-                    "fuse_ms = all launches of one dmi_fuse (+ cz table, two classification passes, ordering); the path "
-                    "is bound by instruction issue (vector and scalar) and, with holes in the depth maps, the texture "
-                    "addresser -- not by HBM: see roofline_issue, roofline_valu and DESIGN.md 9",
+                    "fuse_ms = all launches of one dmi_fuse (+ cz table, two classification passes, window origins, ordering); "
+                    "the path is bound by instruction issue (vector, then scalar) -- not by HBM: see roofline_issue, "
+                    "roofline_valu and DESIGN.md 9",
         },
         "roofline_valu": {
             "bound": "valu_fp64",
@@ -615,13 +619,24 @@ def issue_roofline(counts, kernel_ms):
     vector = counts["valu_insts"]
     busy = counts.get("valu_active_quad_cycles") or vector
     salu = counts.get("salu_insts") or 0
+    ta = counts.get("ta_busy_cycles")
     vector_ms = busy * 4 / (1024 * 2.4e9) * 1e3
     scalar_ms = salu / (256 * 2.4e9) * 1e3
-    return {"bound": "vector_issue" if vector_ms >= scalar_ms else "scalar_issue",
+    ta_ms = ta / (256 * 2.4e9) * 1e3 if ta else None   # one texture addresser per CU: its busy cycles, summed over the chip
+    floors = {"vector_issue": vector_ms, "scalar_issue": scalar_ms}
+    if ta_ms is not None:
+        floors["texture_addresser"] = ta_ms
+    bound = max(floors, key=floors.get)
+    return {"bound": bound,
             "vector_wave_instructions": vector, "vector_busy_quad_cycles": busy, "salu_wave_instructions": salu,
             "branch_wave_instructions": counts.get("branch_insts"), "smem_wave_instructions": counts.get("smem_insts"),
-            "vector_floor_ms": vector_ms, "scalar_floor_ms": scalar_ms, "kernel_ms": kernel_ms,
-            "frac": max(vector_ms, scalar_ms) / kernel_ms, "source": counts.get("tag")}
+            "gather_wave_instructions": counts.get("vmem_rd_insts"), "cross_lane_lookup_wave_instructions": counts.get("lds_insts"),
+            "texture_addresser_busy_cycles": ta,
+            "vector_floor_ms": vector_ms, "scalar_floor_ms": scalar_ms, "ta_floor_ms": ta_ms, "kernel_ms": kernel_ms,
+            "frac": floors[bound] / kernel_ms,
+            "source": counts.get("tag"),
+            "note": "counters of the rocprofv3 passes recorded in profiles/pmc_traffic.json under the same key and tag as "
+                    "roofline.traffic (an earlier run of this workload, NOT this run); kernel_ms is this run's"}
 
 
 # ---- N > 1 -------------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ into build/obj/ and relinked only when a source or header is newer.
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -170,6 +171,17 @@ def audit_accumulator_registers(asm_text: str) -> tuple[int, list[str]]:
     return checked, bad
 
 
+def scratch_sizes(asm_text: str) -> dict:
+    """.amdhsa_private_segment_fixed_size of every fuse_tile_kernel instantiation (bytes of scratch memory per lane)."""
+    import re
+
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN3dmi\S*fuse_tile_kernel\S*)\b(.*?)\.end_amdhsa_kernel", asm_text, re.S):
+        size = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+        out[m.group(1)] = int(size.group(1)) if size else 0
+    return out
+
+
 def _audit_digest() -> str:
     return source_digest([os.path.join(CSRC, "fusion_tile.hip")] + _headers())
 
@@ -202,13 +214,21 @@ def run_accumulator_audit(verbose: bool = False) -> int:
         with open(out) as fh:
             text = fh.read()
     checked, bad = audit_accumulator_registers(text)
+    scratch = scratch_sizes(text)
+    # the headline instantiations (f32 depth, f32 grid, 16-voxel columns, persistent, with and without the window column) use no
+    # scratch memory at all: a toolchain or source change that makes them spill is caught here, not in a profile months later
+    for name, size in scratch.items():
+        if re.search(r"fuse_tile_kernelIffLi16ELi1ELi1ELi5ELi8ELb0ELb0ELb0ELb1ELb[01]E", name) and size != 0:
+            bad.append(f"{name}: {size} bytes of scratch memory per lane in a headline instantiation (expected none)")
     if bad:
         raise RuntimeError("accumulator-register audit of fusion_tile.hip FAILED (a toolchain change broke the hidden "
                            "register file; results would be silently wrong):\n  " + "\n  ".join(bad[:20]))
     version = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
     os.makedirs(OBJ_DIR, exist_ok=True)
     with open(os.path.join(OBJ_DIR, "acc_audit.json"), "w") as fh:
-        json.dump({"instantiations": checked, "violations": 0, "hipcc": version[:2], "digest": _audit_digest()}, fh)
+        json.dump({"instantiations": checked, "violations": 0, "hipcc": version[:2], "digest": _audit_digest(),
+                   "scratch_bytes_per_lane": {"max": max(scratch.values()) if scratch else None,
+                                              "instantiations_with_scratch": sum(1 for v in scratch.values() if v)}}, fh)
     if verbose:
         print(f"accumulator audit: {checked} fuse_tile_kernel instantiations clean ({version[0] if version else 'hipcc'})", flush=True)
     return checked

@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_fp64_probe", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
-    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram", "dmi_get_window_pair_count",
+    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram", "dmi_get_window_pair_count", "dmi_get_upload_kernel_ms", "dmi_sizeof_info", "dmi_sizeof_timings",
     "dmi_color_set_scratch_budget", "dmi_color_set_vertex_reorder", "dmi_iso_active_cells",
     "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_peer_chunk", "dmi_multi_create",
     "dmi_multi_get_unique_id", "dmi_multi_create_rank", "dmi_multi_destroy", "dmi_multi_last_error", "dmi_multi_add_views",
@@ -170,6 +170,10 @@ def load() -> ctypes.CDLL:
     L.dmi_get_mixed_reason_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     if hasattr(L, "dmi_get_window_pair_count"):  # (absent from an older prebuilt library loaded for an A/B timing, tools/gpu_exp.py)
         L.dmi_get_window_pair_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    if hasattr(L, "dmi_get_upload_kernel_ms"):
+        L.dmi_get_upload_kernel_ms.argtypes = [vp, dp, dp]
+        L.dmi_sizeof_info.restype = ctypes.c_size_t
+        L.dmi_sizeof_timings.restype = ctypes.c_size_t
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -437,6 +441,14 @@ class FusionContext:
             return 0
         self._check(self._lib.dmi_get_window_pair_count(self._h, ctypes.byref(n)))
         return int(n.value)
+
+    def upload_kernel_ms(self) -> tuple:
+        """(last, total) hipEvent milliseconds of the upload pass's kernels (dmi_get_upload_kernel_ms)."""
+        if not hasattr(self._lib, "dmi_get_upload_kernel_ms"):
+            return (0.0, 0.0)
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.dmi_get_upload_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return (float(a.value), float(b.value))
 
     def timings(self) -> TimingsC:
         t = TimingsC()
@@ -944,8 +956,13 @@ def cli_binary() -> str:
     """Path of the dmi_reconstruction executable next to the library (linked now if the build has not done so: it needs
     hipcc, which a box that only runs a prebuilt library may lack -- loading the library never depends on it)."""
     from . import build as _build
-    if not os.path.exists(_build.CLI_PATH):
+    # always through build_cli(): it returns at once when the executable's digest names the library's sources, and relinks one
+    # left over from older sources (an older ABI's main against this library) -- only without hipcc is an existing file taken as is
+    try:
         _build.build_cli()
+    except Exception:
+        if not os.path.exists(_build.CLI_PATH):
+            raise
     return _build.CLI_PATH
 
 

@@ -126,6 +126,8 @@ struct dmi_context {
   double *d_stage_depth = nullptr, *d_stage_cost = nullptr;
   size_t stage_capacity = 0;  // elements per staging buffer
   unsigned long long *d_lossy = nullptr;
+  hipEvent_t up_start = nullptr, up_stop = nullptr;  // around the upload pass's kernels (dmi_get_upload_kernel_ms)
+  double last_upload_kernel_ms = 0.0, total_upload_kernel_ms = 0.0;
 
   std::vector<EventPair> pending, pool;
   dmi_timings timings{};
@@ -309,6 +311,8 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
         e = hipMemcpyAsync(ctx->d_stage_cost, best_cost + m0 * npix, cnt * npix * 8, hipMemcpyHostToDevice, ctx->upload_stream);
       void *dst = static_cast<char *>(b.d_depth) + m0 * npix * esz;
       // one pass over the staged tables: threshold, row flip, narrowing, the finest pyramid level, validity bytes and bits
+      const bool timed = m0 + cnt >= (size_t)n && ctx->up_start && ctx->up_stop;  // (the last chunk of the call: with it, the pyramid levels)
+      if (e == hipSuccess && timed) e = hipEventRecord(ctx->up_start, ctx->upload_stream);
       if (e == hipSuccess)
         e = dmi::launch_upload_views(ctx->d_stage_depth, depth32 ? 0 : 1, (!depth32 && best_cost) ? ctx->d_stage_cost : nullptr, threshold,
                                      dst, ctx->depth_f64 ? 1 : 0, (int64_t)cnt, ctx->W, ctx->H, ctx->pyramid,
@@ -320,10 +324,22 @@ int upload_batch(dmi_context *ctx, const double *depth64, const float *depth32, 
     }
     // depth bounds per 16 x 16 ... image-sized tile of every table: what the brick classification reads
     if (e == hipSuccess) e = dmi::launch_build_pyramid_levels(n, ctx->pyramid, b.d_pyramid, ctx->upload_stream);
+    if (e == hipSuccess && ctx->up_start && ctx->up_stop) e = hipEventRecord(ctx->up_stop, ctx->upload_stream);
     unsigned long long counters[3] = {0, 0, 0};
     if (e == hipSuccess)
       e = hipMemcpyAsync(counters, ctx->d_lossy, sizeof(counters), hipMemcpyDeviceToHost, ctx->upload_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->upload_stream);
+    if (e == hipSuccess && ctx->up_start && ctx->up_stop) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->up_start, ctx->up_stop) == hipSuccess) {
+        // (a call of several staged chunks times its last one: scaled to the call's views)
+        const size_t last_cnt = (size_t)n - ((size_t)n - 1) / chunk * chunk;
+        ctx->last_upload_kernel_ms = (double)ms * (double)n / (double)last_cnt;
+        ctx->total_upload_kernel_ms += ctx->last_upload_kernel_ms;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     *lossy_out = counters[0];
     b.holes = counters[1];
     b.mingled_strips = counters[2];
@@ -707,6 +723,15 @@ int sync_maps(dmi_context *ctx) {
 extern "C" {
 
 int dmi_abi_version(void) { return DMI_ABI_VERSION; }
+size_t dmi_sizeof_info(void) { return sizeof(dmi_info); }
+size_t dmi_sizeof_timings(void) { return sizeof(dmi_timings); }
+
+int dmi_get_upload_kernel_ms(dmi_context *ctx, double *last, double *total) {
+  if (!ctx) return DMI_ERR_INVALID_ARGUMENT;
+  if (last) *last = ctx->last_upload_kernel_ms;
+  if (total) *total = ctx->total_upload_kernel_ms;
+  return DMI_OK;
+}
 
 int dmi_device_count(void) {
   int n = 0;
@@ -813,6 +838,10 @@ int dmi_create(const dmi_grid_desc *grid, const dmi_ray_potential *ray, const dm
   }
   e = hipMalloc(&ctx->d_lossy, 3 * sizeof(unsigned long long));
   if (e != hipSuccess) return hip_fail(e, "hipMalloc(lossy)");
+  if (hipEventCreate(&ctx->up_start) != hipSuccess || hipEventCreate(&ctx->up_stop) != hipSuccess) {
+    (void)hipGetLastError();  // (the upload pass is then not timed)
+    ctx->up_start = ctx->up_stop = nullptr;
+  }
   int rc = dmi_reset_grid(ctx);
   if (rc != DMI_OK) {
     g_create_error = ctx->err;
@@ -840,6 +869,8 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_zero_row) (void)hipFree(ctx->d_zero_row);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
   if (ctx->d_order_level) (void)hipFree(ctx->d_order_level);
+  if (ctx->up_start) (void)hipEventDestroy(ctx->up_start);
+  if (ctx->up_stop) (void)hipEventDestroy(ctx->up_stop);
   for (EventPair &p : ctx->pending) {
     (void)hipEventDestroy(p.start);
     (void)hipEventDestroy(p.stop);
@@ -1210,8 +1241,10 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // has a SIMD to itself, and the seven launches that classify and order the bricks take longer than the per-voxel work
     // they would save (64^3: 79 -> 49 us at 4 views, 278 -> 192 us at 64; from 96^3 on the classes win;
     // profiles/r07o_small_fusions_classes_on_off.txt).
+    // (decided from the WHOLE grid's bricks: a slab launch of a larger grid -- dmi_fuse_slab, the overlapped exchanges of
+    // dmi_multi_fuse -- keeps its classes, as the whole-grid launches the rule was calibrated on)
     if (!(cfg.variant & (dmi::VAR_NO_BRICK_CLASSES | dmi::VAR_BRICK_CLASSES_ALWAYS)) &&
-        (int64_t)t.wbricks_x * t.wbricks_y * ((int64_t)t.super_z * 2) <= dmi::kNoClassesMaxBricks)
+        (int64_t)t.wbricks_x * t.wbricks_y * (int64_t)t.bricks_z <= dmi::kNoClassesMaxBricks)
       cfg.variant |= dmi::VAR_NO_BRICK_CLASSES;
     // row pitch of the class tables: a power of two >= 64 views, so that views arriving in chunks (add, fuse, add,
     // fuse ...) change the layout -- and force a reallocation, which waits for the device -- only at doublings

@@ -453,12 +453,14 @@ int peer_exchange(dmi_multi_context *m, bool by_slabs, std::vector<void *> &grid
   }
   int rc = sum_and_gather(n_rounds - 1);
   if (rc != DMI_OK) return rc;
-  // whoever touches a grid next on its compute stream sees every chunk's sum
+  // Whoever touches a grid next on its compute stream sees every chunk's sum -- and finds the rank's OWN outgoing copies done:
+  // rank r's comm stream is still reading r's summed chunk out of r's grid while it gathers it to the others, so r.compute waits
+  // on r.gathered[s] too.  (Without that, the step's stop event preceded rank 0's outgoing copies -- the exposed exchange time
+  // read short -- and the next writer of the grid on r.compute, a reset or an upload, could overwrite a chunk in flight.)
   for (Rank &r : m->ranks) {
     DMI_M_HIP(m, hipSetDevice(r.device));
     for (Rank &j : m->ranks)
-      for (int s = 0; s < n_rounds; ++s)
-        if (j.rank != r.rank) DMI_M_HIP(m, hipStreamWaitEvent(r.compute, j.gathered[s], 0));
+      for (int s = 0; s < n_rounds; ++s) DMI_M_HIP(m, hipStreamWaitEvent(r.compute, j.gathered[s], 0));
   }
   return DMI_OK;
 }

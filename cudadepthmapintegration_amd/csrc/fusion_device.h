@@ -16,14 +16,20 @@ __device__ __forceinline__ double row4(const double *__restrict__ m, double x, d
 // ---- rayPotential<double>, cu:105-120 --------------------------------------------------------
 // sign = diff != 0 ? (int)(diff/|diff|) : 0 is +1, -1 or 0 and rho*sign one of three host-computed
 // products (FuseArgs::rho_pos / rho_neg / rho_zero), so no division is needed on the device.
-template <typename Args>
-__device__ __forceinline__ double ray_potential(const Args &a, double real_depth, double depth) {
+// (the parameters by value: read through a struct on the stack, hipcc turned the three-way choice of the plateau into an indexed
+// load from that struct -- the only scratch memory of the tiled kernel)
+__device__ __forceinline__ double ray_potential_values(double thick, double delta, double rho_pos, double rho_neg, double rho_zero,
+                                                       double slope, double free_space, double real_depth, double depth) {
   const double diff = real_depth - depth;  // cu:108
   const double ad = fabs(diff);            // cu:110
-  const double far_value = diff > 0 ? 0.0 : a.free_space;                               // cu:115
-  const double plateau = diff > 0 ? a.rho_pos : (diff < 0 ? a.rho_neg : a.rho_zero);    // cu:112,117
-  const double ramp = a.slope * diff;                                                   // cu:119
-  return ad > a.delta ? far_value : (ad > a.thick ? plateau : ramp);                    // cu:114-119
+  const double far_value = diff > 0 ? 0.0 : free_space;                           // cu:115
+  const double plateau = diff > 0 ? rho_pos : (diff < 0 ? rho_neg : rho_zero);    // cu:112,117
+  const double ramp = slope * diff;                                               // cu:119
+  return ad > delta ? far_value : (ad > thick ? plateau : ramp);                  // cu:114-119
+}
+template <typename Args>
+__device__ __forceinline__ double ray_potential(const Args &a, double real_depth, double depth) {
+  return ray_potential_values(a.thick, a.delta, a.rho_pos, a.rho_neg, a.rho_zero, a.slope, a.free_space, real_depth, depth);
 }
 
 // ---- exact pixel decision: the reference's divide + round + bounds test (cu:177-197) ---------

@@ -182,11 +182,6 @@ struct DepthLoad<double> {
   static __device__ __forceinline__ double widen(raw_t d) { return d; }
 };
 
-// Ray-potential parameters as the exact fallback reads them from the FuseArgs copy.
-struct RayArgs {
-  double thick, delta, rho_pos, rho_neg, rho_zero, slope, free_space;
-};
-
 // The reference's expression for one voxel and one map, in full (cu:166-211).  Used for the lanes
 // whose fast-path pixel choice is not proven.  Everything is read from the FuseArgs copy in device
 // memory so that the main loop does not keep it in SGPRs.  Returns true when the thread reaches cu:211.
@@ -218,15 +213,8 @@ __device__ __forceinline__ bool tile_exact(const FuseArgs *__restrict__ fa, int 
   if (!pixel_exact(hx, hy, hz, W, H, px, py)) return false;  // cu:177-197
   const typename DepthLoad<DepthT>::raw_t d = DepthLoad<DepthT>::load(rsrc, (unsigned)(W * py + px));  // cu:201
   if (DepthLoad<DepthT>::is_sentinel(d)) return false;                                                  // cu:202
-  RayArgs ra;
-  ra.thick = cload(&fa->thick);
-  ra.delta = cload(&fa->delta);
-  ra.rho_pos = cload(&fa->rho_pos);
-  ra.rho_neg = cload(&fa->rho_neg);
-  ra.rho_zero = cload(&fa->rho_zero);
-  ra.slope = cload(&fa->slope);
-  ra.free_space = cload(&fa->free_space);
-  val = ray_potential(ra, cz, DepthLoad<DepthT>::widen(d));  // cu:207-209
+  val = ray_potential_values(cload(&fa->thick), cload(&fa->delta), cload(&fa->rho_pos), cload(&fa->rho_neg), cload(&fa->rho_zero),
+                             cload(&fa->slope), cload(&fa->free_space), cz, DepthLoad<DepthT>::widen(d));  // cu:207-209
   return true;
 }
 

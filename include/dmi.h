@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define DMI_ABI_VERSION 3 /* 3: dmi_info grew (pixels_without_depth); dmi_iso_active_cells, DMI_EXCHANGE_PEER_COPY, dmi_multi_peer_chunk */
+#define DMI_ABI_VERSION 4 /* 3: dmi_info grew (pixels_without_depth); dmi_iso_active_cells, DMI_EXCHANGE_PEER_COPY, dmi_multi_peer_chunk
+                           * 4: dmi_get_window_pair_count, dmi_get_upload_kernel_ms, dmi_sizeof_info / dmi_sizeof_timings */
 
 typedef struct dmi_context dmi_context;
 
@@ -229,8 +230,18 @@ int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]);
  * window of validity bits (one coalesced fetch per pair) instead of one gather per voxel.  Synchronises. */
 int dmi_get_window_pair_count(dmi_context *ctx, uint64_t *out);
 
+/* dmi_get_info / dmi_get_timings fill sizeof(dmi_info) / sizeof(dmi_timings) bytes AS THIS LIBRARY WAS BUILT: a caller compiled
+ * against an older header (a shorter struct) must check dmi_abi_version() == DMI_ABI_VERSION -- or compare its own sizeof with
+ * dmi_sizeof_info() / dmi_sizeof_timings() -- before passing its buffer. */
 int dmi_get_timings(dmi_context *ctx, dmi_timings *out);
 int dmi_get_info(dmi_context *ctx, dmi_info *out);
+size_t dmi_sizeof_info(void);
+size_t dmi_sizeof_timings(void);
+
+/* hipEvent time of the upload pass (the one kernel per staged chunk that thresholds, flips and narrows the tables and builds the
+ * pyramid base, the validity bytes and bits, plus the upper pyramid levels) of the last dmi_add_views* call, and summed over
+ * the context's life; the copies are not in it.  Either pointer may be null. */
+int dmi_get_upload_kernel_ms(dmi_context *ctx, double *last, double *total);
 
 /* Pinned host memory for the SoA staging buffers of the host side (hipHostMalloc). */
 int dmi_alloc_pinned(size_t bytes, void **out);

@@ -3,6 +3,7 @@ include/dmi.h declares; with no GPU the product path fails loudly (no CPU fallba
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -29,11 +30,32 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_defaults():
     lib = capi.load()
-    assert lib.dmi_abi_version() == 3
+    assert lib.dmi_abi_version() == 4
     o = capi.OptionsC()
     lib.dmi_default_options(ctypes.byref(o))
     assert (o.device, o.grid_dtype, o.depth_storage, o.count_hits, o.kernel_variant) == (0, capi.DMI_F64, 0, 0, 0)
     assert lib.dmi_last_error(None) is not None
+
+
+def test_struct_sizes_match_the_bindings():
+    lib = capi.load()
+    assert lib.dmi_sizeof_info() == ctypes.sizeof(capi.InfoC)
+    assert lib.dmi_sizeof_timings() == ctypes.sizeof(capi.TimingsC)
+
+
+def test_issue_roofline_reads_the_counters_of_the_traffic_record():
+    """bench.py's roofline.traffic and roofline_issue come from ONE record of profiles/pmc_traffic.json (same key, same tag): a
+    record that has instruction counters also names the profile they came from, and the texture addresser's busy cycles."""
+    import json
+    db = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    rec = db["cfg3:speckle:f32"]
+    assert rec["tag"] and rec["hbm_bytes_per_launch"] > 0 and rec["valu_insts"] > 0
+    assert os.path.exists(os.path.join(ROOT, "profiles", rec["tag"] + "_pmc.json"))
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.issue_roofline(rec, 10.0)
+    assert r["source"] == rec["tag"] and r["bound"] in ("vector_issue", "scalar_issue", "texture_addresser")
+    assert r["ta_floor_ms"] is not None and r["frac"] == max(r["vector_floor_ms"], r["scalar_floor_ms"], r["ta_floor_ms"]) / 10.0
 
 
 def test_invalid_arguments_are_reported_not_fatal():

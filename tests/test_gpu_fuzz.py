@@ -92,6 +92,15 @@ def test_random_scenes_bit_exact(seed):
         assert np.array_equal(mh, mh_w), (seed, variant)
         assert np.array_equal(vh, vh_w), (seed, variant)
         assert bits_equal(out, want), (seed, variant)
+    # the shipped default (no brick classes on grids this small: every pair through the column with every test), with and
+    # without hit counters
+    from helpers import shipped_defaults
+    with shipped_defaults():
+        for count_hits in (True, False):
+            out, vh, mh = capi.fuse_once(grid, rp, views, init_grid=init, count_hits=count_hits, kernel_variant=0)
+            assert bits_equal(out, want), (seed, "shipped", count_hits)
+            if count_hits:
+                assert np.array_equal(mh, mh_w) and np.array_equal(vh, vh_w), (seed, "shipped")
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -44,6 +44,39 @@ def test_golden_bit_exact_f64(golden, variant):
     assert bits_equal(out, golden["expected_grid"])
 
 
+@pytest.mark.parametrize("count_hits", [True, False])
+def test_golden_bit_exact_under_shipped_defaults(golden, count_hits):
+    """What a caller gets with kernel_variant 0: on grids of at most 1024 bricks no brick classes at all (the other tests of this
+    file switch them on, conftest.py).  Rotated grids, general K, initial grids, border footprints: all the golden scenes."""
+    from helpers import shipped_defaults
+    grid, rp, views, thr = _golden_inputs(golden)
+    with shipped_defaults():
+        out, vh, mh = capi.fuse_once(grid, rp, views, threshold=thr, init_grid=golden.get("init_grid"), count_hits=count_hits)
+    assert bits_equal(out, golden["expected_grid"])
+    if count_hits:
+        assert np.array_equal(mh, golden["expected_map_hits"]) and np.array_equal(vh, golden["expected_voxel_hits"])
+
+
+def test_slab_fuses_of_a_larger_grid_keep_their_classes_under_shipped_defaults():
+    """64 x 64 x 256 cells fused in slabs of 32 layers: each launch has 512 bricks, the grid 4096 -- the no-classes rule looks at
+    the grid (dmi_capi.hip), so the slabs are classified like a whole-grid launch; bit for bit the oracle's grid."""
+    from helpers import shipped_defaults
+    grid = scene.default_grid((64, 64, 256))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(5, 160, 120, seed=3, dense=True)
+    views.depth[np.random.default_rng(6).random(views.depth.shape) < 0.1] = -1.0
+    want = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
+    with shipped_defaults():
+        with capi.FusionContext(grid, rp) as ctx:
+            ctx.add_views(views)
+            for z in range(0, 256, 32):
+                ctx.fuse_slab(z, 32)
+            out = ctx.download_grid()
+            hist = ctx.brick_class_histogram()
+    assert bits_equal(out, want)
+    assert sum(hist.values()) > 0, hist
+
+
 W = capi.VARIANT_WINDOWS_ALWAYS   # the FREE column's bit windows whatever the depth maps look like (default: maps with scattered holes)
 
 
@@ -585,7 +618,7 @@ def test_peer_copy_exchange_with_ranks_sharing_this_gpu(world, n_slabs, grid_dty
         expect = part if expect is None else (expect + part).astype(np_t)
     with capi.MultiContext(grid, rp, devices=[0] * world, grid_dtype=grid_dtype, exchange="peer_copy", n_slabs=n_slabs) as m:
         m.add_views(views)          # one batch: rank r takes multi_view_shard(7, r, world), as the expectation above does
-        for _ in range(2):
+        for _ in range(4):          # back to back, never synchronised: a step's reset must not overtake the previous step's copies
             m.fuse()
         got, (first, count) = m.download_grid(np_t)
         info = m.info()
@@ -596,7 +629,7 @@ def test_peer_copy_exchange_with_ranks_sharing_this_gpu(world, n_slabs, grid_dty
             ctx_i = m.local_context_grid(i, np_t)
             assert bits_equal(ctx_i.astype(np.float64), expect.astype(np.float64)), i
         t = m.timings()
-        assert t.steps >= 2 and t.last_step_ms > 0
+        assert t.steps >= 4 and t.last_step_ms > 0
     assert np.abs(expect).max() > 0.5
 
 

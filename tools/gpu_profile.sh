@@ -13,7 +13,7 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS
 timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/fetch -- $P > $O.fetch.log 2>&1; echo "pmc3 rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -- $P > $O.write.log 2>&1; echo "pmc4 rc=$?"
 timeout 600 rocprofv3 --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum --output-format csv -d $O/ta -- $P > $O.ta.log 2>&1; echo "pmc5 rc=$?"
-timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM --output-format csv -d $O/sq3 -- $P > $O.sq3.log 2>&1; echo "pmc6 rc=$?"
+timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM --output-format csv -d $O/sq3 -- $P > $O.sq3.log 2>&1; echo "pmc6 rc=$?"
 if [ -x build/fetch_calibration ]; then
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal -- ./build/fetch_calibration > $O.cal.log 2>&1; echo "cal rc=$?"
 fi

@@ -101,13 +101,16 @@ def main():
             if kern_ms:
                 lines.append(f"* VALU issue floor at 4 cycles per fp64-rate wave-instruction on 1024 SIMDs, 2.4 GHz: "
                              f"{v * 4 / 1024 / 2.4e9 * 1e3:.2f} ms of {kern_ms:.2f} ms")
+        if "TA_TA_BUSY_sum" in c and kern_ms:
+            lines.append(f"* texture-addresser floor: TA_TA_BUSY_sum over 256 CUs (one addresser each) at 2.4 GHz: "
+                         f"{c['TA_TA_BUSY_sum'] / 256 / 2.4e9 * 1e3:.2f} ms of {kern_ms:.2f} ms")
         if "SQ_INSTS_SALU" in c and kern_ms:
             sa = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_BRANCH", 0.0) + c.get("SQ_INSTS_SMEM", 0.0)
             lines.append(f"* scalar-issue floor: SALU + branch + SMEM wave-instructions at one per cycle per CU (the four SIMDs of "
                          f"a CU share one scalar unit), 256 CUs, 2.4 GHz: {sa / 256 / 2.4e9 * 1e3:.2f} ms of {kern_ms:.2f} ms")
         for name in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
                      "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
-                     "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "TA_BUSY_avr", "TA_TA_BUSY_sum",
+                     "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_LDS", "TA_BUSY_avr", "TA_TA_BUSY_sum",
                      "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
             if name in c:
                 lines.append(f"* {name} = {c[name]:.5g}")
@@ -143,7 +146,11 @@ def main():
                                 "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"),
                                 "branch_insts": c.get("SQ_INSTS_BRANCH"), "smem_insts": c.get("SQ_INSTS_SMEM"),
                                 # quad-cycles the vector pipes spent executing (a quarter-rate instruction counts four times)
-                                "valu_active_quad_cycles": c.get("SQ_ACTIVE_INST_VALU")}
+                                "valu_active_quad_cycles": c.get("SQ_ACTIVE_INST_VALU"),
+                                # busy cycles of the texture addressers, summed over the 256 CUs' (one per CU); gathers and
+                                # cross-lane look-ups (ds_bpermute_b32) issued
+                                "ta_busy_cycles": c.get("TA_TA_BUSY_sum"), "vmem_rd_insts": c.get("SQ_INSTS_VMEM_RD"),
+                                "lds_insts": c.get("SQ_INSTS_LDS")}
                 json.dump(db, open(path, "w"), indent=1, sort_keys=True)
         lines.append("")
     with open(os.path.join(pdir, f"{args.tag}_summary.md"), "w") as f:
