@@ -568,8 +568,13 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           } else {
             czf64 = ((cload(&rf->rz0) * wx + cload(&rf->rz1) * wy) + cload(kf->cz_table + (int64_t)m * kf->kpad + k0)) + cload(&rf->rz3);
           }
+          // (one row of the record at a time: fetched in one batch, the set-up's loads need forty scalar registers at once and
+          // the long-lived values around them go to spill lanes and back -- a dozen vector instructions per pair)
+          __builtin_amdgcn_sched_barrier(0);
           hxf = __builtin_fma(cload(&rf->cpx), wxf, __builtin_fma(cload(&rf->cpy), wyf, __builtin_fma(cload(&rf->cpz), wzf, cload(&rf->cp0))));
+          __builtin_amdgcn_sched_barrier(0);
           hyf = __builtin_fma(cload(&rf->cqx), wxf, __builtin_fma(cload(&rf->cqy), wyf, __builtin_fma(cload(&rf->cqz), wzf, cload(&rf->cq0))));
+          __builtin_amdgcn_sched_barrier(0);
         };
         f32x2 H0, C0, DH, DC;
         {
@@ -581,11 +586,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column (4d)
           const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
           const float thr = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
-          // lanes outside the grid own no voxel (their sums are never stored): with c.z = 1 and an infinite threshold they accept
-          // whatever candidate they form, so "not accepted" needs no mask of the lanes that count
-          C0.x = lane_ok ? czf : 1.0f;
-          C0.y = lane_ok ? thr : __builtin_inff();
+          // (lanes outside the grid own no voxel -- their sums are never stored -- and run like any other: their world position
+          // is as finite as their neighbours'; one of them not accepted costs a redo that adds to a sum nobody reads)
+          C0.x = czf;
+          C0.y = thr;
         }
+        __builtin_amdgcn_sched_barrier(0);
         DH.x = cload(&rec->t1_dhx);
         DH.y = cload(&rec->t1_dhy);
         DC.x = cload(&rec->t1_dcz);
