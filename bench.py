@@ -22,7 +22,8 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   roofline      HBM view of the fusion launch: algorithmic bytes / hipEvent time vs 8 TB/s; flop_frac_* say how much of
                 SURVEY 8d's arithmetic the timed kernel executes (the brick classes prove most of it away)
   scenes        the other scene kinds on the same context: dense (every pixel valid), speckle (the default: 10 % of the
-                pixels invalidated by the best-cost threshold), noisy (+ depth noise and holes)
+                pixels invalidated by the best-cost threshold), noisy (+ depth noise and holes), room (a second
+                geometry: cameras inside the grid looking outward at walls)
   roofline_valu the binding roof of the per-voxel path: fp64 VALU issue (DESIGN.md "Roofline"), measured on
                 the same workload with brick classes switched off (every projection computed)
   roofline_issue what bounds the default path: vector / scalar instruction issue -- vector-pipe busy cycles and SALU
@@ -56,7 +57,7 @@ L2_GATHER_PEAK_GBPS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": rows served
 FLOP_PER_PROJECTION = 48.0  # algorithmic fp64 flop per voxel-projection
 MAPREC_BYTES = 208  # per-map camera record read by the kernel (fusion_kernels.h)
 
-SCENE_KINDS = ("dense", "sparse", "speckle", "noisy")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
 SCENE_SEED = 1000
 
 
@@ -288,7 +289,8 @@ def main():
                     help="speckle (default): SURVEY.md 8d's input -- the dense sphere scene with best-cost values ~ U[0,1) and the "
                          "threshold that turns ~10 %% of the pixels into 'no depth', applied by dmi_add_views as the reference's "
                          "filter applies it (RD.cxx:138-167); dense: every pixel holds a depth; sparse: sphere only; noisy: speckle "
-                         "+ one voxel of depth noise + holes")
+                         "+ one voxel of depth noise + holes; room: a second geometry -- cameras inside the grid looking outward at the "
+                         "walls of a room, depths over an order of magnitude, grazing walls, 10 %% speckle")
     ap.add_argument("--no-scenes", action="store_true", help="N = 1: skip the `scenes` object (the other scene kinds, timed beside the headline)")
     ap.add_argument("--grid-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--variant", type=int, default=0)
@@ -487,16 +489,21 @@ def main():
     if not args.no_scenes:
         scenes = {}
         resident = args.scene
-        for kind in ("dense", "speckle", "noisy"):
+        for kind in ("dense", "speckle", "noisy", "room"):
             if kind != resident:
                 ctx.clear_views()
                 upload_scene(ctx, scene, kind, maps_per_gpu, W, H, spacing)
                 resident = kind
             n_steps = max(2, args.steps // 2)
             dt2, kern2 = timed(n_steps, 1)
+            bc = ctx.brick_class_histogram()
+            pairs = sum(bc.values())
             scenes[kind] = {"value": n_vox * maps_per_gpu * n_steps / dt2 / 1e9, "ms_per_step": dt2 / n_steps * 1e3,
-                            "fuse_ms": kern2, "kernel_ms": timed.main_ms, "brick_classes": ctx.brick_class_histogram(),
-                            "mixed_reasons": ctx.mixed_reason_histogram()}
+                            "fuse_ms": kern2, "kernel_ms": timed.main_ms, "brick_classes": bc,
+                            "mixed_reasons": ctx.mixed_reason_histogram(), "window_pairs": ctx.window_pair_count(),
+                            # the launch shape the library picked for these depth maps (dmi_capi.hip): voxels per column, from the
+                            # number of (brick, view) pairs it classified
+                            "column_height": (int(round(n_vox * maps_per_gpu / 64 / pairs)) if pairs else None)}
         if resident != args.scene:   # leave the context as the sections below expect it: the headline scene resident
             ctx.clear_views()
             upload_scene(ctx, scene, args.scene, maps_per_gpu, W, H, spacing)

@@ -438,8 +438,11 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   const double D = kMaxColumn * std::max(std::fabs(t.cdhx), std::fabs(t.cdhy));  // their change over a column
   const double Dz = kMaxColumn * std::fabs(dcz);
   const double nl = rot * 32.0 * 0x1p-53 * M[2];  // computed c.z against its affine model along a column (roundings of cu:80-92)
-  if (!(czmin > 0.0) || !std::isfinite(czmin)) return;  // the camera is inside (or too near) the grid: fp64 tier only
-  const double pmax = Sc / czmin + 1.0;                 // bounds every accepted tier-1 candidate |P|
+  if (!std::isfinite(czmin)) return;
+  // The camera inside (or too near) the grid: no bound of |P| holds for the whole view; the kernel forms one per lane from its
+  // column's own c.z (t1_ok = 2).  pmax enters e1 linearly: e1 = (A + B pmax)(1 + 2^-10).
+  const bool per_lane = !(czmin > 0.0) || !(Sc / czmin + 1.0 < 0x1p22);
+  const double pmax = per_lane ? 0.0 : Sc / czmin + 1.0;  // bounds every accepted tier-1 candidate |P|
   // W*py'' + px'' and the validity map's byte index yt*(8W - 8) + (8 px'' + py'') (|.| <= H*W + 4W + H/2) exact in fp32
   // (of the padded image: every pixel the FREE column may ask for lies within the margin, 4b.9)
   const bool index_exact = ((int64_t)ctx->H + 2 * dmi::kValidMargin + 8) * ((int64_t)ctx->W + 2 * dmi::kValidMargin) + ctx->H +
@@ -450,8 +453,19 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   t.t1_erel = 0x1p-22f * (1.0f + 0x1p-10f);
   t.t1_hspan = float_not_below(D * (1.0 + 0x1p-20));
   if (!(pmax < 0x1p22) || !index_exact || !(e1 > 0x1p-100) || !(Sc < 0x1p60) || !std::isfinite(e1)) return;
-  t.t1_e1 = float_not_below(e1);
+  t.t1_e1 = float_not_below(e1);  // (per_lane: the part of e1 that does not depend on pmax)
   t.t1_ok = 1;
+  if (per_lane) {
+    // the coefficient of pmax, rounded up, with one more factor (1 + 2^-10) for the roundings of the lane's own p
+    const double B = (3.0 * 0x1p-24 * Dz + nl) * (1.0 + 0x1p-10) * (1.0 + 0x1p-10);
+    if (!(B < 0x1p60) || !(B >= 0.0)) {
+      t.t1_ok = 0;
+      t.t1_e1 = std::numeric_limits<float>::infinity();
+      return;
+    }
+    t.t1_b = float_not_below(B);
+    t.t1_ok = 2;
+  }
 }
 
 // Per-map record of the tiled kernel: row 2 of RT for the exact c.z, rows 0 and 1 of K*[R|T] for the
@@ -1272,8 +1286,10 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       // ... and behind that the window origins of the FREE column (TileArgs::win_origin), one word per class byte
       // (for depth maps with holes scattered all over them -- cfg.holes: what makes the FREE column the busiest one -- ; the
       // launch then runs the kernel's WIN instantiation, which pays for the window code in every column, fusion_tile.hip)
+      bool any_tier1 = false;  // (a launch none of whose views runs tier 1 has no window pair: the plain instantiation serves it)
+      for (int32_t m = first; m < first + count && !any_tier1; ++m) any_tier1 = ctx->h_tile_maps[(size_t)m].t1_ok != 0;
       const bool windows = !cfg.general_k && !cfg.count_hits && !(cfg.variant & (dmi::VAR_NO_WINDOWS | dmi::VAR_NO_INTERIOR)) &&
-                           (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS));
+                           (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS)) && any_tier1;
       const size_t cbytes = coarse_end + (windows ? fine_bytes * 4 : 0);
       ctx->coarse_offset = fine_bytes;
       if (ctx->classes_capacity < cbytes) {

@@ -83,7 +83,7 @@ struct alignas(16) TileMapRec {
   float t1_e1, t1_c1;  // e1 = t1_e1 + t1_erel * (max(|hx''|, |hy''|) at the column's first voxel + t1_hspan)
   float t1_erel, t1_hspan;
   int32_t t1_cidx;  // W * cyc + cxc: pixel index of the image centre
-  int32_t t1_ok;
+  int32_t t1_ok;  // 0: tier 1 never accepts (t1_e1 = +inf); 1: e1 is the view's constant; 2: e1 per lane (t1_b)
   // Validity map of the view (round 3): one byte per pixel, 1 = the pixel holds a depth (anything but the -1 sentinel), in
   // tiles of 8 image rows over the image and its margin (kValidMargin): with X = x + margin, Y = y + margin and Wp = W + 2 margin,
   // byte (x, y) at ((Y >> 3) * Wp + X) * 8 + (Y & 7), valid_map_bytes(W, H) in all.  The FREE column of
@@ -103,7 +103,11 @@ struct alignas(16) TileMapRec {
   int32_t vb_bytes;    // valid_bits_bytes(W, H): the buffer range of one view's bits
   int32_t vb_rowskip;  // (tiles_x - 1) * 128: what a step to the next tile row adds beyond the 128 bytes of the tile itself
   int32_t vb_mx, vb_my;  // 0x4B400000 + margin + W / 2 (H / 2): the bits of the float 1.5 * 2^23 + (centre of the padded image)
-  int32_t vb_pad[2];
+  // t1_ok == 2 (round 4): the view has no positive lower bound of c.z over the grid -- its camera stands inside or next to the
+  // volume -- so the bound |P| <= pmax that the margin e1 needs is formed per lane and (brick, view) from the column's own c.z:
+  // e1 = t1_e1 + t1_b * (HB / min c.z of the column + 1) + t1_erel * HB (fusion_tile.hip)
+  float t1_b;
+  int32_t vb_pad;
 };
 #ifndef DMI_TIER1
 #define DMI_TIER1 1  // 0: every instantiation selects its pixels in fp64 only (A/B builds, tools/exp_list*.txt)

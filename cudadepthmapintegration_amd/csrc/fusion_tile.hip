@@ -128,6 +128,19 @@ __device__ __forceinline__ float max_abs(float a, float b) {
   asm("v_max_f32 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// Tier 1's absolute margin for a view without a grid-wide bound of |P| (TileMapRec::t1_ok == 2): an accepted
+// candidate of this column satisfies |P| < |h''| / c.z + 1 <= HB / (the column's least c.z) + 1 =: p, and the margin is linear
+// in that bound: e1 = e1_const + b * p.  c.z is affine along the column (its fp32 image monotone in the voxel's position), so
+// the least is at an end.  A column that reaches the camera plane (least c.z <= 0) or whose bound is not below 2^21 gets +inf:
+// tier 1 accepts nothing there and the fp64 tier decides, as for the whole view before.
+template <int TK>
+__device__ __forceinline__ float t1_lane_margin(float cz0, float dcz, float hb, float e1_const, float b) {
+  const float cz_last = __builtin_fmaf((float)(TK - 1), dcz, cz0);
+  const float least = __builtin_fmaxf(__builtin_fminf(cz0, cz_last), 0x1p-100f);
+  const float p = __builtin_fmaf(hb, __builtin_amdgcn_rcpf(least), 1.0f);
+  return p < 0x1p21f ? __builtin_fmaf(b, p, e1_const) : __builtin_inff();
+}
+
 // v_rcp_f32 whose result an inline-asm instruction may read next.  gfx950 does not interlock a transcendental result against
 // the very next VALU instruction; the compiler inserts the wait state for consumers it generates itself, but it cannot see
 // into an asm statement (found the hard way: the packed multiply below read a stale register in a part of the wave, and
@@ -585,7 +598,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           H0.y = (float)hyf;
           // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column (4d)
           const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
-          const float thr = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
+          float e1 = cload(&rec->t1_e1);
+          if (cload(&rec->t1_ok) == 2) e1 = t1_lane_margin<TK>(czf, cload(&rec->t1_dcz), hb, e1, cload(&rec->t1_b));  // wave-uniform
+          const float thr = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), e1));
           // (lanes outside the grid own no voxel -- their sums are never stored -- and run like any other: their world position
           // is as finite as their neighbours'; one of them not accepted costs a redo that adds to a sum nobody reads)
           C0.x = czf;
@@ -754,7 +769,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       C0.x = czf;
       // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column
       const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
-      C0.y = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), cload(&rec->t1_e1)));
+      float e1 = cload(&rec->t1_e1);
+      if (cload(&rec->t1_ok) == 2) e1 = t1_lane_margin<TK>(czf, cload(&rec->t1_dcz), hb, e1, cload(&rec->t1_b));  // wave-uniform
+      C0.y = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), e1));
       DH.x = cload(&rec->t1_dhx);
       DH.y = cload(&rec->t1_dhy);
       DC.x = cload(&rec->t1_dcz);

@@ -169,8 +169,63 @@ def make_views(n: int, W: int, H: int, seed: int = 0, layout: str = "sphere", de
     return Views(depth, K4, RT4, best)
 
 
+# ---- a second geometry: cameras INSIDE the volume, looking outward at the walls of a room -----------------------------
+ROOM_HALF = (0.92, 0.86, 0.78)  # half extents of the room (an axis-aligned box inside the grid cube [-1, 1]^3)
+
+
+def room_camera_positions(n: int, seed: int = 0) -> np.ndarray:
+    """n camera centres inside the room, up to 0.8 of the way from its centre to the walls (deterministic, view g the same
+    whoever asks): some stand a hand's breadth from a wall, whose depth then is a tenth of the far corner's."""
+    rng = np.random.default_rng([int(seed), 7])
+    p = rng.uniform(-1.0, 1.0, size=(n, 3))
+    return 0.8 * p * np.asarray(ROOM_HALF)
+
+
+def render_room_depth(K: np.ndarray, RT: np.ndarray, W: int, H: int) -> np.ndarray:
+    """Camera-z depth of the room's walls seen from inside (every ray leaves the box through one of six planes): the depth
+    range within one image reaches an order of magnitude, walls are seen at every angle down to grazing.  f32-representable
+    f64, vtk row order."""
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    px = np.arange(W, dtype=np.float64)
+    py = np.arange(H, dtype=np.float64)
+    dx = ((px - cx) / fx)[None, :]
+    dy = ((py - cy) / fy)[:, None]
+    R = RT[:3, :3]
+    c = -R.T @ RT[:3, 3]                       # camera centre in the world
+    # ray direction in the world per unit of camera z: R^T (dx, dy, 1)
+    d = (R.T[:, 0][:, None, None] * dx[None] + R.T[:, 1][:, None, None] * dy[None] + R.T[:, 2][:, None, None])
+    half = np.asarray(ROOM_HALF)[:, None, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_hi = (half - c[:, None, None]) / d
+        t_lo = (-half - c[:, None, None]) / d
+    t_exit = np.where(d > 0, t_hi, np.where(d < 0, t_lo, np.inf))
+    t = t_exit.min(axis=0)                     # camera-space z of the wall along this pixel's ray
+    img = t.astype(np.float32).astype(np.float64)
+    return img[::-1].copy()
+
+
+def make_room_views(n: int, W: int, H: int, seed: int = 0, view_range: tuple | None = None, focal_scale: float = 0.6) -> "Views":
+    """n cameras inside the room looking outward in directions spread over the sphere (a wider lens than the sphere scene's:
+    f = 0.6 W)."""
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = focal_scale * W
+    K[0, 2] = W / 2.0
+    K[1, 2] = H / 2.0
+    pos = room_camera_positions(n, seed)
+    dirs = camera_positions(n, radius=1.0)     # Fibonacci directions
+    lo, hi = (0, n) if view_range is None else (int(view_range[0]), int(view_range[1]))
+    depth = np.empty((hi - lo, H, W))
+    K4 = np.empty((hi - lo, 4, 4))
+    RT4 = np.empty((hi - lo, 4, 4))
+    for m in range(lo, hi):
+        RT4[m - lo] = look_at_rt(pos[m], target=pos[m] + dirs[m])
+        K4[m - lo] = K
+        depth[m - lo] = render_room_depth(K[:3, :3], RT4[m - lo], W, H)
+    return Views(depth, K4, RT4)
+
+
 # ---- scenes as a stereo pipeline hands them over: invalid speckle, noise, holes --------------------------------------
-SCENE_KINDS = ("dense", "sparse", "speckle", "noisy")
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room")
 SPECKLE_THRESHOLD = 0.9  # best cost ~ U[0, 1): "threshold chosen to kill ~10 % of pixels" (SURVEY.md 8d)
 
 
@@ -190,10 +245,20 @@ def make_scene_views(kind: str, n: int, W: int, H: int, seed: int = 0, view_rang
                random, into the -1 sentinel -- SURVEY.md 8d's scene, what the filter sees on real stereo output
       noisy    speckle + depth noise (every depth += N(0, noise_sigma), in scene units: the bench passes one voxel's
                spacing) + `holes` discs of 8-40 pixels radius without depth per view
+      room     a second geometry: cameras INSIDE the grid looking outward at the walls of a room (make_room_views) + the speckle
     Depths stay f32-representable (the device keeps them as f32 without changing a bit); best cost is f64 as the
     reference's array is.  Views lo .. hi-1 of the n-camera scene when view_range is given."""
     if kind not in SCENE_KINDS:
         raise ValueError(f"scene kind {kind!r}: one of {SCENE_KINDS}")
+    if kind == "room":
+        # room: cameras inside the grid looking outward at the walls of a box (depths over an order of magnitude, grazing
+        # walls, voxels behind every camera) + the same 10 % speckle as `speckle`
+        base = make_room_views(n, W, H, seed=seed, view_range=view_range)
+        lo, hi = (0, n) if view_range is None else (int(view_range[0]), int(view_range[1]))
+        best = np.empty((hi - lo, H, W), dtype=np.float64)
+        for m in range(lo, hi):
+            best[m - lo] = view_rng(seed, m, 1).random((H, W), dtype=np.float32)
+        return Views(base.depth, base.K4, base.RT4, best), 1.0 - float(speckle)
     base = make_views(n, W, H, seed=seed, layout=layout, dense=(kind != "sparse"), view_range=view_range)
     if kind in ("dense", "sparse"):
         return base, None

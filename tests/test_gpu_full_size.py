@@ -121,6 +121,41 @@ def test_cfg3_speckled_depth_tables(kind):
     assert np.abs(want).max() > 1.0
 
 
+def test_cfg3_room_scene():
+    """A second geometry at BASELINE configs[2]'s size: the cameras stand INSIDE the grid and look outward at the walls of a room
+    (scene.make_room_views) -- voxels behind every camera (cu:177), walls at grazing angles, depths over an order of magnitude,
+    footprints of a brick from a few pixels to hundreds -- with the same 10 % speckle.  tiled == tiled without classes ==
+    general over the whole grid, 4096 oracle voxels; the classes that this geometry is about really occur."""
+    from bench import upload_scene
+    grid = scene.default_grid(512)
+    rp = scene.default_ray_potential(grid)
+    out = {}
+    views = None
+    for name, variant in (("tiled", 0), ("tiled_no_classes", capi.VARIANT_NO_BRICK_CLASSES), ("general", G)):
+        with capi.FusionContext(grid, rp, grid_dtype="f32", kernel_variant=variant) as ctx:
+            v = upload_scene(ctx, scene, "room", 256, 1280, 720, float(max(grid.spacing)), keep_host=(views is None))
+            views = views or v
+            assert ctx.info().tiled_kernel == (1 if name.startswith("tiled") else 0)
+            ctx.fuse()
+            out[name] = ctx.download_grid(np.float32)
+            if name == "tiled":
+                reasons = ctx.mixed_reason_histogram()
+                hist = ctx.brick_class_histogram()
+    assert np.array_equal(out["tiled"].view(np.uint32), out["general"].view(np.uint32))
+    assert np.array_equal(out["tiled"].view(np.uint32), out["tiled_no_classes"].view(np.uint32))
+    pairs = sum(hist.values())
+    assert pairs in (64 * 64 * 32 * 256, 64 * 64 * 64 * 256)
+    # every camera has bricks behind it and bricks its image plane cuts; most of the room is free space seen through holes
+    assert hist["skip"] > 0.3 * pairs and reasons["camera_plane"] > 0 and reasons["free_or_no_depth"] > 0, (hist, reasons)
+    frac = float((views.depth == -1.0).mean())
+    assert 0.09 < frac < 0.13, frac
+    ids = _sample_ids(grid, 4096, 8)
+    want, _ = oracle.fuse_voxels(oracle_params_from_scene(grid, rp, views), views.depth.astype(np.float64), views.K4,
+                                 views.RT4, ids, n_threads=oracle.max_threads())
+    assert np.array_equal(out["tiled"].reshape(-1)[ids], want.astype(np.float32))
+    assert np.abs(want).max() > 1.0
+
+
 def test_wide_depth_maps_leave_tier_one():
     """Depth maps so large that W * py + px is no longer exact in fp32 ((H + 2) * W >= 2^24): the tiled kernel's packed-fp32
     pixel selection (tier 1) declines the view on the host and every pixel comes from the fp64 tier; also a view whose
