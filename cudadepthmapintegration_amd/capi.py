@@ -31,6 +31,8 @@ VARIANT_PERSISTENT_ALWAYS = 32768  # tiled kernel: persistent one-wave workgroup
 VARIANT_PERSISTENT_NEVER = 65536  # tiled kernel: one workgroup per brick whatever the number of views
 VARIANT_NO_WINDOWS = 262144  # tiled kernel: the FREE column always gathers from the validity maps (no bit windows)
 VARIANT_WINDOWS_ALWAYS = 524288  # tiled kernel: bit windows whatever the depth maps look like (default: maps with scattered holes)
+VARIANT_COST_ORDER = 1048576  # tiled kernel: bricks ordered by their number of mixed views whatever the grid's size (default: up to 2^16 bricks)
+VARIANT_NO_COST_ORDER = 2097152  # tiled kernel: never (four work levels, an eighth of each per XCD)
 VARIANT_BRICK_CLASSES_ALWAYS = 131072  # tiled kernel: brick classes for tiny grids too (default: none up to 1024 bricks per launch)
 VARIANT_FIXED_TILE_SHAPE = 4096  # tile-shape bits 0 mean shape 0 (tk16_w5) whatever the grid size; without it grids
                                  # below 512^3 pick tk8_w7 on their own

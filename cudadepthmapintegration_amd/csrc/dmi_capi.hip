@@ -1334,6 +1334,17 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
         // (launch_order_bricks): chunk 0's four entries are where the levels start
         t.order_levels = reinterpret_cast<const int32_t *>(ctx->d_order_level + (n_slots + 15) / 16 * 16);
         t.xcd_run_wg = 32 * (4 / (sh.wx * sh.wy));  // 32 workgroups of four waves, 128 of one (profiles: 7.73 vs 7.78 ms)
+        // Small grids (one-wave workgroups): the bricks ordered by their NUMBER of mixed views and dealt to the XCDs in short runs.
+        // With a few bricks per wave the launch ends when its longest bricks do -- a brick's views are serial, ~3 us each however
+        // empty the chip -- and four levels let a 30-view brick start halfway through (256^3 x 64 views: the last 0.1 of 0.35 ms
+        // with under a third of the waves at work, profiles/r16b_wg_cfg2_*).  Large grids keep the four levels, an eighth of each
+        // per XCD: their tail is short against the launch, and the XCDs' compact regions save L2 traffic.
+        const bool cost_order = sh.wx * sh.wy == 1 && !(cfg.variant & dmi::VAR_NO_COST_ORDER) &&
+                                ((cfg.variant & dmi::VAR_COST_ORDER) || n_slots <= (size_t)dmi::kCostOrderMaxSlots);
+        if (cost_order) {
+          t.flags |= dmi::TILE_FLAG_COST_ORDER | dmi::TILE_FLAG_XCD_RUNS;
+          t.xcd_run_wg = 16;
+        }
       }
     }
     // +0.0 adds are no-ops unless a sum can be -0.0 (only an uploaded grid can bring one) or hits are counted

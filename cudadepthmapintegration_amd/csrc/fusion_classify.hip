@@ -487,6 +487,8 @@ __device__ __forceinline__ uint8_t classify_box(const TileArgs &a, const MapRec 
   return class_from_bounds(a, pyramid_query<kQueryTiles>(mr->pyramid, P, fp.x0, fp.x1, fp.y0, fp.y1), fp.czmin, fp.czmax);
 }
 
+constexpr int kCostLevels = 64;  // levels of the cost order (small grids): bricks by their share of mixed views
+
 // Coarse pass: one thread per (box of 32 x 32 x 32 voxels = 4 x 4 x 32/tk wave bricks, view).  Most of the volume is far
 // from every surface a view saw: there the whole box is proven at once and its bricks inherit the class; the bricks of
 // unproven boxes are left to the fine pass.  threadIdx.x runs over 64 consecutive views, so the box's own table row
@@ -495,6 +497,13 @@ template <bool ROT, bool GK>
 __global__ __launch_bounds__(256) void classify_coarse_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                               const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
                                                               uint8_t *__restrict__ coarse) {
+  // the tables the fusion kernel reads beside the classes (r22 * wz(k) per view, the sums of n free-space constants, the brick
+  // counters): this is the first launch of a fusion with classes
+  fill_launch_tables(a, maps, ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.y * 64 + threadIdx.x,
+                     (int64_t)gridDim.x * gridDim.y * 256);
+  // ... and the counters of the cost order (brick_work_kernel_1x1, order_cost_kernel): 64 level sizes, 64 cursors
+  if ((a.flags & TILE_FLAG_COST_ORDER) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0)
+    for (int q = threadIdx.x; q < 2 * kCostLevels; q += 64) const_cast<int32_t *>(a.order_levels)[q] = 0;
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
   const int per_z = 32 / tk;  // wave-brick layers per box; slab starts are multiples of 32 cells
@@ -555,7 +564,7 @@ constexpr int kWindow = 16;  // tiles per axis of the staged window
 template <int kQueryTiles, int kChildren, bool ROT, bool GK>
 __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const MapRec *__restrict__ maps,
                                                        const PyramidDesc P, int tk, uint8_t *__restrict__ classes,
-                                                       const uint8_t *__restrict__ coarse) {
+                                                       const uint8_t *__restrict__ coarse, int group_views) {
   constexpr int children = kChildren;
   constexpr int views_per_wave = 64 / children;  // 1 or 2
   constexpr int per_z = children / 16;           // wave-brick layers per box = 32 / tk
@@ -568,10 +577,12 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
   const int cbx = local % cx_n;
   const int ct = local / cx_n;
   const int cby = ct % cy_n, cbz = ct / cy_n + bz_first / per_z;
-  // the views of this workgroup that the coarse pass left to it: bit v = view chunk0 + v
-  const int chunk0 = blockIdx.y * 64;
+  // the views of this workgroup that the coarse pass left to it: bit v = view chunk0 + v.  group_views (8, 16, 32 or 64)
+  // views per workgroup: 64 on large grids; fewer where the boxes alone would not fill the chip (launch_classify_bricks)
+  const int chunk0 = blockIdx.y * group_views;
   const uint8_t *__restrict__ crow = coarse + (int64_t)((cbz * cy_n + cby) * cx_n + cbx) * a.class_pitch + a.first_map + chunk0;
-  const unsigned long long unproven = __builtin_amdgcn_ballot_w64(chunk0 + lane < a.n_maps && (crow[lane] & (3 | COARSE_CHILDREN_WRITTEN)) == BRICK_MIXED);
+  const unsigned long long unproven = __builtin_amdgcn_ballot_w64(
+      lane < group_views && chunk0 + lane < a.n_maps && (crow[lane] & (3 | COARSE_CHILDREN_WRITTEN)) == BRICK_MIXED);
   if (unproven == 0) return;
   // a wave's work items are runs of views_per_wave views; wave w takes the items w, w + 4, w + 8 ...
   unsigned long long items = views_per_wave == 1 ? unproven & (0x1111111111111111ull << wave)
@@ -678,10 +689,11 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
 // column.  A wave is 64 consecutive bricks and walks over kOriginViews views, four class bytes per load; the view is
 // wave-uniform, so its camera record arrives through scalar loads (as in the fine pass), and the lanes that have the class are
 // neighbours in space: all of them or none, mostly.
-constexpr int kOriginViews = 32;  // views per workgroup (a multiple of 4)
+constexpr int kOriginViews = 32;  // views per workgroup (a multiple of 4) on large grids; fewer on small ones (launch_window_origins)
 template <bool ROT>
 __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, const MapRec *__restrict__ maps, int tk,
-                                                            uint8_t *__restrict__ classes, uint32_t *__restrict__ origins) {
+                                                            uint8_t *__restrict__ classes, uint32_t *__restrict__ origins,
+                                                            int group_views) {
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
@@ -696,8 +708,8 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
   const bool eligible = exists && bz * tk + tk <= a.nz;
   // views [m_lo, m_hi) of this workgroup, in groups of four that start at multiples of 4 (the rows are 64-byte aligned)
   const int m_begin = a.first_map, m_end = a.first_map + a.n_maps;
-  const int g_lo = (m_begin & ~3) + blockIdx.y * kOriginViews;
-  for (int m4 = g_lo; m4 < g_lo + kOriginViews && m4 < m_end; m4 += 4) {  // wave-uniform
+  const int g_lo = (m_begin & ~3) + blockIdx.y * group_views;
+  for (int m4 = g_lo; m4 < g_lo + group_views && m4 < m_end; m4 += 4) {  // wave-uniform
     uint32_t c4 = eligible ? *reinterpret_cast<const uint32_t *>(classes + row + m4) : 0u;
     const uint32_t before = c4;
 #pragma unroll
@@ -854,6 +866,84 @@ __global__ __launch_bounds__(kOrderChunk) void order_scatter_kernel(const TileAr
   }
 }
 
+// The three launches above in one, for slabs of up to kOrderOneLaunchSlots slots: every workgroup counts the levels of ALL slots
+// itself (the level bytes of 2^18 slots are 256 KB in L2; sixteen of them per 16-byte load) -- those before its chunk give its
+// bases, all of them the levels' starts -- and then ranks and scatters its own chunk as order_scatter_kernel does.  Two launches
+// fewer per fusion (each ~5 us start to end on this chip: a quarter of the preparation at 256^3 x 64 views).
+constexpr int kOrderOneLaunchSlots = 1 << 18;
+__global__ __launch_bounds__(kOrderChunk) void order_rank_kernel(const TileArgs a, const uint8_t *__restrict__ level, int n_slots,
+                                                                 int *__restrict__ level_starts, int *__restrict__ order,
+                                                                 int *__restrict__ n_valid) {
+  __shared__ int partial[16][2 * kWorkLevels];
+  __shared__ unsigned long long wave_totals[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int cnt[2 * kWorkLevels];  // [0, 4): slots of level l before this chunk; [4, 8): in the whole slab
+#pragma unroll
+  for (int q = 0; q < 2 * kWorkLevels; ++q) cnt[q] = 0;
+  const int pieces = n_slots >> 4;  // n_slots is a multiple of 32 (whole super-bricks)
+  const int my_first = blockIdx.x * (kOrderChunk / 16);
+  for (int p = threadIdx.x; p < pieces; p += kOrderChunk) {
+    const uint4 w = reinterpret_cast<const uint4 *>(level)[p];
+    const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+    int n[kWorkLevels] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t c = words[q];
+      const uint32_t ok = (~c >> 7) & 0x01010101u;  // a level below 4 (padding slots carry 255)
+      const uint32_t b0 = c & ok, b1 = (c >> 1) & ok;
+      const int n3 = __builtin_popcount(b0 & b1), n2 = __builtin_popcount(b1 & ~b0), n1 = __builtin_popcount(b0 & ~b1);
+      n[3] += n3, n[2] += n2, n[1] += n1, n[0] += __builtin_popcount(ok) - n1 - n2 - n3;
+    }
+    const bool before = p < my_first;
+#pragma unroll
+    for (int l = 0; l < kWorkLevels; ++l) {
+      cnt[kWorkLevels + l] += n[l];
+      cnt[l] += before ? n[l] : 0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2 * kWorkLevels; ++q) {
+    int v = cnt[q];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) partial[wave][q] = v;
+  }
+  // this chunk: rank of every slot among the chunk's slots of its level (four 16-bit counters in one word)
+  const int s = blockIdx.x * kOrderChunk + threadIdx.x;
+  const int l = s < n_slots ? level[s] : 255;
+  const unsigned long long one = l < kWorkLevels ? 1ull << (16 * l) : 0ull;
+  unsigned long long incl = one;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_totals[wave] = incl;
+  __syncthreads();
+  int tot[2 * kWorkLevels];
+#pragma unroll
+  for (int q = 0; q < 2 * kWorkLevels; ++q) {
+    tot[q] = 0;
+    for (int w = 0; w < 16; ++w) tot[q] += partial[w][q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // what the fusion kernel reads (TileArgs::order_levels, n_order)
+    level_starts[0] = 0;
+    level_starts[1] = tot[4];
+    level_starts[2] = tot[4] + tot[5];
+    level_starts[3] = tot[4] + tot[5] + tot[6];
+    *n_valid = tot[4] + tot[5] + tot[6] + tot[7];
+  }
+  unsigned long long before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_totals[w];
+  if (l < kWorkLevels) {
+    const int rank = (int)(((before + incl - one) >> (16 * l)) & 0xffffull);
+    int base = 0;  // level-major: all slots of the lighter-numbered (heavier) levels, then this level's slots of earlier chunks
+#pragma unroll
+    for (int q = 0; q < kWorkLevels; ++q) base += q < l ? tot[kWorkLevels + q] : (q == l ? tot[q] : 0);
+    int bx = 0, by = 0, bz = 0;
+    slot_to_brick(a, s + a.slot_base, bx, by, bz);
+    order[base + rank] = pack_brick(bx, by, bz);
+  }
+}
+
 // The same for one-wave workgroups (slot = wave brick), four slots per wave: 16 lanes read a slot's class row 16 bytes
 // per lane (256 views per pass), so a wave issues one load where the kernel above issues four per slot.
 __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, int n_slots, uint8_t *__restrict__ level) {
@@ -882,8 +972,63 @@ __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, i
     }
   }
   for (int off = 8; off > 0; off >>= 1) mixed += __shfl_xor(mixed, off, 64);
+  if (a.flags & TILE_FLAG_COST_ORDER) {
+    // cost order: level 0 = every view mixed ... 62 = one view in 63 or fewer, 63 = none; the levels' sizes are counted here,
+    // one atomic per level present in the wave's four slots
+    const int lv = !in_grid ? 255 : (mixed == 0 ? kCostLevels - 1 : (kCostLevels - 1) - (mixed * (kCostLevels - 1) + a.n_maps - 1) / a.n_maps);
+    if (exists && part == 0) level[slot] = (uint8_t)lv;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(exists && part == 0 && lv < kCostLevels);
+    while (todo) {  // wave-uniform
+      const int l0 = __shfl(lv, __builtin_ctzll(todo), 64);
+      const unsigned long long same = __builtin_amdgcn_ballot_w64(lv == l0) & todo;
+      if (lane == __builtin_ctzll(todo)) atomicAdd(const_cast<int32_t *>(a.order_levels) + l0, __builtin_popcountll(same));
+      todo &= ~same;
+    }
+    return;
+  }
   if (exists && part == 0)
     level[slot] = !in_grid ? 255 : (mixed * 2 >= a.n_maps ? 0 : (mixed * 8 >= a.n_maps ? 1 : (mixed > 0 ? 2 : 3)));
+}
+
+// Cost order, second launch: the levels' starts (a scan of the 64 sizes, by every workgroup for itself), then every slot takes
+// the next position of its level -- one atomic per level present in a wave, the wave's slots of that level side by side, in
+// slot order.  Waves arrive in any order: the order inside a level differs from run to run, the fused grid does not (every
+// brick is fused by one wave, whichever).
+__global__ __launch_bounds__(kOrderChunk) void order_cost_kernel(const TileArgs a, const uint8_t *__restrict__ level, int n_slots,
+                                                                 int *__restrict__ order, int *__restrict__ n_valid) {
+  __shared__ int base[kCostLevels];
+  int32_t *sizes = const_cast<int32_t *>(a.order_levels), *cursors = sizes + kCostLevels;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    const int v = sizes[lane];
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    base[lane] = incl - v;
+    if (blockIdx.x == 0 && lane == 63) *n_valid = incl;
+  }
+  __syncthreads();
+  const int s = blockIdx.x * kOrderChunk + threadIdx.x;
+  const int lv = s < n_slots ? level[s] : 255;
+  int pos = -1;
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(lv < kCostLevels);
+  while (todo) {  // wave-uniform
+    const int leader = __builtin_ctzll(todo);
+    const int l0 = __shfl(lv, leader, 64);
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(lv == l0) & todo;
+    int first = 0;
+    if (lane == leader) first = atomicAdd(cursors + l0, __builtin_popcountll(same));
+    first = __shfl(first, leader, 64);
+    if (lv == l0) pos = base[l0] + first + __builtin_popcountll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (pos >= 0) {
+    int bx = 0, by = 0, bz = 0;
+    slot_to_brick(a, s + a.slot_base, bx, by, bz);
+    order[pos] = pack_brick(bx, by, bz);
+  }
 }
 
 inline unsigned blocks_of(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -949,12 +1094,17 @@ hipError_t launch_window_origins(const TileArgs &a, const MapRec *maps_dev, int 
   const int bz_count = std::min(2 * a.super_z, a.bricks_z - 2 * a.sbz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
   if (n_bricks <= 0) return hipSuccess;
-  const int groups = (a.first_map + a.n_maps - (a.first_map & ~3) + kOriginViews - 1) / kOriginViews;
-  const dim3 grid((unsigned)((n_bricks + 255) / 256), (unsigned)groups);
+  // (a wave walks over its workgroup's views one after the other: on a small grid fewer views per workgroup, so that the chip
+  // has eight workgroups per CU -- at 256^3 x 64 views 128 workgroups took 44 us)
+  const int64_t brick_groups = (n_bricks + 255) / 256;
+  const int span = a.first_map + a.n_maps - (a.first_map & ~3);
+  int group_views = kOriginViews;
+  while (group_views > 4 && brick_groups * ((span + group_views - 1) / group_views) < 2048) group_views >>= 1;
+  const dim3 grid((unsigned)brick_groups, (unsigned)((span + group_views - 1) / group_views));
   if (a.rotated)
-    hipLaunchKernelGGL((window_origin_kernel<true>), grid, dim3(256), 0, stream, a, maps_dev, tk, classes, a.win_origin);
+    hipLaunchKernelGGL((window_origin_kernel<true>), grid, dim3(256), 0, stream, a, maps_dev, tk, classes, a.win_origin, group_views);
   else
-    hipLaunchKernelGGL((window_origin_kernel<false>), grid, dim3(256), 0, stream, a, maps_dev, tk, classes, a.win_origin);
+    hipLaunchKernelGGL((window_origin_kernel<false>), grid, dim3(256), 0, stream, a, maps_dev, tk, classes, a.win_origin, group_views);
   return hipGetLastError();
 }
 
@@ -980,7 +1130,12 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
 #undef DMI_LAUNCH_COARSE
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const dim3 fine_grid((unsigned)n_boxes, (unsigned)((a.n_maps + 63) / 64));
+  // views per workgroup of the fine pass: 64, or fewer while that leaves the chip (256 CUs) under eight workgroups per CU --
+  // at 256^3 x 64 views 512 workgroups walked up to 16 views per wave one after the other (62 us; with 16 views per
+  // workgroup: profiles/r16*)
+  int group_views = 64;
+  while (group_views > 8 && n_boxes * ((a.n_maps + group_views - 1) / group_views) < 2048) group_views >>= 1;
+  const dim3 fine_grid((unsigned)n_boxes, (unsigned)((a.n_maps + group_views - 1) / group_views));
   // tiles per axis the fine pass may read for its depth bounds: 2 -> 3 -> 5 took the mixed pairs of cfg 3 from 10.1 M to
   // 8.4 M to 7.6 M and the fusion from 10.8 to 10.0 to 9.8 ms; more gains nothing at 8-pixel tiles, and 4-pixel tiles
   // cost more in this pass than they save in the next (profiles/r01zm_*)
@@ -990,7 +1145,7 @@ hipError_t launch_classify_bricks(const TileArgs &a, const MapRec *maps_dev, con
 #endif
   const bool wide = tk == 8;  // 64 bricks per box
 #define DMI_LAUNCH_FINE_G(Q, C, R, G) \
-  hipLaunchKernelGGL((classify_kernel<Q, C, R, G>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse)
+  hipLaunchKernelGGL((classify_kernel<Q, C, R, G>), fine_grid, dim3(256), 0, stream, a, maps_dev, P, tk, classes, coarse, group_views)
 #define DMI_LAUNCH_FINE_R(Q, C, R)      \
   do {                                  \
     if (general_k)                      \
@@ -1042,6 +1197,14 @@ hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level
   // per-chunk counts live behind the levels in the same scratch buffer (order_scratch_bytes)
   int *counts = reinterpret_cast<int *>(level + ((size_t)n_slots + 15) / 16 * 16);
   const int n_chunks = (n_slots + kOrderChunk - 1) / kOrderChunk;
+  if ((a.flags & TILE_FLAG_COST_ORDER) && wx == 1 && wy == 1) {
+    hipLaunchKernelGGL(order_cost_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, a, level, n_slots, order, n_valid);
+    return hipGetLastError();
+  }
+  if (n_slots <= kOrderOneLaunchSlots) {
+    hipLaunchKernelGGL(order_rank_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, a, level, n_slots, counts, order, n_valid);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, level, n_slots, counts);
   hipLaunchKernelGGL(order_base_kernel, dim3(1), dim3(1024), 0, stream, counts, n_chunks, n_valid);
   hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)n_chunks), dim3(kOrderChunk), 0, stream, a, level, n_slots, counts, order);
@@ -1049,7 +1212,8 @@ hipError_t launch_order_bricks(const TileArgs &a, int wx, int wy, uint8_t *level
 }
 
 size_t order_scratch_bytes(size_t n_slots) {
-  return (n_slots + 15) / 16 * 16 + ((n_slots + kOrderChunk - 1) / kOrderChunk) * kWorkLevels * sizeof(int) + 64;
+  // (level bytes, then per-chunk counts of the four-level order or the 64 sizes and 64 cursors of the cost order)
+  return (n_slots + 15) / 16 * 16 + std::max<size_t>(((n_slots + kOrderChunk - 1) / kOrderChunk) * kWorkLevels, 2 * kCostLevels) * sizeof(int) + 64;
 }
 
 }  // namespace dmi

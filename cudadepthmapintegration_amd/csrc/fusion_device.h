@@ -80,5 +80,51 @@ __device__ __forceinline__ int pixel_fast(double hx, double hy, double hz, int W
   return 1;
 }
 
+// ---- the per-launch tables of the tiled kernel (fusion_tile.hip), filled by whichever preparation kernel runs first --------
+// TileArgs::free_sums: the running sum of n free-space constants (cu:115, cu:211), n = 0 .. n_maps, added one at a time exactly
+// as a voxel's sum receives them (one thread; the chain of n_maps dependent adds is a few microseconds), and the fusion kernel's
+// brick counters, one per XCD (16 ints apart).
+__device__ __forceinline__ void fill_free_sums(const TileArgs &a) {
+  if (a.queue_heads)
+    for (int x = 0; x < 8; ++x) a.queue_heads[16 * x] = 0;
+  if (!a.free_sums) return;
+  double *out = const_cast<double *>(a.free_sums);
+  double sum = 0.0;
+  out[0] = sum;
+  for (int n = 1; n <= a.n_maps; ++n) {
+    sum += a.free_space;
+    out[n] = sum;
+  }
+}
+
+// TileArgs::cz_table.  Axis-aligned grid: r22[m] * wz(k), the one product of c.z that depends on (map, k) only -- an exact fp64
+// multiply (cu:92, cu:168), one row of kpad entries per view; rows above the grid hold -inf, which makes c.z = -inf there: behind
+// the camera.  Rotated grid: table[k][0..2] = (g02, g12, g22) * gz(k), the k-dependent products of cu:168.  `tid` of `nthreads`
+// threads of the calling kernel share the entries out; thread 0 also fills free_sums.
+__device__ __forceinline__ void fill_launch_tables(const TileArgs &a, const MapRec *__restrict__ maps, int64_t tid, int64_t nthreads) {
+  if (tid == 0) fill_free_sums(a);
+  double *__restrict__ table = const_cast<double *>(a.cz_table);
+  if (a.rotated) {
+    for (int64_t k = tid; k < a.kpad; k += nthreads) {
+      const double gz = a.oz + (((int)k + a.kz0) + 0.5) * a.sz;  // cu:82
+      table[4 * k + 0] = a.g[2] * gz;
+      table[4 * k + 1] = a.g[6] * gz;
+      table[4 * k + 2] = a.g[10] * gz;
+      table[4 * k + 3] = 0.0;
+    }
+    return;
+  }
+  const double gx = a.ox + (0 + 0.5) * a.sx;
+  const double gy = a.oy + (0 + 0.5) * a.sy;
+  const int64_t entries = (int64_t)a.n_maps * a.kpad;
+  for (int64_t e = tid; e < entries; e += nthreads) {
+    const int k = (int)(e % a.kpad);
+    const int m = a.first_map + (int)(e / a.kpad);
+    const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
+    const double wz = row4(a.g + 8, gx, gy, gz);  // cu:168 row 2; depends on k only (diagonal 3x3)
+    table[(int64_t)m * a.kpad + k] = k < a.nz ? maps[m].rt[10] * wz : -__builtin_inf();
+  }
+}
+
 }  // namespace
 }  // namespace dmi

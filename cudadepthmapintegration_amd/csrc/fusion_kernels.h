@@ -234,7 +234,8 @@ static_assert(offsetof(TileArgs, nx) == 0 && offsetof(TileArgs, nz) == 8 && offs
               "TileArgs head layout");
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
-  TILE_FLAG_XCD_RUNS = 2      // tuning / tests: deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping)
+  TILE_FLAG_XCD_RUNS = 2,     // deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping; with TILE_FLAG_COST_ORDER)
+  TILE_FLAG_COST_ORDER = 4    // the bricks are ordered by their number of mixed views (64 levels; small grids: launch_order_bricks)
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight
@@ -293,7 +294,9 @@ enum VariantBits : int {
   VAR_PERSISTENT_NEVER = 65536,   // tiled kernel, one-wave workgroups: one workgroup per brick whatever the number of views
   VAR_BRICK_CLASSES_ALWAYS = 131072,  // tiled kernel: classify and order the bricks of tiny grids too (default: not below 1025 bricks)
   VAR_NO_WINDOWS = 262144,           // tiled kernel: the FREE column always gathers from the validity maps (no bit windows)
-  VAR_WINDOWS_ALWAYS = 524288        // tiled kernel: bit windows whatever the depth maps look like (default: maps with scattered holes)
+  VAR_WINDOWS_ALWAYS = 524288,       // tiled kernel: bit windows whatever the depth maps look like (default: maps with scattered holes)
+  VAR_COST_ORDER = 1048576,          // tiled kernel, one-wave workgroups: bricks ordered by their number of mixed views whatever the grid's size
+  VAR_NO_COST_ORDER = 2097152        // ... never (four levels, an eighth of each per XCD, as on large grids)
 };
 
 constexpr int kMaxColumnHeight = 16;  // the tallest column of any tile shape: what z-slab partitions must be multiples of
@@ -341,6 +344,10 @@ hipError_t launch_classify_bricks(const TileArgs &args, const MapRec *maps_dev, 
 int64_t coarse_class_bytes(const TileArgs &args, int tk);
 // order[p] = slot (super_brick * 32 + brick) of the p-th workgroup, bricks with the most BRICK_MIXED pairs first;
 // level: scratch of super_x*super_y*super_z*32 bytes; wx, wy: waves per workgroup
+// slabs of up to this many bricks are fused in cost order (dmi_capi.hip).  0: by kernel_variant only -- measured at 128^3 .. 512^3
+// (profiles/r16f_form_sweep.txt) the fusion kernel gains 0-4 % from it and the two ordering launches, whose level counters are
+// atomics on 64 addresses, take 0.3 ms instead of 0.01 at 256^3
+constexpr int kCostOrderMaxSlots = 0;
 // bytes of the `level` scratch of launch_order_bricks for n_slots workgroup slots (levels + per-chunk counts)
 size_t order_scratch_bytes(size_t n_slots);
 hipError_t launch_order_bricks(const TileArgs &args, int wx, int wy, uint8_t *level, int *order, int *n_valid,

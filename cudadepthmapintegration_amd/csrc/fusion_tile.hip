@@ -20,7 +20,7 @@
 // Only c.z and depth reach the accumulated value; h.x, h.y only SELECT the pixel.  So
 //   * c.z is computed in the reference's exact arithmetic, but shared: with an axis-aligned grid
 //     c.z = ((r20*wx(i) + r21*wy(j)) + r22*wz(k)) + r23; the first sum is per lane and map (3 flops per
-//     TK voxels), r22*wz(k) is per map and k (a table filled by cz_table_kernel, read by scalar loads),
+//     TK voxels), r22*wz(k) is per map and k (a table filled by fill_launch_tables, fusion_device.h, read by scalar loads),
 //     leaving 2 adds per voxel-projection instead of 6 flops;
 //   * the pixel is chosen from hx, hy evaluated as an affine function (3 FMAs per column, then one add
 //     per voxel) and a Newton-refined reciprocal, and the choice is ACCEPTED only when the distance of
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #ifdef DMI_TUNING
   unsigned long long wg_t0 = 0;
   if (kb->wg_times) wg_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned dbg_cols = 0, dbg_redo = 0;  // views with a column of their own / voxels redone after their column
 #endif
   const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
   if ((wbx >= kb->wbricks_x) | (wby >= kb->wbricks_y)) DMI_NEXT_BRICK     // wave entirely outside the grid
@@ -535,6 +536,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // of tier 1 accepts or not (4d.3: any candidate will do).  What it does not accept is redone after the column, in fp64
     // (tier 2), then with the reference's expression.  The whole view is handled here, apart from the other columns, so that
     // nothing of it stays live across them.
+#ifdef DMI_TUNING
+    ++dbg_cols;
+#endif
     if constexpr (WIN) {
       if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
 #ifdef DMI_EXP_SKIP_WINDOW_VIEWS  // timing experiment (wrong results): what everything but the window views costs
@@ -674,6 +678,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // column and before the next view: every voxel accumulates in view order (cu:211)
 #pragma unroll 1
         while (und_kk) {  // wave-uniform
+#ifdef DMI_TUNING
+          ++dbg_redo;
+#endif
           const int kk = __builtin_ctz(und_kk);
           und_kk &= und_kk - 1;
           const bool mine = (undecided >> kk) & 1u;
@@ -1164,6 +1171,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // gets at most one add per map, so doing them after the column keeps every voxel's accumulation in map order, cu:211)
 #pragma unroll 1
     while (und_kk) {  // wave-uniform: the voxels for which some lane is undecided
+#ifdef DMI_TUNING
+      ++dbg_redo;
+#endif
       const int kk = __builtin_ctz(und_kk);
       und_kk &= und_kk - 1;
       const bool mine = (undecided >> kk) & 1u;
@@ -1205,7 +1215,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     if (uid < n_uid) {
       wt[2 * uid] = wg_t0;
       wt[2 * uid + 1] = __builtin_amdgcn_s_memrealtime();
-      wt[2 * n_uid + uid] = (xcc & 15u) | ((unsigned long long)blockIdx.x << 8);
+      wt[2 * n_uid + uid] = (xcc & 15u) | ((unsigned long long)(blockIdx.x & 0xffffffu) << 8) | ((unsigned long long)(dbg_cols & 0xfffu) << 32) |
+                            ((unsigned long long)(dbg_redo & 0xfffffu) << 44);
     }
   }
 #endif
@@ -1248,46 +1259,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #undef KC
 #undef KFRESH
 
-// TileArgs::free_sums: the running sum of n free-space constants (cu:115, cu:211), n = 0 .. n_maps, added one at a time
-// exactly as a voxel's sum receives them.  One thread; the chain of n_maps dependent adds is a few microseconds.
-__device__ __forceinline__ void fill_free_sums(const TileArgs &a) {
-  if (a.queue_heads)  // the fusion kernel's brick counters, one per XCD (16 ints apart)
-    for (int x = 0; x < 8; ++x) a.queue_heads[16 * x] = 0;
-  if (!a.free_sums) return;
-  double *out = const_cast<double *>(a.free_sums);
-  double sum = 0.0;
-  out[0] = sum;
-  for (int n = 1; n <= a.n_maps; ++n) {
-    sum += a.free_space;
-    out[n] = sum;
-  }
-}
-
-// r22[m] * wz(k): the one product of c.z that depends on (map, k) only.  Exact fp64 multiply.
-__global__ __launch_bounds__(256) void cz_table_kernel(const TileArgs a, const MapRec *__restrict__ maps,
-                                                       double *__restrict__ table) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = a.first_map + blockIdx.y;
-  if (k == 0 && blockIdx.y == 0) fill_free_sums(a);
-  if (k >= a.kpad) return;
-  const double gx = a.ox + (0 + 0.5) * a.sx;
-  const double gy = a.oy + (0 + 0.5) * a.sy;
-  const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;
-  const double wz = row4(a.g + 8, gx, gy, gz);  // cu:168 row 2; depends on k only (diagonal 3x3)
-  // rows above the grid: -inf makes c.z = -inf there, which the kernel treats as behind the camera
-  table[(int64_t)m * a.kpad + k] = k < a.nz ? maps[m].rt[10] * wz : -__builtin_inf();
-}
-
-// rotated grids: table[k][0..2] = (g02, g12, g22) * gz(k), the k-dependent products of cu:168 (exact fp64 multiplies)
-__global__ __launch_bounds__(256) void wk_table_kernel(const TileArgs a, double *__restrict__ table) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0) fill_free_sums(a);
-  if (k >= a.kpad) return;
-  const double gz = a.oz + ((k + a.kz0) + 0.5) * a.sz;  // cu:82
-  table[4 * k + 0] = a.g[2] * gz;
-  table[4 * k + 1] = a.g[6] * gz;
-  table[4 * k + 2] = a.g[10] * gz;
-  table[4 * k + 3] = 0.0;
+// The per-launch tables (fusion_device.h: fill_launch_tables) for a launch WITHOUT brick classes; with classes the coarse
+// classification pass -- the first launch of the preparation -- fills them on its way (one launch fewer per fusion).
+__global__ __launch_bounds__(256) void launch_tables_kernel(const TileArgs a, const MapRec *__restrict__ maps) {
+  fill_launch_tables(a, maps, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 constexpr int kPersistentMinViews = 96;  // below: one workgroup per brick (fuse_tile_kernel, STAY)
@@ -1318,16 +1293,22 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   const auto counted = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>;
   const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, (WX * WY == 1), WIN>;
   if constexpr (WX * WY == 1) {
-    // few views per brick (and classes to make most of them cheap): one workgroup per brick, see the kernel
+    // Persistent workgroups or one workgroup per brick?  Measured per size and scene at the round-4 kernel (both forms of one
+    // library, rounds interleaved: profiles/r16f_form_sweep.txt), main kernel, per-brick / persistent:
+    //   maps without holes (most bricks light):  128^3 x 64 views 0.100 / 0.162 ms, 256^3 x 64 0.246 / 0.338, 256^3 x 128
+    //     0.470 / 0.548, 384^3 x 128 1.13 / 1.21, 512^3 x 64 1.29 / 1.31, 1024^3 x 64 6.05 / 7.95 -- and 512^3 x 96 1.91 / 1.85,
+    //     512^3 x 256 4.74 / 4.50: persistent from 96 views on, on grids of 512^3 voxels and more;
+    //   maps with holes all over them (most pairs are per-voxel work, a brick lives long): 128^3 x 64 0.193 / 0.219, 256^3 x 32
+    //     0.333 / 0.356, 256^3 x 64 a tie, 384^3 x 64 1.86 / 1.74, 512^3 x 256 14.1 / 13.7, 1024^3 x 64 25.2 / 24.8: persistent
+    //     from 48 views on, on grids of 256^3 voxels and more.
+    // (round 3's rule -- persistent from 48 views on every grid of up to 2^18 bricks -- was fitted to a kernel whose light bricks
+    // cost twice as much; it had cfg 2's dense scene at 0.34 ms where the per-brick form takes 0.25)
+    const int64_t voxels = (int64_t)a.super_x * a.super_y * a.super_z * 32 * 64 * TK;  // of this launch's slab, padding included
     const bool stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
                       : (cfg.variant & VAR_PERSISTENT_NEVER) ? false
-                      : a.n_maps >= kPersistentMinViews || (cfg.variant & VAR_NO_BRICK_CLASSES) ||
-                            // (round 3: with holes in the depth maps most pairs are per-voxel work and a brick lives long
-                            // enough from fewer views on: 256^3 x 64 views speckle 0.85 against 1.04 ms, dense 0.44 against
-                            // 0.43, profiles/r06w_exp_cfg2_forms.json; at 1024^3 the per-brick form keeps winning at 64 views)
-                            // With holes on a larger grid too: 1024^3 x 64 views speckle 27.0 against 29.7 ms -- and dense, where
-                            // most bricks are light, 8.7 against 6.9 (profiles/r08q_exp_cfg5_forms_by_scene.json).
-                            (a.n_maps >= 48 && (cfg.holes || (int64_t)a.bricks_x * a.bricks_y * a.bricks_z <= (int64_t(1) << 18)));
+                      : (cfg.variant & VAR_NO_BRICK_CLASSES) ? true
+                      : cfg.holes ? (a.n_maps >= 48 && voxels >= (int64_t(1) << 24))
+                                  : (a.n_maps >= kPersistentMinViews && voxels >= (int64_t(1) << 27));
     if (!stay) {
       if (cfg.count_hits)
         hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
@@ -1435,13 +1416,13 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
                              uint8_t *order_scratch, uint8_t *coarse_classes, hipEvent_t before_main_kernel,
                              hipStream_t stream) {
   if (a.n_maps <= 0) return hipSuccess;
-  if (a.rotated)
-    hipLaunchKernelGGL(wk_table_kernel, dim3((a.kpad + 255) / 256), dim3(256), 0, stream, a, const_cast<double *>(a.cz_table));
-  else
-    hipLaunchKernelGGL(cz_table_kernel, dim3((a.kpad + 255) / 256, a.n_maps), dim3(256), 0, stream, a, maps_dev,
-                       const_cast<double *>(a.cz_table));
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
+  if (cfg.variant & VAR_NO_BRICK_CLASSES) {
+    const int64_t entries = a.rotated ? a.kpad : (int64_t)a.kpad * a.n_maps;
+    hipLaunchKernelGGL(launch_tables_kernel, dim3((unsigned)std::min<int64_t>((entries + 255) / 256, 4096)), dim3(256), 0, stream, a, maps_dev);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   if (!(cfg.variant & VAR_NO_BRICK_CLASSES)) {
     const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0 || cfg.general_k != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, cfg.general_k, stream);

@@ -49,7 +49,9 @@ def main():
         kernel_ms = ctx.timings().last_fuse_main_kernel_ms
     t = buf[:2 * blocks].reshape(blocks, 2).astype(np.int64)
     xcc = (buf[2 * blocks:] & np.uint64(15)).astype(np.int64)
-    block = (buf[2 * blocks:] >> np.uint64(8)).astype(np.int64)   # the (persistent) workgroup that fused the brick
+    block = ((buf[2 * blocks:] >> np.uint64(8)) & np.uint64(0xffffff)).astype(np.int64)   # the (persistent) workgroup that fused the brick
+    n_cols = ((buf[2 * blocks:] >> np.uint64(32)) & np.uint64(0xfff)).astype(np.int64)    # views with a column of their own
+    n_redo = ((buf[2 * blocks:] >> np.uint64(44)) & np.uint64(0xfffff)).astype(np.int64)  # voxels redone after their column
     ran = t[:, 1] > 0
     t0 = t[ran, 0].min()
     start = (t[ran, 0] - t0) * 1e-5   # ms (100 MHz)
@@ -95,13 +97,23 @@ def main():
     # the bricks that end last: position in the order (heaviest level first), start and duration
     uid = np.nonzero(ran)[0]
     last = np.argsort(end)[-24:]
-    late = [{"order_pos": int(uid[x]), "of": int(ran.size), "start_us": round(float(start[x]) * 1e3, 1), "dur_us": round(float(dur[x]) * 1e3, 1)} for x in last]
+    cols_r, redo_r = n_cols[ran], n_redo[ran]
+    late = [{"order_pos": int(uid[x]), "of": int(ran.size), "start_us": round(float(start[x]) * 1e3, 1), "dur_us": round(float(dur[x]) * 1e3, 1),
+             "columns": int(cols_r[x]), "redone_voxels": int(redo_r[x])} for x in last]
+    # duration against the number of views with a column of their own, and the redone voxels (all bricks)
+    by_cols = []
+    for lo_c in range(0, int(cols_r.max()) + 1, 8):
+        sel = (cols_r >= lo_c) & (cols_r < lo_c + 8)
+        if sel.any():
+            by_cols.append({"columns": f"{lo_c}-{lo_c + 7}", "bricks": int(sel.sum()), "median_us": round(float(np.median(dur[sel])) * 1e3, 1),
+                            "p99_us": round(float(np.percentile(dur[sel], 99)) * 1e3, 1), "mean_redone": round(float(redo_r[sel].mean()), 2),
+                            "us_per_column": round(float(dur[sel].sum() / max(1, cols_r[sel].sum())) * 1e3, 2)})
     # duration by position in the order, twenty equal parts
     parts = np.array_split(np.arange(uid.size), 20)
     by_pos = [{"median_us": round(float(np.median(dur[q])) * 1e3, 1), "max_us": round(float(dur[q].max()) * 1e3, 1),
                "median_start_us": round(float(np.median(start[q])) * 1e3, 1)} for q in parts]
     brick_us = {f"p{q}": float(np.percentile(dur, q) * 1e3) for q in (1, 10, 25, 50, 75, 90, 99)}
-    rec = {"late_bricks": late, "by_order_position": by_pos, "between_bricks": between, "brick_us": brick_us, "workload": args.workload, "scene": args.scene, "variant": args.variant, "kernel_ms_by_events": kernel_ms,
+    rec = {"late_bricks": late, "by_columns": by_cols, "redone_voxels_total": int(redo_r.sum()), "by_order_position": by_pos, "between_bricks": between, "brick_us": brick_us, "workload": args.workload, "scene": args.scene, "variant": args.variant, "kernel_ms_by_events": kernel_ms,
            "span_ms_by_memrealtime": float(total), "bricks_fused": int(ran.sum()), "workgroups_that_fused_a_brick": int(len(set(block[ran].tolist()))), "peak_resident_workgroups": int(peak),
            "ms_below_90pct_of_peak": below90, "ms_below_50pct_of_peak": below50,
            "workgroup_ms": {"median": float(np.median(dur)), "p99": float(np.percentile(dur, 99)), "max": float(dur.max())},

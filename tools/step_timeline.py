@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""From a rocprofv3 --kernel-trace directory: the launches of the last fusion step (from the last cz_table_kernel on), each with
+"""From a rocprofv3 --kernel-trace directory: the launches of the last fusion step (from its first preparation launch on), each with
 its start relative to the step's first launch, its duration and the gap to the launch before it.  usage: step_timeline.py DIR"""
 import csv, glob, re, sys
 
@@ -8,7 +8,10 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "cz_table_kernel" in r[2]]
+# a step's first launch: the coarse classification pass (it fills the per-launch tables too), or launch_tables_kernel in a fusion
+# without brick classes (cz_table_kernel: traces of rounds 1-3)
+firsts = ("classify_coarse_kernel", "launch_tables_kernel", "cz_table_kernel", "wk_table_kernel")
+starts = [i for i, r in enumerate(rows) if any(f in r[2] for f in firsts)]
 if not starts:
     sys.exit("no fusion step in the trace")
 lo = starts[-1]
