@@ -1254,11 +1254,13 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // A launch of no more bricks than the chip has SIMDs (64^3 voxels in 8-voxel columns) fuses without classes: every brick
     // has a SIMD to itself, and the seven launches that classify and order the bricks take longer than the per-voxel work
     // they would save (64^3: 79 -> 49 us at 4 views, 278 -> 192 us at 64; from 96^3 on the classes win;
-    // profiles/r07o_small_fusions_classes_on_off.txt).
+    // profiles/r07o_small_fusions_classes_on_off.txt).  Round 4, the preparation down to four launches: 64^3 x 4 views
+    // 48 -> 40 us, x 16 73 -> 63 without classes -- and x 64 views 164 us WITH them against 201 (dense; speckle 218 / 204):
+    // the rule now ends at 48 views (profiles/r16i_small_fusions_classes_on_off.txt).
     // (decided from the WHOLE grid's bricks: a slab launch of a larger grid -- dmi_fuse_slab, the overlapped exchanges of
     // dmi_multi_fuse -- keeps its classes, as the whole-grid launches the rule was calibrated on)
     if (!(cfg.variant & (dmi::VAR_NO_BRICK_CLASSES | dmi::VAR_BRICK_CLASSES_ALWAYS)) &&
-        (int64_t)t.wbricks_x * t.wbricks_y * (int64_t)t.bricks_z <= dmi::kNoClassesMaxBricks)
+        (int64_t)t.wbricks_x * t.wbricks_y * (int64_t)t.bricks_z <= dmi::kNoClassesMaxBricks && count < dmi::kNoClassesMaxViews)
       cfg.variant |= dmi::VAR_NO_BRICK_CLASSES;
     // row pitch of the class tables: a power of two >= 64 views, so that views arriving in chunks (add, fuse, add,
     // fuse ...) change the layout -- and force a reallocation, which waits for the device -- only at doublings

@@ -26,6 +26,7 @@ struct alignas(16) DepthTile {
 enum TileFlags : uint32_t { TILE_HAS_SENTINEL = 1, TILE_HAS_VALID = 2, TILE_HAS_NAN = 4, TILE_PART_HOLE_FREE = 8, TILE_PART_NO_VALID = 16 };
 // launches of at most this many wave bricks (the chip's SIMDs) run without brick classes (dmi_capi.hip)
 constexpr int64_t kNoClassesMaxBricks = 1024;
+constexpr int kNoClassesMaxViews = 48;  // ... and only launches of fewer views than this
 // coarse class table only: the box's bricks already hold the (BRICK_MIXED) class of the byte's low bits
 constexpr uint8_t COARSE_CHILDREN_WRITTEN = 0x80;
 

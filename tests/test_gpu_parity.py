@@ -459,15 +459,17 @@ def test_brick_classes_cover_every_case_and_change_nothing():
             assert sum(hist.values()) == 0
 
 
-@pytest.mark.parametrize("dims,classes", [((64, 64, 64), False), ((64, 64, 128), False), ((72, 64, 128), True)])
-def test_tiny_launches_fuse_without_classes(dims, classes):
-    """The shipped rule (dmi_capi.hip): a launch of at most 1024 bricks -- one per SIMD -- skips the classification and ordering
-    launches and takes every (brick, view) pair per voxel; from 1025 bricks on the classes are built.  Bit for bit the oracle's
-    grid either way, and VARIANT_BRICK_CLASSES_ALWAYS (what the other tests run with) brings the classes back."""
+@pytest.mark.parametrize("dims,n_views,classes", [((64, 64, 64), 6, False), ((64, 64, 128), 6, False), ((72, 64, 128), 6, True),
+                                                  ((64, 64, 64), 47, False), ((64, 64, 64), 48, True)])
+def test_tiny_launches_fuse_without_classes(dims, n_views, classes):
+    """The shipped rule (dmi_capi.hip): a launch of at most 1024 bricks -- one per SIMD -- and fewer than 48 views skips the
+    classification and ordering launches and takes every (brick, view) pair per voxel; from 1025 bricks or 48 views on the
+    classes are built.  Bit for bit the oracle's grid either way, and VARIANT_BRICK_CLASSES_ALWAYS (what the other tests run
+    with) brings the classes back."""
     from helpers import shipped_defaults
     grid = scene.default_grid(dims)
     rp = scene.default_ray_potential(grid)
-    views = scene.make_views(6, 160, 120, seed=77, dense=True)
+    views = scene.make_views(n_views, 160, 120, seed=77, dense=True)
     views.depth[np.random.default_rng(5).random(views.depth.shape) < 0.1] = -1.0
     want, vh_w, mh_w = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4,
                                    n_threads=oracle.max_threads())
