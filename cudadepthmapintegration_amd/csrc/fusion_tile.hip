@@ -402,6 +402,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   unsigned long long wg_t0 = 0;
   if (kb->wg_times) wg_t0 = __builtin_amdgcn_s_memrealtime();
   unsigned dbg_cols = 0, dbg_redo = 0;  // views with a column of their own / voxels redone after their column
+  unsigned dbg_win = 0, dbg_win_early = 0;  // window pairs / those before the brick's first view of another column
 #endif
   const int wbx = bx * WX + (w % WX), wby = by * WY + (w / WX);    // this wave's brick (8 x 8 x TK voxels)
   if ((wbx >= kb->wbricks_x) | (wby >= kb->wbricks_y)) DMI_NEXT_BRICK     // wave entirely outside the grid
@@ -543,6 +544,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
 #ifdef DMI_EXP_SKIP_WINDOW_VIEWS  // timing experiment (wrong results): what everything but the window views costs
         continue;
+#endif
+#ifdef DMI_TUNING
+        ++dbg_win;
+        if (dbg_cols == dbg_win) ++dbg_win_early;
 #endif
         const kernarg_t kw = KFRESH();
 #ifdef DMI_EXP_SAME_REC  // timing experiment (wrong results): every view reads the first view's record
@@ -1215,8 +1220,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     if (uid < n_uid) {
       wt[2 * uid] = wg_t0;
       wt[2 * uid + 1] = __builtin_amdgcn_s_memrealtime();
-      wt[2 * n_uid + uid] = (xcc & 15u) | ((unsigned long long)(blockIdx.x & 0xffffffu) << 8) | ((unsigned long long)(dbg_cols & 0xfffu) << 32) |
-                            ((unsigned long long)(dbg_redo & 0xfffffu) << 44);
+      wt[2 * n_uid + uid] = (xcc & 15u) | ((unsigned long long)(blockIdx.x & 0xffffffu) << 8) | ((unsigned long long)(dbg_cols & 0x3ffu) << 32) |
+                            ((unsigned long long)(dbg_win & 0x3ffu) << 42) | ((unsigned long long)(dbg_win_early & 0x3ffu) << 52) |
+                            ((unsigned long long)(dbg_redo > 3 ? 3 : dbg_redo) << 62);
     }
   }
 #endif

@@ -50,8 +50,10 @@ def main():
     t = buf[:2 * blocks].reshape(blocks, 2).astype(np.int64)
     xcc = (buf[2 * blocks:] & np.uint64(15)).astype(np.int64)
     block = ((buf[2 * blocks:] >> np.uint64(8)) & np.uint64(0xffffff)).astype(np.int64)   # the (persistent) workgroup that fused the brick
-    n_cols = ((buf[2 * blocks:] >> np.uint64(32)) & np.uint64(0xfff)).astype(np.int64)    # views with a column of their own
-    n_redo = ((buf[2 * blocks:] >> np.uint64(44)) & np.uint64(0xfffff)).astype(np.int64)  # voxels redone after their column
+    n_cols = ((buf[2 * blocks:] >> np.uint64(32)) & np.uint64(0x3ff)).astype(np.int64)    # views with a column of their own
+    n_win = ((buf[2 * blocks:] >> np.uint64(42)) & np.uint64(0x3ff)).astype(np.int64)     # ... through a bit window
+    n_win_early = ((buf[2 * blocks:] >> np.uint64(52)) & np.uint64(0x3ff)).astype(np.int64)  # ... before the brick's first other column
+    n_redo = (buf[2 * blocks:] >> np.uint64(62)).astype(np.int64)  # voxels redone after their column (saturates at 3)
     ran = t[:, 1] > 0
     t0 = t[ran, 0].min()
     start = (t[ran, 0] - t0) * 1e-5   # ms (100 MHz)
@@ -113,7 +115,10 @@ def main():
     by_pos = [{"median_us": round(float(np.median(dur[q])) * 1e3, 1), "max_us": round(float(dur[q].max()) * 1e3, 1),
                "median_start_us": round(float(np.median(start[q])) * 1e3, 1)} for q in parts]
     brick_us = {f"p{q}": float(np.percentile(dur, q) * 1e3) for q in (1, 10, 25, 50, 75, 90, 99)}
-    rec = {"late_bricks": late, "by_columns": by_cols, "redone_voxels_total": int(redo_r.sum()), "by_order_position": by_pos, "between_bricks": between, "brick_us": brick_us, "workload": args.workload, "scene": args.scene, "variant": args.variant, "kernel_ms_by_events": kernel_ms,
+    win_r, early_r = n_win[ran], n_win_early[ran]
+    rec = {"late_bricks": late, "by_columns": by_cols, "redone_voxels_total_saturating": int(redo_r.sum()),
+           "columns_total": int(cols_r.sum()), "window_pairs": int(win_r.sum()), "window_pairs_before_first_other_column": int(early_r.sum()),
+           "bricks_with_only_window_columns": int(((win_r == cols_r) & (cols_r > 0)).sum()), "by_order_position": by_pos, "between_bricks": between, "brick_us": brick_us, "workload": args.workload, "scene": args.scene, "variant": args.variant, "kernel_ms_by_events": kernel_ms,
            "span_ms_by_memrealtime": float(total), "bricks_fused": int(ran.sum()), "workgroups_that_fused_a_brick": int(len(set(block[ran].tolist()))), "peak_resident_workgroups": int(peak),
            "ms_below_90pct_of_peak": below90, "ms_below_50pct_of_peak": below50,
            "workgroup_ms": {"median": float(np.median(dur)), "p99": float(np.percentile(dur, 99)), "max": float(dur.max())},
