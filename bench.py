@@ -210,10 +210,11 @@ def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int 
     return out
 
 
-def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, pcie, chunk_views: int = 32):
+def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, pcie, chunk_views: int = 32, download_slabs: int = 8):
     """PCIe-inclusive rate (never the headline value): depth tables start in pinned host memory, go up chunk by chunk on
     the context's upload stream while the previous chunk is being fused (dmi_add_views + dmi_fuse_range), and the grid
-    comes back into pinned host memory.  host f64 / grid f64 is the reference's contract (vtkDoubleArray in and out).
+    comes back into pinned host memory, slab by slab under the last chunk's fusion (dmi_fuse_range_download: what
+    FusionDriver::ProcessDepthMap calls).  host f64 / grid f64 is the reference's contract (vtkDoubleArray in and out).
     pcie_floor_s = the same bytes at the copy rates dmi_pcie_probe measured on this box, nothing else counted."""
     n = views.n
     np_host = np.float64 if host_dtype == "f64" else np.float32
@@ -231,15 +232,17 @@ def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, pcie
             for v0 in range(0, n, chunk_views):
                 v1 = min(n, v0 + chunk_views)
                 c.add_views(scene.Views(pinned[v0:v1], views.K4[v0:v1], views.RT4[v0:v1]))
-                c.fuse(v0, v1 - v0)
-            c.download_grid(np_grid, out=out)
+                if v1 < n:
+                    c.fuse(v0, v1 - v0)
+                else:  # the last chunk: fused slab by slab, every slab on its way back under the next one's fusion
+                    c.fuse_download(v0, v1 - v0, np_grid, out=out, n_slabs=download_slabs)
             times.append(time.perf_counter() - t0)
     dt = float(np.median(times[1:]))
     moved = pinned.nbytes + out.nbytes
     floor = pinned.nbytes / (pcie[0] * 1e9) + out.nbytes / (pcie[1] * 1e9)
     return {"host_depth": host_dtype, "grid": grid_dtype, "seconds": dt, "value": grid.n_voxels * n / dt / 1e9,
             "unit": "Gvoxel-projections/s including H2D of every depth table and D2H of the grid",
-            "pcie_bytes": moved, "pcie_GBps_if_alone": moved / dt / 1e9, "chunk_views": chunk_views,
+            "pcie_bytes": moved, "pcie_GBps_if_alone": moved / dt / 1e9, "chunk_views": chunk_views, "download_slabs": download_slabs,
             "pcie_floor_s": floor, "seconds_over_floor": dt / floor}
 
 

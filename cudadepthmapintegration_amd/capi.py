@@ -95,7 +95,7 @@ DMI_UNIQUE_ID_BYTES = 128
 # every symbol include/dmi.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
     "dmi_default_options", "dmi_create", "dmi_destroy", "dmi_last_error", "dmi_add_views", "dmi_add_views_f32",
-    "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_fuse_slab", "dmi_synchronize",
+    "dmi_clear_views", "dmi_reset_grid", "dmi_upload_grid", "dmi_fuse", "dmi_fuse_range", "dmi_fuse_slab", "dmi_fuse_range_download", "dmi_synchronize",
     "dmi_download_grid_f64", "dmi_download_grid_f32", "dmi_download_hits", "dmi_grid_device_pointer",
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_fp64_probe", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
@@ -157,6 +157,7 @@ def load() -> ctypes.CDLL:
     L.dmi_fuse.argtypes = [vp]
     L.dmi_fuse_range.argtypes = [vp, i32, i32]
     L.dmi_fuse_slab.argtypes = [vp, i32, i32]
+    L.dmi_fuse_range_download.argtypes = [vp, i32, i32, vp, i32, i32]
     L.dmi_synchronize.argtypes = [vp]
     L.dmi_download_grid_f64.argtypes = [vp, dp]
     L.dmi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -371,6 +372,19 @@ class FusionContext:
 
     def synchronize(self):
         self._check(self._lib.dmi_synchronize(self._h))
+
+    def fuse_download(self, first: int, count: int, dtype=np.float64, out: np.ndarray | None = None, n_slabs: int = 8) -> np.ndarray:
+        """Fuse views [first, first + count) and return the grid as [nz, ny, nx]: with `dtype` the grid's own type the grid is
+        fused in `n_slabs` z-slabs and every slab is copied to the host under the fusion of the next ones
+        (dmi_fuse_range_download); bit for bit what fuse(first, count) + download_grid(dtype) return."""
+        nx, ny, nz = (int(c) for c in self.grid.cell_dims)
+        if out is None:
+            out = np.empty(self.n_voxels, dtype=dtype)
+        if out.dtype != np.dtype(dtype) or out.size != self.n_voxels or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous array of n_voxels elements of the requested dtype")
+        self._check(self._lib.dmi_fuse_range_download(self._h, int(first), int(count), ctypes.c_void_p(out.ctypes.data),
+                                                      DMI_F64 if np.dtype(dtype) == np.float64 else DMI_F32, int(n_slabs)))
+        return out.reshape(nz, ny, nx)
 
     def download_grid(self, dtype=np.float64, out: np.ndarray | None = None) -> np.ndarray:
         """The grid as [nz, ny, nx]; `out` (flat, contiguous, e.g. from pinned_empty) receives it when given."""

@@ -59,6 +59,8 @@ struct dmi_context {
   // dmi_add_views copies, converts and builds pyramids on a stream of its own and waits for that stream only: a fuse
   // still running on `stream` overlaps the upload of the next views (FusionDriver::ProcessDepthMap pipelines on this)
   hipStream_t upload_stream = nullptr;
+  hipStream_t download_stream = nullptr;  // dmi_fuse_range_download: the slabs' copies to the host
+  std::vector<hipEvent_t> slab_events;    // ... and what each waits for
 
   void *d_grid = nullptr;
   bool own_grid = false;
@@ -912,6 +914,8 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_points) (void)hipFree(ctx->d_points);
   if (ctx->c2p_start) (void)hipEventDestroy(ctx->c2p_start);
   if (ctx->c2p_stop) (void)hipEventDestroy(ctx->c2p_stop);
+  for (hipEvent_t e : ctx->slab_events) (void)hipEventDestroy(e);
+  if (ctx->download_stream) (void)hipStreamDestroy(ctx->download_stream);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1466,6 +1470,59 @@ int dmi_download_grid_f32(dmi_context *ctx, float *out) {
     int rc_ = download_converted<float>(ctx, out);  // narrowed on the device (round to nearest, as the host cast)
     if (rc_ != DMI_OK) return rc_;
   }
+  ctx->timings.last_download_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return drain_events(ctx);
+  });
+}
+
+// The last step of a chunked reconstruction (cu:343-371: the last map's kernel, then the copy back): views [first, first +
+// count) are fused slab by slab and every slab starts its way to the host the moment its fusion ends, on a stream of its
+// own, while the next slabs are being fused.  Slabs fused one after the other give the bits of one fusion (dmi_fuse_slab).
+int dmi_fuse_range_download(dmi_context *ctx, int32_t first, int32_t count, void *out, int32_t out_dtype, int32_t n_slabs) {
+  return guarded(ctx, "dmi_fuse_range_download", [&]() -> int {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range_download: null argument");
+  if (out_dtype != DMI_F64 && out_dtype != DMI_F32) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range_download: out_dtype must be DMI_F32 or DMI_F64");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  const int32_t nz = ctx->grid.cell_dims[2];
+  const int32_t max_slabs = std::max(1, (nz + DMI_SLAB_ALIGNMENT - 1) / DMI_SLAB_ALIGNMENT);
+  n_slabs = std::min(std::max(n_slabs, 1), max_slabs);
+  if (out_dtype != ctx->opt.grid_dtype || n_slabs == 1) {
+    // another type than the grid's: converted on the device after the whole fusion (dmi_download_grid_*), nothing overlaps
+    int rc = fuse_impl(ctx, first, count, 0, nz);
+    if (rc != DMI_OK) return rc;
+    return out_dtype == DMI_F64 ? dmi_download_grid_f64(ctx, static_cast<double *>(out)) : dmi_download_grid_f32(ctx, static_cast<float *>(out));
+  }
+  { int rc_ = flush_zero_fill(ctx); if (rc_ != DMI_OK) return rc_; }
+  if (!ctx->download_stream) DMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->download_stream, hipStreamNonBlocking));
+  while ((int32_t)ctx->slab_events.size() < n_slabs) {
+    hipEvent_t e = nullptr;
+    DMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->slab_events.push_back(e);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  // slabs of whole alignment units, as equal as they come
+  const int32_t units = max_slabs, per = units / n_slabs, extra = units % n_slabs;
+  const size_t gsz = grid_elem(ctx);
+  const size_t layer = (size_t)ctx->grid.cell_dims[0] * ctx->grid.cell_dims[1];
+  int32_t z0 = 0;
+  for (int32_t i = 0; i < n_slabs; ++i) {
+    const int32_t z1 = std::min(nz, z0 + (per + (i < extra ? 1 : 0)) * DMI_SLAB_ALIGNMENT);
+    if (count > 0) {
+      int rc = fuse_impl(ctx, first, count, z0, z1 - z0);
+      if (rc != DMI_OK) {
+        (void)hipStreamSynchronize(ctx->download_stream);  // the copies already queued end before the caller sees the error
+        return rc;
+      }
+    }
+    DMI_HIP(ctx, hipEventRecord(ctx->slab_events[(size_t)i], ctx->stream));
+    DMI_HIP(ctx, hipStreamWaitEvent(ctx->download_stream, ctx->slab_events[(size_t)i], 0));
+    DMI_HIP(ctx, hipMemcpyAsync(static_cast<char *>(out) + (size_t)z0 * layer * gsz, static_cast<const char *>(ctx->d_grid) + (size_t)z0 * layer * gsz,
+                                (size_t)(z1 - z0) * layer * gsz, hipMemcpyDeviceToHost, ctx->download_stream));
+    z0 = z1;
+  }
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->download_stream));
+  DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timings.last_download_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return drain_events(ctx);

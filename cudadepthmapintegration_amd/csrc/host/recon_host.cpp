@@ -413,6 +413,8 @@ bool FusionDriver::ProcessDepthMap(size_t n_views, const ViewSource &fill, doubl
   const size_t chunk = std::max<size_t>(1, std::min(n_views, HostChunkBytes / std::max<size_t>(1, npix * 16)));
   Feed feed;
   bool ok = true;
+  int32_t last_first = (int32_t)n_views, last_count = 0;  // the chunk whose fusion is left to dmi_fuse_range_download
+  constexpr int32_t kDownloadSlabs = 8;
   for (Chunk &c : feed.slot) {
     void *pd = nullptr, *pc = nullptr;
     if (dmi_alloc_pinned(chunk * npix * 8, &pd) != DMI_OK || dmi_alloc_pinned(chunk * npix * 8, &pc) != DMI_OK) {
@@ -506,8 +508,14 @@ bool FusionDriver::ProcessDepthMap(size_t n_views, const ViewSource &fill, doubl
       rc = dmi_multi_add_views(mctx, c.depth, cost, thresholdBestCost, c.K4.data(), c.RT.data(), (int32_t)c.count, W, H);
     } else {
       rc = dmi_add_views(ctx, c.depth, cost, thresholdBestCost, c.K4.data(), c.RT.data(), (int32_t)c.count, W, H);
-      // replaces the kernel launches of these views (cu:363); runs while the next chunk is filled and copied
-      if (rc == DMI_OK) rc = dmi_fuse_range(ctx, (int32_t)c.first, (int32_t)c.count);
+      // replaces the kernel launches of these views (cu:363); runs while the next chunk is filled and copied.  The LAST chunk
+      // is fused together with the copy back, below: slab by slab, each slab on its way to the host under the next one's fusion
+      if (c.first + c.count == n_views) {
+        last_first = (int32_t)c.first;
+        last_count = (int32_t)c.count;
+      } else if (rc == DMI_OK) {
+        rc = dmi_fuse_range(ctx, (int32_t)c.first, (int32_t)c.count);
+      }
     }
     if (rc != DMI_OK) {
       Error = std::string(multi ? "dmi_multi_add_views: " : "dmi_add_views / dmi_fuse_range: ") + last_error();
@@ -542,8 +550,9 @@ bool FusionDriver::ProcessDepthMap(size_t n_views, const ViewSource &fill, doubl
     dmi_multi_timings t;
     if (dmi_multi_get_timings(mctx, &t) == DMI_OK) FuseKernelMs = t.last_step_ms;
   } else {
-    if (dmi_download_grid_f64(ctx, io_scalar) != DMI_OK) {  // cu:368-371 (synchronises)
-      Error = std::string("dmi_download_grid_f64: ") + last_error();
+    // cu:363 for the last chunk's views and cu:368-371 (synchronises)
+    if (dmi_fuse_range_download(ctx, last_first, last_count, io_scalar, DMI_F64, kDownloadSlabs) != DMI_OK) {
+      Error = std::string("dmi_fuse_range_download: ") + last_error();
       destroy();
       return false;
     }

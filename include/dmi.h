@@ -188,6 +188,14 @@ int dmi_synchronize(dmi_context *ctx);
 int dmi_download_grid_f64(dmi_context *ctx, double *out);
 int dmi_download_grid_f32(dmi_context *ctx, float *out);
 
+/* The last step of a chunked reconstruction in one call (cu:343-371: the last maps' kernels, then the copy back): fuse views
+ * [first, first + count) -- count may be 0 -- and bring the whole grid to `out` (out_dtype: DMI_F32 or DMI_F64; [n_voxels], pinned
+ * memory for DMA speed).  When out_dtype is the grid's own type the grid is fused in n_slabs z-slabs (clamped to 1 .. the number of
+ * DMI_SLAB_ALIGNMENT units of the grid) and every slab's copy starts when its fusion ends, on a stream of its own, under the
+ * fusion of the next slabs: at 512^3 the copy (9-19 ms) hides all of the fusion but its first slab.  Bit for bit what
+ * dmi_fuse_range + dmi_download_grid_* return.  Synchronises.  (Added in round 4; dmi_abi_version() stays 4.) */
+int dmi_fuse_range_download(dmi_context *ctx, int32_t first, int32_t count, void *out, int32_t out_dtype, int32_t n_slabs);
+
 /* voxel_hits [n_voxels] u32 and/or map_hits [n_views] u64 (either may be NULL).
  * Needs count_hits at creation. */
 int dmi_download_hits(dmi_context *ctx, uint32_t *voxel_hits, uint64_t *map_hits);

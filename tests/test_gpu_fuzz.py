@@ -87,7 +87,7 @@ def test_random_scenes_bit_exact(seed):
                                        init_grid=init, n_threads=oracle.max_threads())
     for variant in (0, capi.VARIANT_FIXED_TILE_SHAPE, capi.VARIANT_NO_BRICK_CLASSES, 96, capi.VARIANT_FORCE_GENERAL,
                     capi.VARIANT_NO_INTERIOR | capi.VARIANT_XCD_RUNS, capi.VARIANT_ZMAJOR_SLOTS,
-                    capi.VARIANT_PERSISTENT_ALWAYS, capi.VARIANT_PERSISTENT_NEVER):
+                    capi.VARIANT_PERSISTENT_ALWAYS, capi.VARIANT_PERSISTENT_NEVER, capi.VARIANT_COST_ORDER):
         out, vh, mh = capi.fuse_once(grid, rp, views, init_grid=init, kernel_variant=variant)
         assert np.array_equal(mh, mh_w), (seed, variant)
         assert np.array_equal(vh, vh_w), (seed, variant)

@@ -20,10 +20,11 @@ NC = capi.VARIANT_NO_BRICK_CLASSES
 # kernel; NC = tiled kernel, every pair on the per-voxel path; 32..224 = other tile shapes; G | x = the general
 # kernel with its own switches
 FX = capi.VARIANT_FIXED_TILE_SHAPE   # shape 0 (16-voxel columns) also on the small grids of these tests
-VARIANTS = [0, FX, FX | NC, NC, capi.VARIANT_SPATIAL_ORDER, 32, 64, 96 | NC, 128, 160 | NC, 192, 224, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
+CO = capi.VARIANT_COST_ORDER         # bricks ordered by their number of mixed views, dealt to the XCDs in short runs
+VARIANTS = [0, FX, FX | NC, NC, capi.VARIANT_SPATIAL_ORDER, CO, CO | FX | capi.VARIANT_PERSISTENT_ALWAYS, 32, 64, 96 | NC, 128, 160 | NC, 192, 224, G, G | capi.VARIANT_EXACT_DIVISION, G | capi.VARIANT_GENERAL_K,
             G | capi.VARIANT_EXACT_DIVISION | capi.VARIANT_GENERAL_K, G | 4, G | 8, G | 12]
 SO = capi.VARIANT_SPATIAL_ORDER
-TILE_SHAPES = [0, FX, FX | NC, NC, SO, FX | SO, 32, 64 | NC, 96, 96 | SO, 128, 160, 192 | NC, 224]
+TILE_SHAPES = [0, FX, FX | NC, NC, SO, FX | SO, CO, CO | capi.VARIANT_WINDOWS_ALWAYS, 32, 64 | NC, 96, 96 | SO, 128, 160, 192 | NC, 224]
 
 
 def _golden_inputs(g):
@@ -75,6 +76,43 @@ def test_slab_fuses_of_a_larger_grid_keep_their_classes_under_shipped_defaults()
             hist = ctx.brick_class_histogram()
     assert bits_equal(out, want)
     assert sum(hist.values()) > 0, hist
+
+
+@pytest.mark.parametrize("dims,grid_dtype,n_slabs", [((64, 64, 200), "f64", 3), ((64, 64, 200), "f64", 100), ((64, 64, 200), "f32", 4),
+                                                     ((48, 40, 24), "f64", 8), ((64, 64, 96), "f64", 1), ((64, 64, 96), "f64", 2)])
+def test_last_chunk_fused_under_the_copy_back(dims, grid_dtype, n_slabs):
+    """dmi_fuse_range_download, the last step of FusionDriver::ProcessDepthMap: the views arrive in chunks, the last chunk is
+    fused slab by slab and every slab copied to the host under the next one's fusion.  Bit for bit the chunks fused whole and
+    downloaded afterwards, and (f64) the oracle; a grid shorter than one slab unit, a last slab that is not a whole unit, more
+    slabs asked for than the grid has units, the converting fallback (another type than the grid's) and count = 0 alike."""
+    grid = scene.default_grid(dims)
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(7, 160, 120, seed=21, dense=True)
+    views.depth[np.random.default_rng(8).random(views.depth.shape) < 0.1] = -1.0
+    np_grid = np.float64 if grid_dtype == "f64" else np.float32
+    want = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
+    chunks = [(0, 3), (3, 2), (5, 2)]
+    with capi.FusionContext(grid, rp, grid_dtype=grid_dtype) as ref:
+        for v0, n in chunks:
+            ref.add_views(scene.Views(views.depth[v0:v0 + n], views.K4[v0:v0 + n], views.RT4[v0:v0 + n]))
+            ref.fuse(v0, n)
+        plain = ref.download_grid(np_grid).copy()
+    pinned = capi.pinned_empty((grid.n_voxels,), np_grid)
+    with capi.FusionContext(grid, rp, grid_dtype=grid_dtype) as ctx:
+        for v0, n in chunks[:-1]:
+            ctx.add_views(scene.Views(views.depth[v0:v0 + n], views.K4[v0:v0 + n], views.RT4[v0:v0 + n]))
+            ctx.fuse(v0, n)
+        v0, n = chunks[-1]
+        ctx.add_views(scene.Views(views.depth[v0:v0 + n], views.K4[v0:v0 + n], views.RT4[v0:v0 + n]))
+        got = ctx.fuse_download(v0, n, np_grid, out=pinned, n_slabs=n_slabs).copy()
+        again = ctx.fuse_download(7, 0, np_grid, n_slabs=n_slabs)        # nothing left to fuse: the copy alone, pageable memory
+        other = ctx.fuse_download(7, 0, np.float32 if grid_dtype == "f64" else np.float64, n_slabs=n_slabs)  # the converting path
+        with pytest.raises(capi.DmiError):
+            ctx.fuse_download(5, 3, np_grid)                             # range outside the resident views
+    assert bits_equal(got, plain) and bits_equal(again, plain)
+    assert bits_equal(other, plain.astype(other.dtype))
+    if grid_dtype == "f64":
+        assert bits_equal(got, want)
 
 
 W = capi.VARIANT_WINDOWS_ALWAYS   # the FREE column's bit windows whatever the depth maps look like (default: maps with scattered holes)

@@ -36,7 +36,7 @@ def main():
     variants = [(0, True), (0, False), (fx, True), (fx, False), (fx | capi.VARIANT_NO_BRICK_CLASSES, True), (96, True),
                 (capi.VARIANT_FORCE_GENERAL, True), (capi.VARIANT_NO_INTERIOR, False), (capi.VARIANT_XCD_RUNS, False),
                 (capi.VARIANT_ZMAJOR_SLOTS, False), (capi.VARIANT_WINDOWS_ALWAYS, False), (fx | capi.VARIANT_WINDOWS_ALWAYS, False),
-                (SHIPPED, False)]
+                (capi.VARIANT_COST_ORDER | capi.VARIANT_WINDOWS_ALWAYS, False), (SHIPPED, False)]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     t0 = time.time()
     done = 0
