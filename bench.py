@@ -185,7 +185,7 @@ def coloration_probe(scene, capi, n_vertices: int, W: int, H: int, n_views: int 
             # the three outputs written once (3 + 3 + 4 B)
             b_alg = float(n_vertices * 24 + hits * 4 + n_vertices * 10)
             l2 = None
-            key = {"random_vertices": "random", "mesh_ordered_vertices": "mesh"}.get(name)
+            key = {"random_vertices": "random", "mesh_ordered_vertices": "mesh", "random_vertices_reordered_on_device": "reordered"}.get(name)
             if key and pmc.get(key, {}).get("counters_project_and_median_kernels", {}).get("TCP_TCC_READ_REQ_sum") \
                     and (pmc[key].get("vertices"), pmc[key].get("views")) == (n_vertices, n_views):
                 req_bytes = pmc[key]["counters_project_and_median_kernels"]["TCP_TCC_READ_REQ_sum"] * 64.0

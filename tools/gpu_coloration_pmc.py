@@ -24,6 +24,7 @@ if order == "mesh":
     pts = pts[scene.morton_order(pts)]
 with capi.ColorContext() as c:
     c.add_views(colors, K4, views.RT4)
+    c.set_vertex_reorder(order == "reordered")   # random input, Z-order processing inside the library (dmi_color_set_vertex_reorder)
     mean, median, count = c.process(pts)
     print(json.dumps({"order": order, "vertices": n_vertices, "views": n_views, "kernel_ms": c.kernel_ms(),
                       "pairs_in_image": int(count.sum(dtype=np.int64))}))
