@@ -608,7 +608,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column (4d)
           const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
           float e1 = cload(&rec->t1_e1);
-          if (cload(&rec->t1_ok) == 2) e1 = t1_lane_margin<TK>(czf, cload(&rec->t1_dcz), hb, e1, cload(&rec->t1_b));  // wave-uniform
+#ifndef DMI_EXP_NO_LANE_MARGIN  // timing experiment (wrong for views with t1_ok == 2): what the branch costs the other views
+    #ifndef DMI_EXP_NO_LANE_MARGIN
+      if (cload(&rec->t1_ok) == 2) e1 = t1_lane_margin<TK>(czf, cload(&rec->t1_dcz), hb, e1, cload(&rec->t1_b));  // wave-uniform
+#endif
+#endif
           const float thr = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), e1));
           // (lanes outside the grid own no voxel -- their sums are never stored -- and run like any other: their world position
           // is as finite as their neighbours'; one of them not accepted costs a redo that adds to a sum nobody reads)
