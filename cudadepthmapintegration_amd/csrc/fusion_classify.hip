@@ -199,20 +199,24 @@ __global__ __launch_bounds__(512) void upload_views_kernel(const InT *__restrict
   if (t < 2 && block_counts[t] != 0) atomicAdd(counters + 1 + t, (unsigned long long)block_counts[t]);
 }
 
-// level l from level l-1: one thread per tile, 2 x 2 children
-__global__ __launch_bounds__(256) void pyramid_up_kernel(int64_t n_maps, int level, PyramidDesc P, DepthTile *__restrict__ pyr) {
-  const int64_t tiles = (int64_t)P.width[level] * P.height[level];
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= tiles * n_maps) return;
-  const int64_t m = idx / tiles;
-  const int t = (int)(idx - m * tiles);
-  const int ty = t / P.width[level], tx = t - ty * P.width[level];
-  const DepthTile *child = pyr + m * P.total_tiles + P.offset[level - 1];
-  const int cw = P.width[level - 1], ch = P.height[level - 1];
-  TileAcc acc;
-  for (int y = 2 * ty; y < 2 * ty + 2 && y < ch; ++y)
-    for (int x = 2 * tx; x < 2 * tx + 2 && x < cw; ++x) acc.add_tile(child[y * cw + x]);
-  pyr[m * P.total_tiles + P.offset[level] + t] = acc.tile();
+// Every level above the finest of ONE view's pyramid, by one workgroup: level l from level l - 1 (2 x 2 children per tile), a
+// barrier between levels -- the levels shrink by four each (160 x 90 tiles, 80 x 45 ... 1 x 1 at 1280 x 720), so one launch per
+// level (eight of ~5 us each per upload, round 3) was launch latency and nothing else.
+__global__ __launch_bounds__(1024) void pyramid_levels_kernel(PyramidDesc P, DepthTile *pyr) {
+  DepthTile *view = pyr + (int64_t)blockIdx.x * P.total_tiles;
+  for (int level = 1; level < P.n_levels; ++level) {
+    const int w = P.width[level], tiles = w * P.height[level];
+    const DepthTile *child = view + P.offset[level - 1];
+    const int cw = P.width[level - 1], ch = P.height[level - 1];
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+      const int ty = t / w, tx = t - ty * w;
+      TileAcc acc;
+      for (int y = 2 * ty; y < 2 * ty + 2 && y < ch; ++y)
+        for (int x = 2 * tx; x < 2 * tx + 2 && x < cw; ++x) acc.add_tile(child[y * cw + x]);
+      view[P.offset[level] + t] = acc.tile();
+    }
+    __syncthreads();  // (also orders this level's stores before the next level's loads, workgroup scope)
+  }
 }
 
 // bounds of the depth values in pixels [x0, x1] x [y0, y1] (inside the image): the finest level whose tiles cover the
@@ -1079,13 +1083,9 @@ hipError_t launch_upload_views(const void *in, int in_is_f64, const double *best
 }
 
 hipError_t launch_build_pyramid_levels(int64_t n_maps, const PyramidDesc &P, DepthTile *pyramids, hipStream_t stream) {
-  hipError_t e = hipSuccess;
-  for (int li = 1; e == hipSuccess && li < P.n_levels; ++li) {
-    const int64_t n = (int64_t)P.width[li] * P.height[li] * n_maps;
-    hipLaunchKernelGGL(pyramid_up_kernel, dim3(blocks_of(n)), dim3(256), 0, stream, n_maps, li, P, pyramids);
-    e = hipGetLastError();
-  }
-  return e;
+  if (n_maps <= 0 || P.n_levels <= 1) return hipSuccess;
+  hipLaunchKernelGGL(pyramid_levels_kernel, dim3((unsigned)n_maps), dim3(1024), 0, stream, P, pyramids);
+  return hipGetLastError();
 }
 
 hipError_t launch_window_origins(const TileArgs &a, const MapRec *maps_dev, int tk, uint8_t *classes, int general_k,
