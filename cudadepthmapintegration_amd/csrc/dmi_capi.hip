@@ -1393,10 +1393,13 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     DMI_HIP(ctx, hipEventCreate(&ev.stop));
     DMI_HIP(ctx, hipEventCreate(&ev.mid));
   }
-  ev.has_mid = cfg.use_tile != 0;
+  // (the event between the preparation launches and the fusion kernel costs ~6 us of idle queue: a launch without brick
+  // classes -- tiny grids, 50 us in all -- has one 3-us table kernel before its fusion kernel and is timed as a whole)
+  ev.has_mid = cfg.use_tile != 0 && !(cfg.variant & dmi::VAR_NO_BRICK_CLASSES);
   DMI_HIP(ctx, hipEventRecord(ev.start, ctx->stream));
   hipError_t e = cfg.use_tile ? dmi::launch_fuse_tiled(t, ctx->d_maps, cfg, ctx->pyramid, ctx->d_order_level,
-                                                         ctx->d_classes ? ctx->d_classes + ctx->coarse_offset : nullptr, ev.mid, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
+                                                         ctx->d_classes ? ctx->d_classes + ctx->coarse_offset : nullptr,
+                                                         ev.has_mid ? ev.mid : nullptr, ctx->stream) : dmi::launch_fuse(a, cfg, ctx->stream);
   if (e != hipSuccess) {
     ctx->pool.push_back(ev);
     (void)hipGetLastError();

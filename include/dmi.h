@@ -106,7 +106,8 @@ typedef struct dmi_timings {
   double last_cell_to_point_ms; /* hipEvent time of the last dmi_cell_to_point kernel */
   /* of last_fuse_kernel_ms / total_fuse_kernel_ms, the fusion kernel proper (without the cz table, the brick
    * classification and the workgroup ordering that precede it) */
-  double last_fuse_main_kernel_ms;
+  double last_fuse_main_kernel_ms;  /* (a launch without brick classes -- at most 1024 bricks -- is timed as a whole: its one table
+                                       kernel included, = last_fuse_kernel_ms) */
   double total_fuse_main_kernel_ms;
 } dmi_timings;
 
