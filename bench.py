@@ -586,7 +586,7 @@ def main():
             "fuse_ms": kern_ms,
             "algorithmic_bytes_per_launch": b_alg,
             "note": "kernel_ms = hipEvent time of the fusion kernel alone (the launch rocprofv3 lists under this name), "
-                    "fuse_ms = all launches of one dmi_fuse (+ cz table, two classification passes, window origins, ordering); "
+                    "fuse_ms = all launches of one dmi_fuse (+ two classification passes -- the first fills the launch's tables --, window origins, two ordering launches); "
                     "the path is bound by instruction issue (vector, then scalar) -- not by HBM: see roofline_issue, "
                     "roofline_valu and DESIGN.md 9",
         },

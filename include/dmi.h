@@ -104,8 +104,9 @@ typedef struct dmi_timings {
   double last_upload_ms; /* host wall time of the last dmi_add_views (copy + convert, synchronised) */
   double last_download_ms;
   double last_cell_to_point_ms; /* hipEvent time of the last dmi_cell_to_point kernel */
-  /* of last_fuse_kernel_ms / total_fuse_kernel_ms, the fusion kernel proper (without the cz table, the brick
-   * classification and the workgroup ordering that precede it) */
+  /* of last_fuse_kernel_ms / total_fuse_kernel_ms, the fusion kernel proper (without the brick classification, the window
+   * origins and the workgroup ordering that precede it).  A launch without brick classes -- at most 1024 bricks and fewer than 48
+   * views -- is timed as a whole, its one table kernel included: the two are equal then */
   double last_fuse_main_kernel_ms;  /* (a launch without brick classes -- at most 1024 bricks -- is timed as a whole: its one table
                                        kernel included, = last_fuse_kernel_ms) */
   double total_fuse_main_kernel_ms;
