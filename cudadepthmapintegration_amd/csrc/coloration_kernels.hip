@@ -146,10 +146,23 @@ __global__ __launch_bounds__(256) void bbox_kernel(const double *__restrict__ po
       lo[a] = l2 < lo[a] ? l2 : lo[a];
       hi[a] = h2 > hi[a] ? h2 : hi[a];
     }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(&box[a], lo[a]);
-      atomicMax(&box[3 + a], hi[a]);
+  }
+  // one pair of atomics per axis and WORKGROUP (they all hit the same six words: per wave, 1024 workgroups' 24 576 atomics took
+  // 0.28 ms for a million vertices -- profiles/r17o_coloration_cfg5_kernel_stats.csv)
+  __shared__ unsigned long long wave_lo[4][3], wave_hi[4][3];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; ++a) wave_lo[wave][a] = lo[a], wave_hi[wave][a] = hi[a];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    unsigned long long l = wave_lo[0][a], h = wave_hi[0][a];
+    for (int w = 1; w < 4; ++w) {
+      l = wave_lo[w][a] < l ? wave_lo[w][a] : l;
+      h = wave_hi[w][a] > h ? wave_hi[w][a] : h;
     }
+    atomicMin(&box[a], l);
+    atomicMax(&box[3 + a], h);
   }
 }
 
@@ -697,7 +710,7 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
       // the order of work: along a Z-order curve of the chunk's bounding box (see bbox_kernel)
       static const unsigned long long kEmptyBox[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
       DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_box, kEmptyBox, sizeof(kEmptyBox), hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(bbox_kernel, dim3(std::min<unsigned>(blocks, 1024u)), dim3(256), 0, c->stream, c->d_points, nv, c->d_box);
+      hipLaunchKernelGGL(bbox_kernel, dim3(std::min<unsigned>(blocks, 256u)), dim3(256), 0, c->stream, c->d_points, nv, c->d_box);
       hipLaunchKernelGGL(morton_key_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, c->d_box, c->d_keys, c->d_index);
       DMI_COLOR_HIP(c, hipGetLastError());
       size_t temp = c->sort_temp_bytes;
