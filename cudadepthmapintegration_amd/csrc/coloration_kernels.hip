@@ -202,7 +202,7 @@ struct MedianSeed {
 // HIST: also fill, per lane, 16-bin histograms of the upper nibbles of the three channels in LDS (every lane owns a
 // column of counters: no barrier, no conflict) and leave the MedianSeed of the vertex: the first of the two passes of
 // the histogram medians costs no read of the scratch table.
-template <bool HIST>
+template <bool HIST, bool PIPE>
 __global__ __launch_bounds__(256) void project_color_kernel(const double *__restrict__ points, int64_t nv,
                                                             const uint32_t *__restrict__ perm,
                                                             const ColorView *__restrict__ views, int n, int W, int H,
@@ -222,7 +222,25 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
   };
   if constexpr (HIST)
     for (int q = 0; q < 3 * kHistWords; ++q) hist[q * 256 + lane] = 0;
-  for (int m = 0; m < n; ++m) {
+  // what happens to a view's texel once it has arrived: count, integer sums, histogram, the scratch table's entry
+  auto consume = [&](int mq, uchar4 c, bool ok) {
+    uchar4 out = make_uchar4(0, 0, 0, 0);
+    if (ok) {
+      out = make_uchar4(c.x, c.y, c.z, 1);
+      cnt += 1;
+      s0 += c.x;  // std::accumulate(..., 0): integer running sums (MC.cxx:176-178)
+      s1 += c.y;
+      s2 += c.z;
+      if constexpr (HIST) {
+        bump(0, c.x >> 4);
+        bump(1, c.y >> 4);
+        bump(2, c.z >> 4);
+      }
+    }
+    scratch[(int64_t)mq * nv + id] = out;
+  };
+  // the view's pixel for this vertex and the request for its texel
+  auto project = [&](int m, uchar4 &c, bool &ok) __attribute__((always_inline)) {
     const ColorView *v = views + m;  // wave-uniform
     // The pixel only has to be the reference's pixel: the homogeneous coordinates come from the rows of K3*[R|T] (nine
     // FMAs instead of the reference's 33 operations), and the pixel they select is taken when it provably is the
@@ -231,7 +249,6 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
     const double ax = __builtin_fma(cload(&v->p[0]), x, __builtin_fma(cload(&v->p[1]), y, __builtin_fma(cload(&v->p[2]), z, cload(&v->p[3]))));
     const double ay = __builtin_fma(cload(&v->p[4]), x, __builtin_fma(cload(&v->p[5]), y, __builtin_fma(cload(&v->p[6]), z, cload(&v->p[7]))));
     const double az = __builtin_fma(cload(&v->p[8]), x, __builtin_fma(cload(&v->p[9]), y, __builtin_fma(cload(&v->p[10]), z, cload(&v->p[11]))));
-    uchar4 out = make_uchar4(0, 0, 0, 0);
     int px = 0, py = 0;
     const FastQuotient by_az(az);
     bool have_pixel = by_az.round_to_pixel_near(ax, cload(&margins[m].ex), px) && by_az.round_to_pixel_near(ay, cload(&margins[m].ey), py);
@@ -248,20 +265,45 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
       const FastQuotient by_dz(dz);
       is_pixel = by_dz.round_to_pixel(dx, dz, px) && by_dz.round_to_pixel(dy, dz, py);   // RD.cxx:177-181
     }
-    if (is_pixel && px >= 0 && py >= 0 && px < W && py < H) {                            // MC.cxx:158-163
-      const uchar4 c = cload(&v->color)[(int64_t)py * W + px];      // RD.cxx:106-108 (row flip done at upload)
-      out = make_uchar4(c.x, c.y, c.z, 1);
-      cnt += 1;
-      s0 += c.x;  // std::accumulate(..., 0): integer running sums (MC.cxx:176-178)
-      s1 += c.y;
-      s2 += c.z;
-      if constexpr (HIST) {
-        bump(0, c.x >> 4);
-        bump(1, c.y >> 4);
-        bump(2, c.z >> 4);
-      }
+    ok = is_pixel && px >= 0 && py >= 0 && px < W && py < H;                             // MC.cxx:158-163
+    c = make_uchar4(0, 0, 0, 0);
+    if (ok) c = cload(&v->color)[(int64_t)py * W + px];             // RD.cxx:106-108 (row flip done at upload)
+  };
+  if constexpr (PIPE) {
+    // Vertices in the caller's order (a mesh: neighbours in neighbouring lanes): the loop software-pipelined.  View m's texel is
+    // requested in its own step and consumed two steps later, behind the projections of the two views in between -- consumed at
+    // once, a gather that misses every cache stalled the wave once per view (2.9 us per view and wave at 512 views,
+    // profiles/r17o_*).  Integer sums, histogram counts, distinct table entries: the order of consumption changes no result
+    // bit.  Two named slots, the loop unrolled by two: a slot is a register the load writes and nothing copies.
+    // (mesh order 4.96 -> 4.51 ms at cfg 5's scale; with scattered vertices -- random order 7.7 -> 9.2 ms, the device-reordered
+    // pass 6.0 -> 6.3 -- the gathers are bound by the lines they drag in and twice as many in flight evict each other: the
+    // reordered pass keeps the plain loop, profiles/r17q_*)
+    uchar4 c_even = make_uchar4(0, 0, 0, 0), c_odd = make_uchar4(0, 0, 0, 0);
+    bool ok_even = false, ok_odd = false;
+    auto step = [&](int m, uchar4 &slot_c, bool &slot_ok) __attribute__((always_inline)) {
+      uchar4 c;
+      bool ok;
+      project(m, c, ok);
+      if (m >= 2) consume(m - 2, slot_c, slot_ok);  // (wave-uniform) the view this slot held
+      slot_c = c;
+      slot_ok = ok;
+    };
+    int m = 0;
+    for (; m + 1 < n; m += 2) {
+      step(m, c_even, ok_even);
+      step(m + 1, c_odd, ok_odd);
     }
-    scratch[(int64_t)m * nv + id] = out;
+    if (m < n) step(m, c_even, ok_even);  // an odd number of views
+    // the two youngest views are still in their slots
+    if (n >= 2) consume(n - 2, (n & 1) ? c_odd : c_even, (n & 1) ? ok_odd : ok_even);
+    if (n >= 1) consume(n - 1, (n & 1) ? c_even : c_odd, (n & 1) ? ok_even : ok_odd);
+  } else {
+    for (int m = 0; m < n; ++m) {
+      uchar4 c;
+      bool ok;
+      project(m, c, ok);
+      consume(m, c, ok);
+    }
   }
   count[vtx] = cnt;  // MC.cxx:186 (0 when no view sees the vertex, MC.cxx:130)
   // sum / nbVal in double, then static_cast<unsigned char> (MC.cxx:179-180): exactly the integer quotient
@@ -617,6 +659,35 @@ int dmi_color_clear_views(dmi_color_context *c) {
   });
 }
 
+namespace {
+// Are consecutive vertices neighbours in space, as a mesh's are?  A sample of up to 512 consecutive pairs against the same
+// number of pairs half the array apart: coherent when the median step is under a tenth of the median far distance.  What the
+// answer chooses is a loop form of the projection kernel (below), never a result.
+bool vertices_in_coherent_order(const double *p, int64_t n) {
+  if (n < 64) return true;
+  const int64_t samples = std::min<int64_t>(512, n / 2);
+  std::vector<double> near_d, far_d;
+  near_d.reserve((size_t)samples);
+  far_d.reserve((size_t)samples);
+  auto dist2 = [&](int64_t a, int64_t b) {
+    double s2 = 0.0;
+    for (int q = 0; q < 3; ++q) {
+      const double d = p[3 * a + q] - p[3 * b + q];
+      s2 += d * d;
+    }
+    return s2;  // (a NaN compares false everywhere below and sorts anywhere: the answer is a guess either way)
+  };
+  for (int64_t t = 0; t < samples; ++t) {
+    const int64_t i = t * ((n - 1) / samples);
+    near_d.push_back(dist2(i, i + 1));
+    far_d.push_back(dist2(i, (i + n / 2) % n));
+  }
+  std::nth_element(near_d.begin(), near_d.begin() + near_d.size() / 2, near_d.end());
+  std::nth_element(far_d.begin(), far_d.begin() + far_d.size() / 2, far_d.end());
+  return near_d[near_d.size() / 2] < 0.01 * far_d[far_d.size() / 2];  // squared distances: a tenth of the distance
+}
+}  // namespace
+
 int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_points, uint8_t *mean, uint8_t *median,
                       int32_t *count) {
   return guarded(c, "dmi_color_process", [&]() -> int {
@@ -644,6 +715,7 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
     c->views_dirty = false;
   }
+  const bool coherent = !c->reorder && vertices_in_coherent_order(points, n_points);
   std::vector<ViewMargin> margins;
   // vertices per chunk: the scratch table [view][vertex] stays within its budget
   const size_t budget = c->scratch_budget;
@@ -723,13 +795,19 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     if (getenv("DMI_COLOR_BITWISE_MEDIAN")) histogram_medians = false;  // A/B of the two median kernels
 #endif
     if (histogram_medians) {
-      hipLaunchKernelGGL(project_color_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
+      // (vertices in a coherent order of the caller's -- a mesh's -- take the pipelined view loop; scattered ones and the
+      // Z-order pass the plain one)
+      if (perm || !coherent)
+        hipLaunchKernelGGL((project_color_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
+                           (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
+      else
+        hipLaunchKernelGGL((project_color_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
+                           (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
       DMI_COLOR_HIP(c, hipGetLastError());
       hipLaunchKernelGGL(median_low_nibble_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
                          c->d_count, c->d_seeds, c->d_median);
     } else {
-      hipLaunchKernelGGL(project_color_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
+      hipLaunchKernelGGL((project_color_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
                          (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
       DMI_COLOR_HIP(c, hipGetLastError());
       hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,

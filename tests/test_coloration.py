@@ -127,15 +127,25 @@ def test_gpu_color_context_resident_views_chunks_and_batches():
         gw = c.process(weird)
         assert gw[2][5] == 0 and all(np.array_equal(np.delete(g, 5, axis=0), np.delete(w, 5, axis=0)) for g, w in zip(gw, want))
         c.set_vertex_reorder(False)
+        # vertices in a mesh's order (neighbours next to each other) take the pipelined view loop of the projection kernel, an odd
+        # and an even number of views, one view, chunked or not: the same bits as in any other order
+        order = scene.morton_order(pts)
+        for budget in (9 * 4 * 1024, 1 << 30):
+            c.set_scratch_budget(budget)
+            got = c.process(pts[order])
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w[order])
         sub = c.process(pts[100:1100])               # another vertex set, same resident views
         for g, w in zip(sub, want):
             assert np.array_equal(g, w[100:1100])
-        c.clear_views()
-        c.add_views(colors[:2], K4[:2], RT4[:2])
-        got2 = c.process(pts[:500])
-        want2 = oracle.color_mesh(pts[:500], colors[:2], K4[:2], RT4[:2])
-        for g, w in zip(got2, want2):
-            assert np.array_equal(g, w)
+        for n_v in (2, 1):
+            c.clear_views()
+            c.add_views(colors[:n_v], K4[:n_v], RT4[:n_v])
+            for sel in (np.arange(500), order[:3000]):
+                got2 = c.process(pts[sel])
+                want2 = oracle.color_mesh(pts[sel], colors[:n_v], K4[:n_v], RT4[:n_v])
+                for g, w in zip(got2, want2):
+                    assert np.array_equal(g, w)
         with pytest.raises(capi.DmiError):
             c.add_views(colors[:1, :10], K4[:1], RT4[:1])   # a view of another size (MC.cxx:111 reads view 0's)
 
