@@ -271,32 +271,43 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
   };
   if constexpr (PIPE) {
     // Vertices in the caller's order (a mesh: neighbours in neighbouring lanes): the loop software-pipelined.  View m's texel is
-    // requested in its own step and consumed two steps later, behind the projections of the two views in between -- consumed at
+    // requested in its own step and consumed K steps later, behind the projections of the K views in between -- consumed at
     // once, a gather that misses every cache stalled the wave once per view (2.9 us per view and wave at 512 views,
     // profiles/r17o_*).  Integer sums, histogram counts, distinct table entries: the order of consumption changes no result
-    // bit.  Two named slots, the loop unrolled by two: a slot is a register the load writes and nothing copies.
-    // (mesh order 4.96 -> 4.51 ms at cfg 5's scale; with scattered vertices -- random order 7.7 -> 9.2 ms, the device-reordered
-    // pass 6.0 -> 6.3 -- the gathers are bound by the lines they drag in and twice as many in flight evict each other: the
-    // reordered pass keeps the plain loop, profiles/r17q_*)
-    uchar4 c_even = make_uchar4(0, 0, 0, 0), c_odd = make_uchar4(0, 0, 0, 0);
-    bool ok_even = false, ok_odd = false;
-    auto step = [&](int m, uchar4 &slot_c, bool &slot_ok) __attribute__((always_inline)) {
+    // bit.  K slots, the loop unrolled by K: a slot is a register the load writes and nothing copies.
+    // (mesh order at cfg 5's scale: 4.96 ms plain, 4.51 with K = 2, 4.37 with 4, 4.2 with 8, 4.3 with 16, 4.4 with 32; with
+    // scattered vertices -- random order 7.7 -> 9.2 ms at K = 2, the device-reordered pass 6.0 -> 6.3 -- the gathers are bound by
+    // the lines they drag in and more of them in flight evict each other: those keep the plain loop, profiles/r17q_*, r17s_*)
+#ifndef DMI_COLOR_AHEAD
+#define DMI_COLOR_AHEAD 8
+#endif
+    constexpr int K = DMI_COLOR_AHEAD;  // views between a texel's request and its use
+    uchar4 slot_c[K];
+    bool slot_ok[K];
+    int m = 0;
+    if (n >= K) {
+#pragma unroll
+      for (int q = 0; q < K; ++q) project(q, slot_c[q], slot_ok[q]);
+      for (m = K; m + K <= n; m += K) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          uchar4 c;
+          bool ok;
+          project(m + q, c, ok);
+          consume(m + q - K, slot_c[q], slot_ok[q]);  // the view this slot held
+          slot_c[q] = c;
+          slot_ok[q] = ok;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < K; ++q) consume(m - K + q, slot_c[q], slot_ok[q]);
+    }
+    for (; m < n; ++m) {  // the views a whole round of K does not cover
       uchar4 c;
       bool ok;
       project(m, c, ok);
-      if (m >= 2) consume(m - 2, slot_c, slot_ok);  // (wave-uniform) the view this slot held
-      slot_c = c;
-      slot_ok = ok;
-    };
-    int m = 0;
-    for (; m + 1 < n; m += 2) {
-      step(m, c_even, ok_even);
-      step(m + 1, c_odd, ok_odd);
+      consume(m, c, ok);
     }
-    if (m < n) step(m, c_even, ok_even);  // an odd number of views
-    // the two youngest views are still in their slots
-    if (n >= 2) consume(n - 2, (n & 1) ? c_odd : c_even, (n & 1) ? ok_odd : ok_even);
-    if (n >= 1) consume(n - 1, (n & 1) ? c_even : c_odd, (n & 1) ? ok_even : ok_odd);
   } else {
     for (int m = 0; m < n; ++m) {
       uchar4 c;
