@@ -100,7 +100,24 @@ struct FastQuotient {
   }
 };
 
-// [n][H][W][3] in vtk point order (row 0 = bottom, RD.cxx:106-108) -> [n][H][W] RGBA, top row first
+// A colour plane in HBM: RGBA texels, top image row first, in TILES of 8 x 4 texels = one 128-byte line (texel (x, y) at
+// ((y >> 2) * tiles_x + (x >> 3)) * 32 + (y & 3) * 8 + (x & 7)).  The vertices of a wave are neighbours on the surface, their
+// pixels a patch of a few pixels each way: in rows of texels such a patch touches a line per image row, in tiles about half as
+// many (profiles/r17t_*).
+#ifndef DMI_TEX_TILE_LOG_W
+#define DMI_TEX_TILE_LOG_W 3
+#define DMI_TEX_TILE_LOG_H 2
+#endif
+constexpr int kTexLogW = DMI_TEX_TILE_LOG_W, kTexLogH = DMI_TEX_TILE_LOG_H;
+constexpr int kTexTileW = 1 << kTexLogW, kTexTileH = 1 << kTexLogH, kTexTile = kTexTileW * kTexTileH;
+__host__ __device__ inline int64_t color_plane_texels(int W, int H) {
+  return (int64_t)((W + kTexTileW - 1) / kTexTileW) * ((H + kTexTileH - 1) / kTexTileH) * kTexTile;
+}
+__device__ __forceinline__ int64_t texel_index(int x, int y, int tiles_x) {
+  return ((int64_t)(y >> kTexLogH) * tiles_x + (x >> kTexLogW)) * kTexTile + ((y & (kTexTileH - 1)) << kTexLogW) + (x & (kTexTileW - 1));
+}
+
+// [n][H][W][3] in vtk point order (row 0 = bottom, RD.cxx:106-108) -> [n] tiled RGBA planes, top row first
 __global__ __launch_bounds__(256) void pack_color_kernel(const uint8_t *__restrict__ rgb, uchar4 *__restrict__ rgba, int W,
                                                          int H, int64_t n_pixels_total) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256) void pack_color_kernel(const uint8_t *__restri
   const int64_t m = id / npix, r = id % npix;
   const int y = (int)(r / W), x = (int)(r % W);
   const uint8_t *c = rgb + (m * npix + (int64_t)(H - 1 - y) * W + x) * 3;
-  rgba[id] = make_uchar4(c[0], c[1], c[2], 255);
+  rgba[m * color_plane_texels(W, H) + texel_index(x, y, (W + kTexTileW - 1) / kTexTileW)] = make_uchar4(c[0], c[1], c[2], 255);
 }
 
 // ---- processing order ---------------------------------------------------------------------------------------------
@@ -211,6 +228,7 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
                                                             const ViewMargin *__restrict__ margins) {
   __shared__ uint32_t hist[HIST ? 3 * kHistWords * 256 : 1];  // [channel][word][lane]: 24 KB
   const int lane = threadIdx.x;
+  const int tiles_x = (W + kTexTileW - 1) / kTexTileW;
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // position along the Z-order curve
   if (id >= nv) return;
   const int64_t vtx = perm ? (int64_t)perm[id] : id;                  // the vertex this lane colours
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
     }
     ok = is_pixel && px >= 0 && py >= 0 && px < W && py < H;                             // MC.cxx:158-163
     c = make_uchar4(0, 0, 0, 0);
-    if (ok) c = cload(&v->color)[(int64_t)py * W + px];             // RD.cxx:106-108 (row flip done at upload)
+    if (ok) c = cload(&v->color)[texel_index(px, py, tiles_x)];     // RD.cxx:106-108 (row flip and tiling done at upload)
   };
   if constexpr (PIPE) {
     // Vertices in the caller's order (a mesh: neighbours in neighbouring lanes): the loop software-pipelined.  View m's texel is
@@ -276,8 +294,9 @@ __global__ __launch_bounds__(256) void project_color_kernel(const double *__rest
     // profiles/r17o_*).  Integer sums, histogram counts, distinct table entries: the order of consumption changes no result
     // bit.  K slots, the loop unrolled by K: a slot is a register the load writes and nothing copies.
     // (mesh order at cfg 5's scale: 4.96 ms plain, 4.51 with K = 2, 4.37 with 4, 4.2 with 8, 4.3 with 16, 4.4 with 32; with
-    // scattered vertices -- random order 7.7 -> 9.2 ms at K = 2, the device-reordered pass 6.0 -> 6.3 -- the gathers are bound by
-    // the lines they drag in and more of them in flight evict each other: those keep the plain loop, profiles/r17q_*, r17s_*)
+    // scattered vertices -- random order 7.7 -> 9.2 ms at K = 2 -- the gathers are bound by the lines they drag in and more of
+    // them in flight evict each other: those keep the plain loop; the device-reordered pass lost 5 % at K = 2 on row-major
+    // planes and gains 4 % at K = 8 on tiled ones; profiles/r17q_*, r17s_*, r17t_*)
 #ifndef DMI_COLOR_AHEAD
 #define DMI_COLOR_AHEAD 8
 #endif
@@ -600,7 +619,8 @@ int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const doubl
   const size_t npix = (size_t)width * height;
   ColorBatch b;
   b.n = n;
-  DMI_COLOR_HIP(c, hipMalloc(&b.d_rgba, npix * (size_t)n * sizeof(uchar4)));
+  const size_t plane = (size_t)color_plane_texels(width, height);  // a tiled plane: whole tiles of 8 x 4 texels
+  DMI_COLOR_HIP(c, hipMalloc(&b.d_rgba, plane * (size_t)n * sizeof(uchar4)));
   // stage <= 256 MiB of RGB at a time, repack on the device
   const size_t per_chunk = std::max<size_t>(1, (size_t(256) << 20) / (npix * 3));
   const size_t chunk = std::min<size_t>(per_chunk, (size_t)n);
@@ -622,7 +642,7 @@ int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const doubl
     if (e == hipSuccess) {
       const int64_t total = (int64_t)(cnt * npix);
       hipLaunchKernelGGL(pack_color_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_stage,
-                         b.d_rgba + m0 * npix, width, height, total);
+                         b.d_rgba + m0 * plane, width, height, total);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the stage buffer is reused by the next chunk
@@ -638,7 +658,7 @@ int dmi_color_add_views(dmi_color_context *c, const uint8_t *colors, const doubl
     for (int i = 0; i < 12; ++i) v.rt[i] = RT4[16 * (size_t)m + i];
     for (int r = 0; r < 3; ++r)
       for (int q = 0; q < 3; ++q) v.k[3 * r + q] = K4[16 * (size_t)m + 4 * r + q];
-    v.color = b.d_rgba + (size_t)m * npix;
+    v.color = b.d_rgba + (size_t)m * plane;
     for (int r = 0; r < 3; ++r)
       for (int q = 0; q < 4; ++q) {
         double sum = 0.0, mag = 0.0;
@@ -806,9 +826,9 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     if (getenv("DMI_COLOR_BITWISE_MEDIAN")) histogram_medians = false;  // A/B of the two median kernels
 #endif
     if (histogram_medians) {
-      // (vertices in a coherent order of the caller's -- a mesh's -- take the pipelined view loop; scattered ones and the
-      // Z-order pass the plain one)
-      if (perm || !coherent)
+      // (vertices in a coherent order -- the caller's, a mesh's, or the Z-order pass's -- take the pipelined view loop, scattered
+      // ones the plain one)
+      if (!perm && !coherent)
         hipLaunchKernelGGL((project_color_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
                            (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
       else
