@@ -112,6 +112,21 @@ __global__ __launch_bounds__(512) void upload_views_kernel(const InT *__restrict
   OutT *dst = out + m * npix + (int64_t)y * W;
   if (threadIdx.x < 2) block_counts[threadIdx.x] = 0;
   unsigned int lossy = 0;
+  // the row's eight runs of 64 values (and costs) requested before the first is looked at: a load inside the per-lane
+  // `inside` branch below was waited for at the branch's end, eight trips to memory one after the other (columns outside the
+  // image read the row's nearest value: never used)
+  InT held[8];
+  double held_cost[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) held[k] = (InT)0, held_cost[k] = 0.0;
+  if (row_inside) {  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int x = min(max(blockIdx.x * 512 + 64 * k + lane - kValidMargin, 0), W - 1);
+      held[k] = src[x];
+      if (cost != nullptr) held_cost[k] = cost[x];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int X = blockIdx.x * 512 + 64 * k + lane, x = X - kValidMargin;
@@ -119,8 +134,8 @@ __global__ __launch_bounds__(512) void upload_views_kernel(const InT *__restrict
     bool has = false;
     TileAcc acc;
     if (inside) {
-      double d = (double)src[x];
-      if (cost != nullptr && cost[x] > thr) d = -1.0;  // RD.cxx:159-166
+      double d = (double)held[k];
+      if (cost != nullptr && held_cost[k] > thr) d = -1.0;  // RD.cxx:159-166
       const OutT o = (OutT)d;
       if (sizeof(OutT) == 4 && sizeof(InT) == 8) {  // bit compare, so that a NaN round-trips instead of counting as lossy
         const double back = (double)o;
