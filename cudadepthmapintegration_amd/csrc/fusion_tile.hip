@@ -431,23 +431,38 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 
   // the TK running sums live in v[BASE ...], outside the compiler's register budget (fusion_tile_acc.inc)
   uint32_t nh[COUNT ? TK : 1];
-  if (kg->init_from_grid) {  // cu:211 accumulates onto what the grid holds (a chunk of views fused onto the chunks before it)
-    // every slot's value requested before the first is converted: one at a time (a load, a wait, a move into the slot) they were
-    // TK trips to memory in a row at the start of every brick -- 0.2-0.3 ms of a 2-ms fusion of 32 views onto existing sums
-    // (profiles/r17y_*)
-    // (no branch around a load -- a join waits for what is in flight --: lanes outside the grid and slots above it read a voxel
-    // that exists, clamped per axis; their sums are never stored)
-    GridT held[TK];
-    const int ic = i < head0[0] ? i : head0[0] - 1, jc = j < head0[1] ? j : head0[1] - 1;
-    const GridT *column = static_cast<const GridT *>(kg->grid) + ((int64_t)k0 * kg->ny + jc) * kg->nx + ic;
-    const int64_t plane_in = (int64_t)kg->ny * kg->nx;
+#ifndef DMI_EXP_INIT_ALWAYS_OLD
+  if constexpr (!PERSIST) {
+    // One workgroup per brick: the form that launches of few views take -- a chunk of 32 views fused onto the chunks before it,
+    // cu:211 accumulating onto what the grid holds.  Every slot's value is requested before the first is converted: one at a time
+    // (a load, a wait, a move into the slot) they were TK trips to memory in a row at the start of every brick, 0.2-0.3 ms of a
+    // 2-ms fusion of 32 views onto existing sums (profiles/r17y_*).  No branch around a load -- a join waits for what is in
+    // flight --: lanes outside the grid and slots above it read a voxel that exists, clamped per axis; their sums are never stored.
+    // (The persistent form keeps the loop below: there this block cost the launches from a zero grid 2-4 % -- registers --, and
+    // its bricks live ten times as long.)
+    if (kg->init_from_grid) {
+      GridT held[TK];
+      const int ic = i < head0[0] ? i : head0[0] - 1, jc = j < head0[1] ? j : head0[1] - 1;
+      const GridT *column = static_cast<const GridT *>(kg->grid) + ((int64_t)k0 * kg->ny + jc) * kg->nx + ic;
+      const int64_t plane_in = (int64_t)kg->ny * kg->nx;
 #pragma unroll
-    for (int kk = 0; kk < TK; ++kk) held[kk] = column[(int64_t)(kk < kcount ? kk : kcount - 1) * plane_in];
+      for (int kk = 0; kk < TK; ++kk) held[kk] = column[(int64_t)(kk < kcount ? kk : kcount - 1) * plane_in];
 #pragma unroll
-    for (int kk = 0; kk < TK; ++kk) acc_set<BASE, TK>(kk, (double)held[kk]);
-  } else {
+      for (int kk = 0; kk < TK; ++kk) acc_set<BASE, TK>(kk, (double)held[kk]);
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < TK; ++kk) acc_set<BASE, TK>(kk, 0.0);
+      for (int kk = 0; kk < TK; ++kk) acc_set<BASE, TK>(kk, 0.0);
+    }
+  } else
+#endif
+  {
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      double v0 = 0.0;
+      if (kg->init_from_grid && lane_ok && kk < kcount)  // cu:211 accumulates onto what the grid holds
+        v0 = (double)static_cast<const GridT *>(kg->grid)[(((int64_t)(k0 + kk)) * kg->ny + j) * kg->nx + i];
+      acc_set<BASE, TK>(kk, v0);
+    }
   }
   if (COUNT) {
 #pragma unroll
