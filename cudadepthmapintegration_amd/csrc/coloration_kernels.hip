@@ -717,7 +717,7 @@ bool vertices_in_coherent_order(const double *p, int64_t n) {
       const double d = p[3 * a + q] - p[3 * b + q];
       s2 += d * d;
     }
-    return s2;  // (a NaN compares false everywhere below and sorts anywhere: the answer is a guess either way)
+    return std::isfinite(s2) ? s2 : 1.0e300;  // (a NaN / inf vertex: far from everything -- no NaN reaches the partial sort)
   };
   for (int64_t t = 0; t < samples; ++t) {
     const int64_t i = t * ((n - 1) / samples);
