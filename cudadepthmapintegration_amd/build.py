@@ -30,7 +30,10 @@ COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-ma
                 "-Wno-inline-asm", "-Wno-pass-failed"]
 # -disable-promote-alloca-to-vector: without it hipcc turns the tiled kernel's register accumulators into one
 # 32-register tuple that it spills and reloads whole (3000+ spill instructions at 4 waves per SIMD).
-HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector"]
+# -amdgpu-use-amdgpu-trackers: the scheduler measures register pressure with the AMDGPU-specific trackers; the tiled kernel's view
+# body, whose every change shows up as spill traffic, runs 3-4 % faster for it (cfg 3 speckle 13.72 -> 13.29 ms, dense 4.49 -> 4.33;
+# max-ilp scheduling and reversed local assignment cost 3-5 %: profiles/r18c_exp_llvm_flags.json)
+HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
 # DMI_TUNING=1 in the environment of the BUILD compiles the experiment switches of tools/ in (getenv-driven launch
 # geometry, dropped depth loads ...).  The default library contains none of them.
 if os.environ.get("DMI_EXP"):  # tools/gpu_exp.sh: "NAME:-DDMI_EXP_X=0 ..." -> build/obj_exp_NAME, libdmi_hip_exp_NAME.so

@@ -4,7 +4,7 @@
 OUT=${1:-/tmp/fast_fusion_tile.s}
 cd "$(dirname "$0")/../cudadepthmapintegration_amd/csrc" || exit 1
 hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-inline-asm -Wno-pass-failed -Wno-unused-function -DDMI_FAST_BUILD \
-  --offload-arch=gfx950 -mllvm -disable-promote-alloca-to-vector --cuda-device-only -S fusion_tile.hip -o "$OUT" 2>&1 | grep -v "hip-link" | head -20
+  --offload-arch=gfx950 -mllvm -disable-promote-alloca-to-vector -mllvm -amdgpu-use-amdgpu-trackers=1 --cuda-device-only -S fusion_tile.hip -o "$OUT" 2>&1 | grep -v "hip-link" | head -20
 python3 - "$OUT" <<'PY'
 import re, sys, collections
 text = open(sys.argv[1]).read()
