@@ -1174,6 +1174,17 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     }
     cfg.holes = mingled * 8 > strips ? 1 : 0;
   }
+  // ... and maps that are mostly EMPTY in large regions (a silhouette against nothing: a quarter of the pixels or more without a
+  // depth, the holes not mingled with depths): most (brick, view) pairs are skipped and a brick's fixed costs dominate
+  bool mostly_empty = false;
+  if (!cfg.holes) {
+    unsigned long long without = 0, pixels = 0;
+    for (const Batch &bt : ctx->batches) {
+      without += bt.holes;
+      pixels += (unsigned long long)bt.n * (unsigned long long)ctx->W * (unsigned long long)ctx->H;
+    }
+    mostly_empty = without * 4 >= pixels && pixels > 0;
+  }
   // Tile shape when the caller did not pick one: grids up to 512^3 do better with 8-voxel columns at five waves per
   // SIMD (more, smaller work items and a finer brick classification: 0.65 vs 0.74 ms at 256^3 x 64 views, 11.2 vs 11.5
   // ms at 512^3 x 256), 1024^3 with 16-voxel columns (15.5 vs 17.7 ms at 1024^3 x 64: the classification of twice as
@@ -1183,7 +1194,10 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // With holes in the depth maps (cfg.holes) most pairs are the FREE column's, whose voxels are cheap next to the set-up
     // of a (brick, view) pair: 16-voxel columns halve the set-ups per voxel and win from 256^3 on (cfg 2 -2.7 %, 384^3 -3.7 %,
     // cfg 3 -2.2 %, cfg 3 with VGA maps -5.6 %, cfg 4's share -5.7 %; 128^3 ties; dense cfg 3 +6.7 %: profiles/r08z_*)
-    if (bricks16 <= 32768 && !(cfg.holes && bricks16 >= 4096)) cfg.variant |= 7 << dmi::VAR_TILE_SHAPE_SHIFT;
+    // Mostly empty maps: 16-voxel columns from 384^3 on (sparse scene, round 4's last build: 512^3 x 256 views 2.36 -> 2.12 ms,
+    // 512^3 x 64 0.65 -> 0.57, 384^3 x 128 0.62 -> 0.59; 256^3 x 64 the other way, 0.13 -> 0.15: profiles/r18i_*, r18j_*)
+    if (bricks16 <= 32768 && !(cfg.holes && bricks16 >= 4096) && !(mostly_empty && bricks16 >= 13824))
+      cfg.variant |= 7 << dmi::VAR_TILE_SHAPE_SHIFT;
   }
 
   TileArgs t;
