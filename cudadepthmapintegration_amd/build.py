@@ -33,7 +33,52 @@ COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-ma
 # -amdgpu-use-amdgpu-trackers: the scheduler measures register pressure with the AMDGPU-specific trackers; the tiled kernel's view
 # body, whose every change shows up as spill traffic, runs 3-4 % faster for it (cfg 3 speckle 13.72 -> 13.29 ms, dense 4.49 -> 4.33;
 # max-ilp scheduling and reversed local assignment cost 3-5 %: profiles/r18c_exp_llvm_flags.json)
-HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector"]
+# hidden LLVM options: kept only where this hipcc knows them (probed once with an empty translation unit; a toolchain without
+# the option would abort every compile with "Unknown command line argument").  build_record.json lists the flags used.
+OPTIONAL_LLVM_FLAGS = ["-amdgpu-use-amdgpu-trackers=1"]
+
+
+def _probe_llvm_flag(flag: str) -> bool:
+    import tempfile
+
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "probe.hip")
+            with open(src, "w") as fh:
+                fh.write("__global__ void probe() {}\n")
+            r = subprocess.run([hipcc_path(), "--offload-arch=gfx950", "--cuda-device-only", "-mllvm", flag, "-c", src, "-o",
+                                os.path.join(tmp, "probe.o")], capture_output=True)
+            return r.returncode == 0
+    except (OSError, RuntimeError):
+        return False
+
+
+_FLAG_CACHE = os.path.join(ROOT, "build", "llvm_flag_probe.json")
+
+
+def _optional_flags() -> list:
+    import json
+
+    try:
+        version = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout
+    except (OSError, RuntimeError):
+        return []
+    try:
+        with open(_FLAG_CACHE) as fh:
+            rec = json.load(fh)
+        if rec.get("hipcc") == version and set(rec.get("flags", {})) == set(OPTIONAL_LLVM_FLAGS):
+            return [x for f in OPTIONAL_LLVM_FLAGS if rec["flags"][f] for x in ("-mllvm", f)]
+    except (OSError, ValueError):
+        pass
+    flags = {f: _probe_llvm_flag(f) for f in OPTIONAL_LLVM_FLAGS}
+    try:
+        os.makedirs(os.path.dirname(_FLAG_CACHE), exist_ok=True)
+        with open(_FLAG_CACHE, "w") as fh:
+            json.dump({"hipcc": version, "flags": flags}, fh)
+    except OSError:
+        pass
+    return [x for f in OPTIONAL_LLVM_FLAGS if flags[f] for x in ("-mllvm", f)]
 # DMI_TUNING=1 in the environment of the BUILD compiles the experiment switches of tools/ in (getenv-driven launch
 # geometry, dropped depth loads ...).  The default library contains none of them.
 if os.environ.get("DMI_EXP"):  # tools/gpu_exp.sh: "NAME:-DDMI_EXP_X=0 ..." -> build/obj_exp_NAME, libdmi_hip_exp_NAME.so
@@ -52,6 +97,9 @@ def hipcc_path() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: the HIP library cannot be built (no CPU fallback exists)")
+
+
+HIP_FLAGS = HIP_FLAGS + _optional_flags()
 
 
 def _sources():
@@ -246,7 +294,8 @@ def _record(mode: str) -> None:
     try:
         os.makedirs(OBJ_DIR, exist_ok=True)
         with open(os.path.join(OBJ_DIR, "build_record.json"), "w") as fh:
-            json.dump({"mode": mode, "library": os.path.relpath(LIB_PATH, ROOT), "digest": source_digest(), "time": time.time()}, fh)
+            json.dump({"mode": mode, "library": os.path.relpath(LIB_PATH, ROOT), "digest": source_digest(), "time": time.time(),
+                       "flags": COMMON_FLAGS + HIP_FLAGS}, fh)
     except OSError:
         pass
 

@@ -157,7 +157,8 @@ def load() -> ctypes.CDLL:
     L.dmi_fuse.argtypes = [vp]
     L.dmi_fuse_range.argtypes = [vp, i32, i32]
     L.dmi_fuse_slab.argtypes = [vp, i32, i32]
-    L.dmi_fuse_range_download.argtypes = [vp, i32, i32, vp, i32, i32]
+    if hasattr(L, "dmi_fuse_range_download"):  # (absent from an older prebuilt library loaded for an A/B timing, tools/gpu_exp.py)
+        L.dmi_fuse_range_download.argtypes = [vp, i32, i32, vp, i32, i32]
     L.dmi_synchronize.argtypes = [vp]
     L.dmi_download_grid_f64.argtypes = [vp, dp]
     L.dmi_download_grid_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -175,8 +176,9 @@ def load() -> ctypes.CDLL:
         L.dmi_get_window_pair_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     if hasattr(L, "dmi_get_upload_kernel_ms"):
         L.dmi_get_upload_kernel_ms.argtypes = [vp, dp, dp]
-        L.dmi_sizeof_info.restype = ctypes.c_size_t
-        L.dmi_sizeof_timings.restype = ctypes.c_size_t
+    for name in ("dmi_sizeof_info", "dmi_sizeof_timings"):
+        if hasattr(L, name):
+            getattr(L, name).restype = ctypes.c_size_t
     L.dmi_get_timings.argtypes = [vp, ctypes.POINTER(TimingsC)]
     L.dmi_get_info.argtypes = [vp, ctypes.POINTER(InfoC)]
     L.dmi_alloc_pinned.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -382,6 +384,10 @@ class FusionContext:
             out = np.empty(self.n_voxels, dtype=dtype)
         if out.dtype != np.dtype(dtype) or out.size != self.n_voxels or not out.flags.c_contiguous:
             raise ValueError("out must be a contiguous array of n_voxels elements of the requested dtype")
+        if not hasattr(self._lib, "dmi_fuse_range_download"):  # an older prebuilt library: the same bits, nothing overlapped
+            if count > 0:
+                self.fuse(int(first), int(count))
+            return self.download_grid(dtype, out)
         self._check(self._lib.dmi_fuse_range_download(self._h, int(first), int(count), ctypes.c_void_p(out.ctypes.data),
                                                       DMI_F64 if np.dtype(dtype) == np.float64 else DMI_F32, int(n_slabs)))
         return out.reshape(nz, ny, nx)

@@ -91,6 +91,8 @@ struct dmi_context {
   // tiled kernel (fusion_tile.hip): per-map records, the r22*wz(k) table, a device copy of FuseArgs
   std::vector<TileMapRec> h_tile_maps;
   TileMapRec *d_tile_maps = nullptr;
+  std::vector<dmi::WinRec> h_win_recs;  // per view: what the window form of the FREE column reads (one line each)
+  dmi::WinRec *d_win_recs = nullptr;
   double *d_cz_table = nullptr;
   size_t cz_table_capacity = 0;  // doubles
   FuseArgs *d_fuse_args = nullptr;
@@ -386,8 +388,11 @@ float float_not_below(double x) {
 // (TileMapRec::cpx ...), in two tiers (fusion_tile.hip).  P, Q, S: rows 0..2 of K*[R|T]; Sx, Sy: magnitudes of
 // the terms of h.x, h.y over the grid; M[2]: of c.z.
 void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4], const double Q[4], const double S[4],
-                       double Sx, double Sy, const double M[3], bool general, bool aligned, TileMapRec *out) {
+                       double Sx, double Sy, const double M[3], bool general, bool aligned, TileMapRec *out, dmi::WinRec *win) {
   TileMapRec &t = *out;
+  std::memset(win, 0, sizeof(*win));
+  win->e_abs = std::numeric_limits<float>::infinity();  // no windows unless everything below holds
+  win->c1 = dmi::kWinC1;
   t.t1_ok = 0;
   t.t1_e1 = std::numeric_limits<float>::infinity();
   t.t1_c1 = 0.5f - 0x1p-20f;
@@ -457,6 +462,48 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   if (!(pmax < 0x1p22) || !index_exact || !(e1 > 0x1p-100) || !(Sc < 0x1p60) || !std::isfinite(e1)) return;
   t.t1_e1 = float_not_below(e1);  // (per_lane: the part of e1 that does not depend on pmax)
   t.t1_ok = 1;
+  {
+    // The window form of the FREE column (WinRec, fusion_kernels.h).  Steps of the centred numerators and of c.z
+    // per voxel along i, j, k: the rows times the grid matrix's columns times the spacings (as cdhx above for k).
+    const double *sp = ctx->grid.spacing;
+    double d[3][2], c[3];
+    for (int ax = 0; ax < 3; ++ax) {
+      const double wxs = g[ax] * sp[ax], wys = g[4 + ax] * sp[ax], wzs = g[8 + ax] * sp[ax];
+      d[ax][0] = (Pc[0] * wxs + Pc[1] * wys) + Pc[2] * wzs;
+      d[ax][1] = (Qc[0] * wxs + Qc[1] * wys) + Qc[2] * wzs;
+      c[ax] = (S[0] * wxs + S[1] * wys) + S[2] * wzs;
+    }
+    // |hw_ref - model| <= cerr + Xmax * nl2: the centred numerator within cerr of the affine model anchored at the brick's first
+    // voxel (the budget of 4d.1 covers the anchor's FMA chain and seven steps each way: < 100 of its 512 ulp), the reference's
+    // c.z within nl2 of ITS model (two computed values, 8 ulp(M[2]) each, rotated grids twice that), times the window's origin
+    const double xmax = (double)(std::max(ctx->W, ctx->H) / 2 + dmi::kValidMargin + 1);
+    const double nl2 = 2.0 * nl;
+    const double pwin = 72.0;  // bounds an accepted candidate: |P| < |h| / z + 1/2 <= (kWindowRows - 1/2) * kWinCzRatio + 2
+    // the steps as the kernel forms them, fl32(d32 - X0 * c32): each within 2^-23 (|d| + |X0 c|) of the real one; a lane takes up
+    // to 7 along i and j and kMaxColumn - 1 along k
+    const double steps[3] = {7.0, 7.0, (double)(kMaxColumn - 1)};
+    double e_step = 0.0;
+    for (int xy = 0; xy < 2; ++xy) {
+      double e = 0.0;
+      for (int ax = 0; ax < 3; ++ax) e += steps[ax] * (std::fabs(d[ax][xy]) + xmax * std::fabs(c[ax]));
+      e_step = std::max(e_step, e * 0x1p-23);
+    }
+    double ew = (cerr + xmax * nl2) + e_step + pwin * nl2 + 0x1p-53 * std::max(Sx, Sy);
+    ew *= 1.0 + 0x1p-10;
+    bool ok = std::isfinite(ew) && ew > 0x1p-100 && ew < 0x1p60;
+    for (int ax = 0; ax < 3; ++ax) ok = ok && std::fabs(d[ax][0]) < 0x1p60 && std::fabs(d[ax][1]) < 0x1p60 && std::fabs(c[ax]) < 0x1p60;
+    if (ok) {
+      for (int xy = 0; xy < 2; ++xy) {
+        win->di[xy] = (float)d[0][xy];
+        win->dj[xy] = (float)d[1][xy];
+        win->dk[xy] = (float)d[2][xy];
+      }
+      win->ci[0] = (float)c[0]; win->ci[1] = (float)(c[0] * (double)dmi::kWinC1);
+      win->cj[0] = (float)c[1]; win->cj[1] = (float)(c[1] * (double)dmi::kWinC1);
+      win->ck[0] = (float)c[2]; win->ck[1] = (float)(c[2] * (double)dmi::kWinC1);
+      win->e_abs = float_not_below(ew);
+    }
+  }
   if (per_lane) {
     // the coefficient of pmax, rounded up, with one more factor (1 + 2^-10) for the roundings of the lane's own p
     const double B = (3.0 * 0x1p-24 * Dz + nl) * (1.0 + 0x1p-10) * (1.0 + 0x1p-10);
@@ -474,7 +521,7 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
 // pixel selection, and `err`, a bound on the absolute difference between the reference's computed
 // h.x / h.y and the kernel's affine evaluation anywhere in the grid (DESIGN.md "Tiled kernel: proof
 // obligations" derives the 73-ulp budget this bound covers seven times over).
-TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
+TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *win) {
   TileMapRec t;
   std::memset(&t, 0, sizeof(t));
   const double *rt = r.rt, *k = r.k;
@@ -552,7 +599,7 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r) {
   //                                  (Sz * r >= 1 - 2^-39).
   t.errk = (t.err + 65536.0 * t.errz) + 0x1p-22 * Sz * (1.0 + 0x1p-20);
   t.depth = r.depth;
-  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, general, aligned, &t);
+  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, general, aligned, &t, win);
   return t;
 }
 
@@ -616,7 +663,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     for (int q = 0; q < 12; ++q) finite = finite && bounded(r.k[q]) && bounded(r.rt[q]);
     const int km = classify_k(r.k, r.rt);
     if (km < ctx->k_mode) ctx->k_mode = km;
-    TileMapRec t = make_tile_rec(ctx, r);
+    dmi::WinRec wrec;
+    TileMapRec t = make_tile_rec(ctx, r, &wrec);
     t.valid = reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.valid_offset + (size_t)m * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H);
     t.vm_c0 = ((float)(ctx->H / 2 + dmi::kValidMargin) - 3.5f) * 0.125f;
     t.vm_w8 = (float)(8 * (ctx->W + 2 * dmi::kValidMargin) - 8);
@@ -629,6 +677,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     t.vb_mx = 0x4B400000 + dmi::kValidMargin + ctx->W / 2;
     t.vb_my = 0x4B400000 + dmi::kValidMargin + ctx->H / 2;
     ctx->h_tile_maps.push_back(t);
+    wrec.vbits = t.vbits;
+    ctx->h_win_recs.push_back(wrec);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);
     // pixel selection must be provable for nearly every lane: the error bounds over h.z must stay far below one pixel
@@ -704,7 +754,10 @@ int sync_maps(dmi_context *ctx) {
     if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
     ctx->d_tile_maps = nullptr;
     DMI_HIP(ctx, hipMalloc(&ctx->d_tile_maps, cap * sizeof(TileMapRec)));
-    ctx->device_bytes += (cap - ctx->d_maps_capacity) * (sizeof(MapRec) + sizeof(TileMapRec));
+    if (ctx->d_win_recs) (void)hipFree(ctx->d_win_recs);
+    ctx->d_win_recs = nullptr;
+    DMI_HIP(ctx, hipMalloc(&ctx->d_win_recs, cap * sizeof(dmi::WinRec)));
+    ctx->device_bytes += (cap - ctx->d_maps_capacity) * (sizeof(MapRec) + sizeof(TileMapRec) + sizeof(dmi::WinRec));
     ctx->d_maps_capacity = cap;
     ctx->maps_dirty = true;
   }
@@ -728,6 +781,7 @@ int sync_maps(dmi_context *ctx) {
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_maps, ctx->h_maps.data(), n * sizeof(MapRec), hipMemcpyHostToDevice, ctx->stream));
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_tile_maps, ctx->h_tile_maps.data(), n * sizeof(TileMapRec), hipMemcpyHostToDevice,
                                 ctx->stream));
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_win_recs, ctx->h_win_recs.data(), n * sizeof(dmi::WinRec), hipMemcpyHostToDevice, ctx->stream));
     // h_maps / h_tile_maps are pageable: the copies above are complete for the host when they return
     ctx->maps_dirty = false;
   }
@@ -902,6 +956,7 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_map_hits) (void)hipFree(ctx->d_map_hits);
   if (ctx->d_maps) (void)hipFree(ctx->d_maps);
   if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
+  if (ctx->d_win_recs) (void)hipFree(ctx->d_win_recs);
   if (ctx->d_cz_table) (void)hipFree(ctx->d_cz_table);
   if (ctx->d_wg_times) (void)hipFree(ctx->d_wg_times);
   if (ctx->d_queue_heads) (void)hipFree(ctx->d_queue_heads);
@@ -948,6 +1003,7 @@ int dmi_clear_views(dmi_context *ctx) {
   ctx->batches.clear();
   ctx->h_maps.clear();
   ctx->h_tile_maps.clear();
+  ctx->h_win_recs.clear();
   ctx->view_k_mode.clear();
   ctx->view_tile_ok.clear();
   ctx->max_tile_err = 0.0;
@@ -1306,11 +1362,11 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       // ... and behind that the window origins of the FREE column (TileArgs::win_origin), one word per class byte
       // (for depth maps with holes scattered all over them -- cfg.holes: what makes the FREE column the busiest one -- ; the
       // launch then runs the kernel's WIN instantiation, which pays for the window code in every column, fusion_tile.hip)
-      bool any_tier1 = false;  // (a launch none of whose views runs tier 1 has no window pair: the plain instantiation serves it)
-      for (int32_t m = first; m < first + count && !any_tier1; ++m) any_tier1 = ctx->h_tile_maps[(size_t)m].t1_ok != 0;
-      const bool windows = !cfg.general_k && !cfg.count_hits && !(cfg.variant & (dmi::VAR_NO_WINDOWS | dmi::VAR_NO_INTERIOR)) &&
+      bool any_tier1 = false;  // (a launch none of whose views has a window record has no window pair: the plain instantiation serves it)
+      for (int32_t m = first; m < first + count && !any_tier1; ++m) any_tier1 = std::isfinite(ctx->h_win_recs[(size_t)m].e_abs);
+      const bool windows = DMI_TIER1 != 0 && !cfg.general_k && !cfg.count_hits && !(cfg.variant & (dmi::VAR_NO_WINDOWS | dmi::VAR_NO_INTERIOR)) &&
                            (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS)) && any_tier1;
-      const size_t cbytes = coarse_end + (windows ? fine_bytes * 4 : 0);
+      const size_t cbytes = coarse_end + (windows ? fine_bytes * sizeof(dmi::WinPair) : 0);
       ctx->coarse_offset = fine_bytes;
       if (ctx->classes_capacity < cbytes) {
         if (ctx->d_classes) {
@@ -1328,8 +1384,13 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       }
       t.classes = ctx->d_classes;
       if (windows) {
-        t.win_origin = reinterpret_cast<uint32_t *>(ctx->d_classes + coarse_end);
-        t.win_delta = (int64_t)reinterpret_cast<intptr_t>(t.win_origin) - 4 * (int64_t)reinterpret_cast<intptr_t>(t.classes);
+        t.win_origin = reinterpret_cast<dmi::WinPair *>(ctx->d_classes + coarse_end);
+        t.win_delta = (int64_t)reinterpret_cast<intptr_t>(t.win_origin) - 16 * (int64_t)reinterpret_cast<intptr_t>(t.classes);
+        t.win_recs = ctx->d_win_recs;
+        t.vb_bytes = (int32_t)std::min<int64_t>(dmi::valid_bits_bytes(ctx->W, ctx->H), 0x7fffffff);
+        t.vb_rowskip = (dmi::valid_bits_tiles_x(ctx->W) - 1) * 128;
+        t.win_cx = dmi::kValidMargin + ctx->W / 2;
+        t.win_cy = dmi::kValidMargin + ctx->H / 2;
       }
       if (!(cfg.variant & dmi::VAR_SPATIAL_ORDER)) {
         const size_t n_slots = (size_t)t.super_x * t.super_y * t.super_z * 32;
@@ -1501,13 +1562,19 @@ int dmi_fuse_range_download(dmi_context *ctx, int32_t first, int32_t count, void
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range_download: null argument");
   if (out_dtype != DMI_F64 && out_dtype != DMI_F32) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range_download: out_dtype must be DMI_F32 or DMI_F64");
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  // the range is checked once, here, for both paths below; count == 0 is a plain download (no view need be resident)
+  const int32_t n_views = (int32_t)ctx->h_maps.size();
+  if (first < 0 || count < 0 || first > n_views || count > n_views - first)
+    return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_fuse_range_download: range outside the resident views");
   const int32_t nz = ctx->grid.cell_dims[2];
   const int32_t max_slabs = std::max(1, (nz + DMI_SLAB_ALIGNMENT - 1) / DMI_SLAB_ALIGNMENT);
   n_slabs = std::min(std::max(n_slabs, 1), max_slabs);
   if (out_dtype != ctx->opt.grid_dtype || n_slabs == 1) {
     // another type than the grid's: converted on the device after the whole fusion (dmi_download_grid_*), nothing overlaps
-    int rc = fuse_impl(ctx, first, count, 0, nz);
-    if (rc != DMI_OK) return rc;
+    if (count > 0) {
+      int rc = fuse_impl(ctx, first, count, 0, nz);
+      if (rc != DMI_OK) return rc;
+    }
     return out_dtype == DMI_F64 ? dmi_download_grid_f64(ctx, static_cast<double *>(out)) : dmi_download_grid_f32(ctx, static_cast<float *>(out));
   }
   { int rc_ = flush_zero_fill(ctx); if (rc_ != DMI_OK) return rc_; }
@@ -1532,14 +1599,22 @@ int dmi_fuse_range_download(dmi_context *ctx, int32_t first, int32_t count, void
         return rc;
       }
     }
-    DMI_HIP(ctx, hipEventRecord(ctx->slab_events[(size_t)i], ctx->stream));
-    DMI_HIP(ctx, hipStreamWaitEvent(ctx->download_stream, ctx->slab_events[(size_t)i], 0));
-    DMI_HIP(ctx, hipMemcpyAsync(static_cast<char *>(out) + (size_t)z0 * layer * gsz, static_cast<const char *>(ctx->d_grid) + (size_t)z0 * layer * gsz,
-                                (size_t)(z1 - z0) * layer * gsz, hipMemcpyDeviceToHost, ctx->download_stream));
+    // (a failure past the first queued copy: the copies in flight end before the caller sees the error, as above)
+    hipError_t he = hipEventRecord(ctx->slab_events[(size_t)i], ctx->stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ctx->download_stream, ctx->slab_events[(size_t)i], 0);
+    if (he == hipSuccess)
+      he = hipMemcpyAsync(static_cast<char *>(out) + (size_t)z0 * layer * gsz, static_cast<const char *>(ctx->d_grid) + (size_t)z0 * layer * gsz,
+                          (size_t)(z1 - z0) * layer * gsz, hipMemcpyDeviceToHost, ctx->download_stream);
+    if (he != hipSuccess) {
+      (void)hipStreamSynchronize(ctx->download_stream);
+      (void)hipGetLastError();
+      return fail(ctx, DMI_ERR_DEVICE, std::string("dmi_fuse_range_download: ") + hipGetErrorString(he));
+    }
     z0 = z1;
   }
   DMI_HIP(ctx, hipStreamSynchronize(ctx->download_stream));
   DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (this call's wall time: the slabs' fusions AND their copies, which overlap -- include/dmi.h says so)
   ctx->timings.last_download_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return drain_events(ctx);
@@ -1575,9 +1650,29 @@ int dmi_grid_device_pointer(dmi_context *ctx, void **ptr) {
   int rc = flush_zero_fill(ctx);
   if (rc != DMI_OK) return rc;
   *ptr = ctx->d_grid;
+  // whoever holds the pointer may write anything, a -0.0 included: later fusions keep the +0.0 adds of the pairs far behind
+  // every surface until the next dmi_reset_grid
+  ctx->grid_free_of_negative_zero = false;
   return DMI_OK;
   });
 }
+
+extern "C++" {
+namespace dmi {
+// dmi_multi's exchanges write SUMS of grids that hold no -0.0 into a context-owned grid ((+0) + (+0) = +0, and x + y = -0.0
+// only when both are): the invariant of 4b.6 survives them, so they take the pointer without giving it up.
+int grid_pointer_for_sums(dmi_context *ctx, void **ptr) {
+  return guarded(ctx, "grid_pointer_for_sums", [&]() -> int {
+  if (!ctx || !ptr) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "grid_pointer_for_sums: null argument");
+  DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
+  int rc = flush_zero_fill(ctx);
+  if (rc != DMI_OK) return rc;
+  *ptr = ctx->d_grid;
+  return DMI_OK;
+  });
+}
+}  // namespace dmi
+}  // extern "C++"
 
 namespace {
 int64_t n_points(const dmi_context *c) {

@@ -430,7 +430,7 @@ int peer_exchange(dmi_multi_context *m, bool by_slabs, std::vector<void *> &grid
     for (Rank &r : m->ranks) {
       DMI_M_HIP(m, hipSetDevice(r.device));
       if (by_slabs && r.n_views > 0) DMI_M_CTX(m, r, dmi_fuse_slab(r.ctx, m->slab_z[s], m->slab_n[s]));
-      if (!grids[(size_t)r.rank]) DMI_M_CTX(m, r, dmi_grid_device_pointer(r.ctx, &grids[(size_t)r.rank]));
+      if (!grids[(size_t)r.rank]) DMI_M_CTX(m, r, dmi::grid_pointer_for_sums(r.ctx, &grids[(size_t)r.rank]));
       DMI_M_HIP(m, hipEventRecord(r.slab_done[s], r.compute));
       DMI_M_HIP(m, hipStreamWaitEvent(r.comm, r.slab_done[s], 0));
     }
@@ -496,7 +496,7 @@ int download_impl(dmi_multi_context *m, T *out, int64_t *owned_first, int64_t *o
     for (Rank &r : m->ranks) {
       void *dptr = nullptr;
       DMI_M_CTX(m, r, dmi_synchronize(r.ctx));
-      DMI_M_CTX(m, r, dmi_grid_device_pointer(r.ctx, &dptr));
+      DMI_M_CTX(m, r, dmi::grid_pointer_for_sums(r.ctx, &dptr));
       DMI_M_HIP(m, hipSetDevice(r.device));
       const int64_t first = (int64_t)r.rank * per;
       if (grid_f64 == want_f64) {
@@ -832,7 +832,7 @@ int dmi_multi_fuse(dmi_multi_context *m) {
       if (exchange) {
         // the collective reads the grid whether or not this rank fused anything: the pointer call also settles a
         // deferred zero fill (a rank with no views contributes zeros)
-        if (r.n_views == 0 || !by_slabs) DMI_M_CTX(m, r, dmi_grid_device_pointer(r.ctx, &grids[i]));
+        if (r.n_views == 0 || !by_slabs) DMI_M_CTX(m, r, dmi::grid_pointer_for_sums(r.ctx, &grids[i]));
       }
     }
 
@@ -851,7 +851,7 @@ int dmi_multi_fuse(dmi_multi_context *m) {
           Rank &r = m->ranks[i];
           DMI_M_HIP(m, hipSetDevice(r.device));
           if (by_slabs && r.n_views > 0) DMI_M_CTX(m, r, dmi_fuse_slab(r.ctx, z0, zc));
-          if (!grids[i]) DMI_M_CTX(m, r, dmi_grid_device_pointer(r.ctx, &grids[i]));
+          if (!grids[i]) DMI_M_CTX(m, r, dmi::grid_pointer_for_sums(r.ctx, &grids[i]));
           DMI_M_HIP(m, hipEventRecord(r.slab_done[s], r.compute));
           DMI_M_HIP(m, hipStreamWaitEvent(r.comm, r.slab_done[s], 0));
         }

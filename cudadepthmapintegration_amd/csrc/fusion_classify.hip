@@ -704,14 +704,18 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
 // Windows of the FREE column (fusion_tile.hip): for every pair of class MIXED_FREE_OR_NODEPTH the footprint of the BRICK (the
 // class may have come down from its box unrefined), as proven by box_footprint (4b.2, 4b.9): every voxel's reference pixel lies
 // in [rx0, rx1] x [ry0, ry1], inside the image or its margin.  Where that rectangle fits a window of kWindowCols x kWindowRows
-// pixels and the view runs tier 1, the pair's origin is written and its class byte marked; every other pair keeps the gathering
-// column.  A wave is 64 consecutive bricks and walks over kOriginViews views, four class bytes per load; the view is
+// pixels, the view has a window record (WinRec::e_abs finite) and c.z varies by less than kWinCzRatio over the brick, the pair's
+// WinPair is written and its class byte marked; every other pair keeps the gathering column.  WinPair (round 5): the window's
+// first pixel and, in fp64 rounded once to fp32, the window-relative numerators hw = h'' - X0 * c.z and c.z at the brick's
+// voxel (0, 0, 0) -- h'' by the FMA chain over the centred rows (TileMapRec::cpx ...) at that voxel's computed world position,
+// c.z in the reference's order (cu:90-92, cu:172), exactly as the fusion kernel's fp64 tier forms them.
+// A wave is 64 consecutive bricks and walks over kOriginViews views, four class bytes per load; the view is
 // wave-uniform, so its camera record arrives through scalar loads (as in the fine pass), and the lanes that have the class are
 // neighbours in space: all of them or none, mostly.
 constexpr int kOriginViews = 32;  // views per workgroup (a multiple of 4) on large grids; fewer on small ones (launch_window_origins)
 template <bool ROT>
 __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, const MapRec *__restrict__ maps, int tk,
-                                                            uint8_t *__restrict__ classes, uint32_t *__restrict__ origins,
+                                                            uint8_t *__restrict__ classes, WinPair *__restrict__ origins,
                                                             int group_views) {
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
@@ -725,6 +729,14 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
   const int64_t row = (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch;
   // (a brick that sticks out of the top of the grid takes the column with every test, fusion_tile.hip: no window for it)
   const bool eligible = exists && bz * tk + tk <= a.nz;
+  // world position of the brick's voxel (0, 0, 0), as the fusion kernel computes it (cu:78-83, cu:168)
+  double wxa, wya, wza;
+  {
+    const double gx = a.ox + (bx * 8 + 0.5) * a.sx;
+    const double gy = a.oy + (by * 8 + 0.5) * a.sy;
+    const double gz = a.oz + ((bz * tk + a.kz0) + 0.5) * a.sz;
+    wxa = row4(a.g + 0, gx, gy, gz), wya = row4(a.g + 4, gx, gy, gz), wza = row4(a.g + 8, gx, gy, gz);
+  }
   // views [m_lo, m_hi) of this workgroup, in groups of four that start at multiples of 4 (the rows are 64-byte aligned)
   const int m_begin = a.first_map, m_end = a.first_map + a.n_maps;
   const int g_lo = (m_begin & ~3) + blockIdx.y * group_views;
@@ -739,7 +751,7 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
       if (__builtin_amdgcn_ballot_w64(want) == 0) continue;  // wave-uniform
       const MapRec *src = maps + m;
       const TileMapRec *tsrc = a.tile_maps + m;
-      if (!cload(&tsrc->t1_ok)) {  // the view does not run tier 1 (wave-uniform): no window, the class bits stay as they are
+      if (!(cload(&a.win_recs[m].e_abs) < __builtin_inff())) {  // the view has no windows (wave-uniform): the class bits stay as they are
         if (want) c4 &= ~((uint32_t)CLASS_HAS_WINDOW << (8 * q));
         continue;
       }
@@ -756,8 +768,20 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
       if (want) {
         const BoxFootprint fp = box_footprint_k<ROT, false>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
         const bool inside = fp.query || (fp.partial && fp.in_margin);
-        if (inside && fp.rx1 - fp.rx0 < kWindowCols && fp.ry1 - fp.ry0 < kWindowRows) {
-          origins[row + m] = (uint32_t)(fp.rx0 + kValidMargin) | ((uint32_t)(fp.ry0 + kValidMargin) << 16);
+        // (czmin > 0 comes with `inside`: box_footprint asks for czmin > 4 err; on a rotated grid the range is the widened one)
+        if (inside && fp.rx1 - fp.rx0 < kWindowCols && fp.ry1 - fp.ry0 < kWindowRows && fp.czmin > 0.0 &&
+            fp.czmax <= kWinCzRatio * fp.czmin) {
+          const double cza = row4(mr_u.rt + 8, wxa, wya, wza);  // cu:172 row 2 at the brick's first voxel, the reference's order
+          const double hxa = __builtin_fma(cload(&tsrc->cpx), wxa, __builtin_fma(cload(&tsrc->cpy), wya, __builtin_fma(cload(&tsrc->cpz), wza, cload(&tsrc->cp0))));
+          const double hya = __builtin_fma(cload(&tsrc->cqx), wxa, __builtin_fma(cload(&tsrc->cqy), wya, __builtin_fma(cload(&tsrc->cqz), wza, cload(&tsrc->cq0))));
+          // the window's first pixel counted from the image centre (integers: exact)
+          const double x0c = (double)(fp.rx0 - a.W / 2), y0c = (double)(fp.ry0 - a.H / 2);
+          WinPair wp;
+          wp.origin = (uint32_t)(fp.rx0 + kValidMargin) | ((uint32_t)(fp.ry0 + kValidMargin) << 16);
+          wp.ax = (float)(hxa - x0c * cza);
+          wp.ay = (float)(hya - y0c * cza);
+          wp.acz = (float)cza;
+          origins[row + m] = wp;
           flag = CLASS_HAS_WINDOW;
         }
         c4 = (c4 & ~((uint32_t)CLASS_HAS_WINDOW << (8 * q))) | (flag << (8 * q));

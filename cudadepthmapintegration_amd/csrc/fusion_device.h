@@ -13,6 +13,15 @@ __device__ __forceinline__ double row4(const double *__restrict__ m, double x, d
   return ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
 }
 
+// ---- a voxel's fp64 sum as the grid stores it.  An f32 grid rounds once per launch; a tiny negative sum would round to
+// -0.0f, and a later fusion onto this grid relies on "no sum is -0.0" to drop the +0.0 adds of the pairs far behind every
+// surface: x + 0.0f is x for every other x and +0.0f for both zeros (not foldable without fast-math).
+template <typename GridT>
+__device__ __forceinline__ GridT stored_sum(double acc) {
+  if constexpr (sizeof(GridT) == 4) return (GridT)acc + (GridT)0.0f;
+  else return (GridT)acc;
+}
+
 // ---- rayPotential<double>, cu:105-120 --------------------------------------------------------
 // sign = diff != 0 ? (int)(diff/|diff|) : 0 is +1, -1 or 0 and rho*sign one of three host-computed
 // products (FuseArgs::rho_pos / rho_neg / rho_zero), so no division is needed on the device.

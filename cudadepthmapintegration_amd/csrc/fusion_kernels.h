@@ -8,7 +8,13 @@
 #include <stdint.h>
 #include <string.h>
 
+struct dmi_context;  // include/dmi.h
+
 namespace dmi {
+
+// The grid's device pointer for a writer that stores sums of grids free of -0.0 (dmi_multi.hip's exchanges): unlike
+// dmi_grid_device_pointer it leaves the context's "no sum is -0.0" bookkeeping alone (dmi_capi.hip)
+int grid_pointer_for_sums(::dmi_context *ctx, void **ptr);
 
 // One depth map as the general kernel (and the exact fallback of the tiled kernel) reads it.  The loop
 // index over maps is wave-uniform, so a record arrives through scalar loads into SGPRs: no VGPRs, no LDS.
@@ -133,6 +139,32 @@ constexpr int kWindowCols = 32, kWindowRows = 64;
 constexpr uint8_t CLASS_HAS_WINDOW = 0x20;
 static_assert(sizeof(TileMapRec) == 368, "TileMapRec layout");
 
+// What the window form of the FREE column needs of a view (round 5): ONE 64-byte line, all fp32, fetched with one scalar load per
+// (brick, view) -- the 368-byte TileMapRec took five or six dependent batches of them, which with four waves per SIMD was what
+// the column waited for.  The centred numerators hx'', hy'' (TileMapRec::cpx ...) and c.z are affine in the voxel's indices; the
+// column works in coordinates relative to the WINDOW's first pixel X0 = (x0'', y0''), hw = h'' - X0 * c.z, whose value at the
+// brick's first voxel window_origin_kernel has formed in fp64 (WinPair): |hw| <= (window size + 1) * c.z, so every fp32 rounding
+// on the way costs 2^-24 of some sixty c.z instead of 2^-24 of up to W/2 c.z.  d*: steps of (hx'', hy'') per
+// voxel along i, j, k; c*: (step of c.z, c1 times it) -- the second half steps the acceptance threshold c1 * c.z - e_abs.
+struct alignas(64) WinRec {
+  const uint32_t *vbits;  // TileMapRec::vbits
+  float di[2], dj[2], dk[2];
+  float ci[2], cj[2], ck[2];
+  float e_abs;            // the absolute part of the margin (rounded up); +inf: the view has no windows
+  float c1;               // kWinC1
+};
+static_assert(sizeof(WinRec) == 64, "WinRec is one cache line");
+constexpr float kWinC1 = 0.5f - 0x1p-14f;  // what is left of 1/2 after every c.z-proportional rounding of the window column (4e.6)
+// the brick's c.z may vary by this factor at most for the pair to get a window (bounds |hw| by the threshold's own c.z)
+constexpr double kWinCzRatio = 1.0 + 1.0 / 16.0;
+// Per windowed (brick, view) pair, TileArgs::win_origin[brick * class_pitch + view]: the window's first pixel (padded-image
+// coordinates, x0 | y0 << 16) and the fp32 images of hw.x, hw.y and c.z at voxel (0, 0, 0) of the brick
+struct alignas(16) WinPair {
+  uint32_t origin;
+  float ax, ay, acz;
+};
+static_assert(sizeof(WinPair) == 16, "WinPair layout");
+
 // How much of K's structure the uploaded views share; checked on the host, value-identical
 // shortcuts proven in DESIGN.md ("K specialisation").
 enum KMode : int {
@@ -219,12 +251,16 @@ struct TileArgs {
   int64_t wg_times_n;
   // brick counters of the persistent workgroups, one per XCD at [16 * xcd]; zeroed by the table kernel of every launch
   int32_t *queue_heads;
-  // Windows of the FREE column (round 4): for a pair whose class byte carries CLASS_HAS_WINDOW, win_origin[brick * class_pitch +
-  // view] = x0 | y0 << 16, the first pixel (padded-image coordinates) of a kWindowCols x kWindowRows window that holds the
-  // reference's pixel of every voxel of the brick (window_origin_kernel, fusion_classify.hip).  The fusion kernel reaches the
-  // entry from the brick's class row: (uint32_t *)(win_delta + 4 * (intptr_t)row) + view, win_delta = win_origin - 4 * classes.
-  uint32_t *win_origin;
-  int64_t win_delta;
+  // Windows of the FREE column (round 4; WinPair since round 5): for a pair whose class byte carries CLASS_HAS_WINDOW,
+  // win_origin[brick * class_pitch + view] holds the first pixel of a kWindowCols x kWindowRows window that holds the reference's
+  // pixel of every voxel of the brick, and the window-relative numerators at the brick's first voxel (window_origin_kernel,
+  // fusion_classify.hip).  The fusion kernel reaches the entry from the brick's class row: (WinPair *)(win_delta + 16 *
+  // (intptr_t)row) + view.
+  WinPair *win_origin;
+  int64_t win_delta;  // = win_origin - 16 * classes (as integers): the pair table is indexed like the class table
+  const WinRec *win_recs;  // [n_views]
+  int32_t vb_bytes, vb_rowskip;  // as TileMapRec's (the same for every view of a context)
+  int32_t win_cx, win_cy;        // kValidMargin + W / 2, kValidMargin + H / 2: the image centre in padded coordinates
 };
 constexpr int kFreeSumsMax = 4096;
 // an entry of TileArgs::order: the workgroup brick (bx, by, bz), 11 + 11 + 10 bits (checked on the host)

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs a) {
   }
 
   if (inside) {
-    grid[gid] = (GridT)acc;
+    grid[gid] = stored_sum<GridT>(acc);
     if (COUNT) a.voxel_hits[gid] += nhit;
   }
 }

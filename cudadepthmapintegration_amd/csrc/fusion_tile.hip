@@ -39,6 +39,13 @@
 #include "fusion_kernels.h"
 #include "fusion_device.h"
 
+// Experiment switches that produce WRONG results exist for timing runs only (tools/exp_list*.txt): they compile in a tuning
+// build (DMI_TUNING, a library of its own) and nowhere else.
+#if !defined(DMI_TUNING) && (defined(DMI_EXP_SKIP_WINDOW_VIEWS) || defined(DMI_EXP_SAME_REC) || defined(DMI_EXP_NO_WINDOW_LOADS) || \
+                             defined(DMI_EXP_NO_LANE_MARGIN))
+#error "a DMI_EXP_* switch that changes results was defined without DMI_TUNING"
+#endif
+
 namespace dmi {
 
 int tile_shape_index(int variant);
@@ -120,6 +127,36 @@ __device__ __forceinline__ f32x2 pk_fma_lo_s(f32x2 a, f32x2 b, unsigned long lon
 __device__ __forceinline__ f32x2 pk_sub_s(f32x2 a, unsigned long long c_bits) {
   f32x2 d;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "s"(c_bits));
+  return d;
+}
+// a.lo * b + c on both halves, a = a pair of per-lane floats of which only the low one is read, c = a wave-uniform pair (SGPRs)
+__device__ __forceinline__ f32x2 pk_fma_lo0_vs(f32x2 a, f32x2 b, unsigned long long c_bits) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "s"(c_bits));
+  return d;
+}
+// a.hi * b + c on both halves (only the high float of a is read)
+__device__ __forceinline__ f32x2 pk_fma_hi0_vv(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// a.lo * b + c on both halves, b = a wave-uniform pair of floats (SGPRs)
+__device__ __forceinline__ f32x2 pk_fma_lo0_sv(f32x2 a, unsigned long long b_bits, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "s"(b_bits), "v"(c));
+  return d;
+}
+// a.hi * b + c on both halves, b = a wave-uniform pair of floats (SGPRs)
+__device__ __forceinline__ f32x2 pk_fma_hi0_sv(f32x2 a, unsigned long long b_bits, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "s"(b_bits), "v"(c));
+  return d;
+}
+// c - a * b.lo on both halves, b = a wave-uniform pair of floats (SGPRs) of which only the low one is read
+__device__ __forceinline__ f32x2 pk_fnma_slo(f32x2 a, unsigned long long b_bits, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(b_bits), "v"(c));
   return d;
 }
 // max(|a|, |b|) as ONE instruction (a C expression may pay a canonicalising v_max first)
@@ -493,14 +530,19 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // window origins of this brick's views (TileArgs::win_origin), 64 views at a time: lane l holds the entry of view
   // 64 * org_block + l -- one coalesced load per 64 views instead of a dependent scalar load per view (the table is read
   // once: every entry comes from HBM)
-  [[maybe_unused]] uint32_t org_vec = 0;
+  // (round 5: WinPair entries of 16 bytes, 32 views at a time: lane l holds dwords 2l and 2l + 1 of the block's 128, i.e. view v's
+  // origin and a.x in lane 2 (v & 31), its a.y and a.cz in the next lane)
+  [[maybe_unused]] uint32_t pair_a = 0, pair_b = 0;
   for (int wbase = first_map & ~7; wbase < m_end; wbase += 8) {
     if constexpr (WIN) {
-      if ((wbase & 56) == 0 || wbase == (first_map & ~7)) {  // wave-uniform: the first word of a block of 64 views, or of the fusion
+      if ((wbase & 24) == 0 || wbase == (first_map & ~7)) {  // wave-uniform: the first word of a block of 32 views, or of the fusion
         const kernarg_t ko = KFRESH();
         if (ko->win_origin) {
-          const uint32_t *row = reinterpret_cast<const uint32_t *>(ko->win_delta + 4 * (int64_t)reinterpret_cast<intptr_t>(crow));
-          org_vec = row[(wbase & ~63) + lane];
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 *row = reinterpret_cast<const u32x2 *>(ko->win_delta + 16 * (int64_t)reinterpret_cast<intptr_t>(crow));
+          const u32x2 pr = row[2 * (wbase & ~31) + lane];
+          pair_a = pr.x;
+          pair_b = pr.y;
         }
       }
     }
@@ -571,46 +613,61 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #endif
     if constexpr (WIN) {
       if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
-#ifdef DMI_EXP_SKIP_WINDOW_VIEWS  // timing experiment (wrong results): what everything but the window views costs
-        continue;
-#endif
 #ifdef DMI_TUNING
         ++dbg_win;
         if (dbg_cols == dbg_win) ++dbg_win_early;
 #endif
-        const kernarg_t kw = KFRESH();
-#ifdef DMI_EXP_SAME_REC  // timing experiment (wrong results): every view reads the first view's record
-        const TileMapRec *rec = kw->tile_maps + first_map;
-#else
-        const TileMapRec *rec = kw->tile_maps + m;
-#endif
-        const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)org_vec, m & 63);
+        // the pair's entry (WinPair): four dwords out of the two lane-held vectors
+        const int pl = (m & 31) * 2;
+        const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)pair_a, pl);
+        const unsigned long long A2 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pair_b, pl) |
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pair_a, pl + 1) << 32);
+        const float acz = __int_as_float(__builtin_amdgcn_readlane((int)pair_b, pl + 1));
         const int x0p = (int)(org & 0xffffu), y0p = (int)(org >> 16);
-        const __amdgpu_buffer_rsrc_t brsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cload(&rec->vbits)), (short)0, cload(&rec->vb_bytes), 0x00020000);
+        // the view's window record: ONE line through one scalar load (WinRec, fusion_kernels.h)
+        const kernarg_t kw = KFRESH();
+        typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+        const u32x16 R = *reinterpret_cast<const u32x16 __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(kw->win_recs + m));
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<uint32_t *>((uintptr_t)R[0] | ((uintptr_t)R[1] << 32)), (short)0, kw->vb_bytes, 0x00020000);
         // byte offset of row Y's dword in tile column tx: ((Y >> 5) * tiles_x + tx) * 128 + (Y & 31) * 4
         const unsigned lin = ((unsigned)lane << 2) + ((unsigned)y0p << 2);
-        const unsigned off = __umul24(lin >> 7, (unsigned)cload(&rec->vb_rowskip)) + lin + (((unsigned)x0p >> 5) << 7);
-#ifdef DMI_EXP_NO_WINDOW_LOADS  // timing experiment (wrong results): no loads, the window's bits come from the addresses
-        const uint32_t w_lo = off * 0x9e3779b9u, w_hi = ~w_lo;
-#else
+        const unsigned off = __umul24(lin >> 7, (unsigned)kw->vb_rowskip) + lin + (((unsigned)x0p >> 5) << 7);
         const uint32_t w_lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)off, 0, 0);
         const uint32_t w_hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)(off + 128u), 0, 0);
-#endif
-        // the floats 1.5 * 2^23 - (origin - centre), x in the low word, y in the high one
-        const unsigned long long M2 =
-            (unsigned long long)(unsigned)(cload(&rec->vb_mx) - x0p) | ((unsigned long long)(unsigned)(cload(&rec->vb_my) - y0p) << 32);
-        // fp64 values at the column's first voxel: the centred h.x, h.y (TileMapRec::cpx ...) and the exact c.z (cu:92, cu:172),
-        // as every tier-1 column starts from them; formed again by the redo below, so that they do not stay live
+        // the window's first pixel counted from the image centre
+        const int x0c = x0p - kw->win_cx, y0c = y0p - kw->win_cy;
+        // ---- set-up, all fp32: the window-relative numerators hw = h'' - X0 * c.z, c.z and the acceptance
+        // threshold are affine in (lane.x, lane.y, kk); their values at the brick's first voxel come with the pair (A2, acz), the
+        // steps with the view: Bw = d - X0 * c per axis, then two packed FMAs along i and j
+        f32x2 O, LJ;
+        O.x = (float)x0c;
+        O.y = (float)y0c;
+        LJ.x = (float)(lane & 7);
+        LJ.y = (float)(lane >> 3);
+        auto pair_of = [&](int q) __attribute__((always_inline)) { return (unsigned long long)R[q] | ((unsigned long long)R[q + 1] << 32); };
+        auto vec_of = [&](int q) __attribute__((always_inline)) {
+          f32x2 v;
+          v.x = __uint_as_float(R[q]);
+          v.y = __uint_as_float(R[q + 1]);
+          asm volatile("" : "+v"(v));  // wave-uniform, but a VGPR operand below (one scalar operand per instruction)
+          return v;
+        };
+        const f32x2 Bwi = pk_fnma_slo(O, pair_of(8), vec_of(2));
+        const f32x2 Bwj = pk_fnma_slo(O, pair_of(10), vec_of(4));
+        const f32x2 DH = pk_fnma_slo(O, pair_of(12), vec_of(6));
+        const f32x2 H0 = pk_fma_hi0_vv(LJ, Bwj, pk_fma_lo0_vs(LJ, Bwi, A2));
+        f32x2 CA;  // (c.z, threshold) at the brick's first voxel: thr = c1 * c.z - e_abs
+        CA.x = acz;
+        CA.y = __builtin_fmaf(acz, __uint_as_float(R[15]), -__uint_as_float(R[14]));
+        const f32x2 C0 = pk_fma_hi0_sv(LJ, pair_of(10), pk_fma_lo0_sv(LJ, pair_of(8), CA));
+        const f32x2 DC = vec_of(12);
+        const unsigned long long M2 = 0x4B4000004B400000ull;  // (1.5 * 2^23, 1.5 * 2^23)
+        // fp64 values at the column's first voxel for the redo below: the centred h.x, h.y (TileMapRec::cpx ...) and the exact
+        // c.z (cu:92, cu:172), as every tier-1 column starts from them
         auto first_voxel = [&](double &hxf, double &hyf, double &czf64) __attribute__((always_inline)) {
-          // (a view of the argument block of its own: with the caller's, the record loads of the whole set-up became one batch,
-          // 40 scalar registers at once, and the kernel 1.7 % slower for the spill traffic: profiles/r10l)
           const kernarg_t kf = KFRESH();
-#ifdef DMI_EXP_SAME_REC
-          const TileMapRec *rf = kf->tile_maps + first_map;
-#else
           const TileMapRec *rf = kf->tile_maps + m;
-#endif
           double wxf = wx, wyf = wy, wzf = wz0;
           if constexpr (ROT) {
             const czvec4 b = cload(reinterpret_cast<const czvec4 *>(kf->cz_table + (int64_t)k0 * 4));
@@ -619,41 +676,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           } else {
             czf64 = ((cload(&rf->rz0) * wx + cload(&rf->rz1) * wy) + cload(kf->cz_table + (int64_t)m * kf->kpad + k0)) + cload(&rf->rz3);
           }
-          // (one row of the record at a time: fetched in one batch, the set-up's loads need forty scalar registers at once and
-          // the long-lived values around them go to spill lanes and back -- a dozen vector instructions per pair)
-          __builtin_amdgcn_sched_barrier(0);
           hxf = __builtin_fma(cload(&rf->cpx), wxf, __builtin_fma(cload(&rf->cpy), wyf, __builtin_fma(cload(&rf->cpz), wzf, cload(&rf->cp0))));
-          __builtin_amdgcn_sched_barrier(0);
           hyf = __builtin_fma(cload(&rf->cqx), wxf, __builtin_fma(cload(&rf->cqy), wyf, __builtin_fma(cload(&rf->cqz), wzf, cload(&rf->cq0))));
-          __builtin_amdgcn_sched_barrier(0);
         };
-        f32x2 H0, C0, DH, DC;
-        {
-          double hxf, hyf, czf64;
-          first_voxel(hxf, hyf, czf64);
-          const float czf = (float)czf64;
-          H0.x = (float)hxf;
-          H0.y = (float)hyf;
-          // threshold at the first voxel: c1 * c.z - (e_abs + e_rel * HB), HB >= |hx''|, |hy''| anywhere in this column (4d)
-          const float hb = max_abs(H0.x, H0.y) + cload(&rec->t1_hspan);
-          float e1 = cload(&rec->t1_e1);
-#ifndef DMI_EXP_NO_LANE_MARGIN  // timing experiment (wrong for views with t1_ok == 2): what the branch costs the other views
-    #ifndef DMI_EXP_NO_LANE_MARGIN
-      if (cload(&rec->t1_ok) == 2) e1 = t1_lane_margin<TK>(czf, cload(&rec->t1_dcz), hb, e1, cload(&rec->t1_b));  // wave-uniform
-#endif
-#endif
-          const float thr = __builtin_fmaf(czf, cload(&rec->t1_c1), -__builtin_fmaf(hb, cload(&rec->t1_erel), e1));
-          // (lanes outside the grid own no voxel -- their sums are never stored -- and run like any other: their world position
-          // is as finite as their neighbours'; one of them not accepted costs a redo that adds to a sum nobody reads)
-          C0.x = czf;
-          C0.y = thr;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        DH.x = cload(&rec->t1_dhx);
-        DH.y = cload(&rec->t1_dhy);
-        DC.x = cload(&rec->t1_dcz);
-        DC.y = cload(&rec->t1_dthr);
-        asm volatile("" : "+v"(DH), "+v"(DC));  // wave-uniform, but VGPR operands of the packed FMAs: placed there once per view
         uint32_t undecided = 0, und_kk = 0;  // per lane / wave-uniform: bit kk = voxel kk is redone after the column
         uint32_t window = 0;                 // this lane's row of the window
         constexpr int WG = 4;                // voxels per group
@@ -745,8 +770,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           const double chk = __builtin_fma(cload(&r2->cerrk), r, __builtin_fmax(__builtin_fabs(fu), __builtin_fabs(fv)));
           const bool p2 = mine && chk < 0.5 && __builtin_fabs(e0) < tiny;
           // a proven pixel is the reference's and lies in the window; column and row within it: the centred pixel minus the
-          // window's first one, 0x4B400000 - (a word of M2).  The other lanes' look-up is not used.
-          const int col = cvt_saturating(ru2) + ((int)(unsigned)M2 - 0x4B400000), row = cvt_saturating(rv2) + ((int)(unsigned)(M2 >> 32) - 0x4B400000);
+          // window's first one.  The other lanes' look-up is not used.
+          const int col = cvt_saturating(ru2) - x0c, row = cvt_saturating(rv2) - y0c;
           const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(row << 2, (int)window);
           double val = free_space;  // 4b.8: every voxel of the pair with a depth accumulates -eta*rho (cu:115)
           bool hit = p2 && ((word >> (col & 31)) & 1u);
@@ -1280,7 +1305,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // profiles/r05k_exp_nt_grid_store.json, r05l_traffic_nt_grid_store.json).  One workgroup per brick (few views,
         // or multi-wave workgroups): neighbours are dispatched together and their pieces DO merge into whole lines --
         // non-temporal stores made 1024^3 x 64 views 12-20 % slower (profiles/r05o_exp_nt_grid_store_by_size.json).
-        const GridT sum = (GridT)acc_get<BASE, TK>(kk);
+        const GridT sum = stored_sum<GridT>(acc_get<BASE, TK>(kk));
         if constexpr (PERSIST)
           __builtin_nontemporal_store(sum, &grid[gid]);
         else
@@ -1377,11 +1402,18 @@ template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0, cfg.general_k != 0);
   // a launch with window origins (dmi_capi.hip: maps with scattered holes, no hit counters, pinhole views): the WIN instantiations
+  // (a -DDMI_TIER1=0 build has no window column: the host allocates no origins then, dmi_capi.hip)
+#if DMI_TIER1
   const bool win = a.win_origin != nullptr && !cfg.count_hits && !cfg.general_k;
+#define DMI_WIN_SHAPE(...) launch_shape<__VA_ARGS__>(a, cfg, s)
+#else
+  const bool win = false;
+#define DMI_WIN_SHAPE(...) hipErrorInvalidValue
+#endif
 #ifdef DMI_FAST_BUILD  // development builds (seconds instead of minutes): the two default shapes, axis-aligned grid, pinhole views
   if (win) {
-    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, false, false, true>(a, cfg, s);
-    return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, false, true>(a, cfg, s);
+    if (shape == 7) return DMI_WIN_SHAPE(DepthT, GridT, 8, 1, 1, 6, 8, false, false, true);
+    return DMI_WIN_SHAPE(DepthT, GridT, 16, 1, 1, 5, 8, false, false, true);
   }
   if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
@@ -1396,8 +1428,8 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   }
   if (a.rotated) {  // rotated grid: the two default shapes
     if (win) {
-      if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true, false, true>(a, cfg, s);
-      return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true, false, true>(a, cfg, s);
+      if (shape == 7) return DMI_WIN_SHAPE(DepthT, GridT, 8, 1, 1, 6, 8, true, false, true);
+      return DMI_WIN_SHAPE(DepthT, GridT, 16, 1, 1, 5, 8, true, false, true);
     }
     if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true>(a, cfg, s);
@@ -1414,8 +1446,8 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     }
   }
   if (win && (shape == 7 || shape == 0)) {
-    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, false, false, true>(a, cfg, s);
-    return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, false, true>(a, cfg, s);
+    if (shape == 7) return DMI_WIN_SHAPE(DepthT, GridT, 8, 1, 1, 6, 8, false, false, true);
+    return DMI_WIN_SHAPE(DepthT, GridT, 16, 1, 1, 5, 8, false, false, true);
   }
   // 80 + 16 = 96 VGPRs: 5 waves; the whole column is one load group (8 gathers in flight before the first is consumed);
   // one wave per workgroup: an 8 x 8 x 8 brick is the unit of scheduling and of the heaviest-first order
@@ -1423,6 +1455,7 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight); one wave per workgroup
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
 #endif
+#undef DMI_WIN_SHAPE
 }
 
 }  // namespace

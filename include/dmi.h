@@ -102,7 +102,8 @@ typedef struct dmi_timings {
   double total_fuse_kernel_ms;
   uint64_t fuse_launches;
   double last_upload_ms; /* host wall time of the last dmi_add_views (copy + convert, synchronised) */
-  double last_download_ms;
+  double last_download_ms; /* host wall time of the last download; for dmi_fuse_range_download the whole call: its slabs' fusions
+                              and their copies, which overlap */
   double last_cell_to_point_ms; /* hipEvent time of the last dmi_cell_to_point kernel */
   /* of last_fuse_kernel_ms / total_fuse_kernel_ms, the fusion kernel proper (without the brick classification, the window
    * origins and the workgroup ordering that precede it).  A launch without brick classes -- at most 1024 bricks and fewer than 48
@@ -250,7 +251,9 @@ size_t dmi_sizeof_timings(void);
 
 /* hipEvent time of the upload pass (the one kernel per staged chunk that thresholds, flips and narrows the tables and builds the
  * pyramid base, the validity bytes and bits, plus the upper pyramid levels) of the last dmi_add_views* call, and summed over
- * the context's life; the copies are not in it.  Either pointer may be null. */
+ * the context's life; the copies are not in it.  A call whose tables are staged in several chunks (more than 256 MiB of f64
+ * tables) times its LAST chunk and scales it to the call's views: an extrapolation then, a measurement for calls of one chunk
+ * (bench.py's calls of 32 views are).  Either pointer may be null. */
 int dmi_get_upload_kernel_ms(dmi_context *ctx, double *last, double *total);
 
 /* Pinned host memory for the SoA staging buffers of the host side (hipHostMalloc). */
