@@ -57,8 +57,11 @@ L2_GATHER_PEAK_GBPS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": rows served
 FLOP_PER_PROJECTION = 48.0  # algorithmic fp64 flop per voxel-projection
 MAPREC_BYTES = 208  # per-map camera record read by the kernel (fusion_kernels.h)
 
-SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room", "blobs")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
 SCENE_SEED = 1000
+
+
+HOLE_FRACTION = None  # --hole-fraction: the share of pixels without a depth in the speckle / noisy / room / blobs scenes (default 0.1)
 
 
 def upload_scene(ctx, scene, kind: str, n: int, W: int, H: int, spacing: float, keep_host: bool = False, chunk: int = 32,
@@ -69,7 +72,8 @@ def upload_scene(ctx, scene, kind: str, n: int, W: int, H: int, spacing: float, 
     and the secondary contexts."""
     kept = []
     for c0 in range(0, n, chunk):
-        v, thr = scene.make_scene_views(kind, n, W, H, seed=SCENE_SEED, view_range=(c0, min(n, c0 + chunk)), noise_sigma=spacing)
+        extra = {} if HOLE_FRACTION is None else {"speckle": float(HOLE_FRACTION)}
+        v, thr = scene.make_scene_views(kind, n, W, H, seed=SCENE_SEED, view_range=(c0, min(n, c0 + chunk)), noise_sigma=spacing, **extra)
         if thr is None:
             v = scene.Views(v.depth.astype(np.float32), v.K4, v.RT4)
             ctx.add_views(v)
@@ -297,6 +301,9 @@ def main():
                          "filter applies it (RD.cxx:138-167); dense: every pixel holds a depth; sparse: sphere only; noisy: speckle "
                          "+ one voxel of depth noise + holes; room: a second geometry -- cameras inside the grid looking outward at the "
                          "walls of a room, depths over an order of magnitude, grazing walls, 10 %% speckle")
+    ap.add_argument("--hole-fraction", type=float, default=None,
+                    help="share of the pixels without a depth in the speckle / noisy / room scenes (scattered at random) and the blobs "
+                         "scene (in discs); default 0.1 -- the hole-density sweep of profiles/")
     ap.add_argument("--no-scenes", action="store_true", help="N = 1: skip the `scenes` object (the other scene kinds, timed beside the headline)")
     ap.add_argument("--grid-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--variant", type=int, default=0)
@@ -327,6 +334,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
+    global HOLE_FRACTION
+    HOLE_FRACTION = args.hole_fraction
 
     env_world = os.environ.get("WORLD_SIZE")
     if args.exchange == "peer_copy":
@@ -559,6 +568,7 @@ def main():
             "k_mode": int(info.k_mode),
             "tiled_kernel": int(info.tiled_kernel),
             "kernel_variant": args.variant,
+            "hole_fraction": 0.1 if args.hole_fraction is None else args.hole_fraction,
             "maps_total": maps_per_gpu,
             "parallelism": "single GPU",
             "rccl_ranks": 0,
@@ -602,6 +612,8 @@ def main():
                     "the default path proves most (brick, view) pairs uniform and skips their projections",
         },
         "brick_classes": hist,
+        "mixed_reasons": ctx.mixed_reason_histogram(),
+        "window_pairs": ctx.window_pair_count(),
         # what actually bounds the default path: instruction issue (issue_roofline below)
         "roofline_issue": issue_roofline(issue_counts, main_ms),
         "box_state": {"fp64_vector_tflops_now": fp64_now, "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -93,6 +93,8 @@ struct dmi_context {
   TileMapRec *d_tile_maps = nullptr;
   std::vector<dmi::WinRec> h_win_recs;  // per view: what the window form of the FREE column reads (one line each)
   dmi::WinRec *d_win_recs = nullptr;
+  std::vector<dmi::FootRec> h_foot_recs;  // per view: the brick's corners relative to its first voxel (window_origin_kernel)
+  dmi::FootRec *d_foot_recs = nullptr;
   double *d_cz_table = nullptr;
   size_t cz_table_capacity = 0;  // doubles
   FuseArgs *d_fuse_args = nullptr;
@@ -388,8 +390,10 @@ float float_not_below(double x) {
 // (TileMapRec::cpx ...), in two tiers (fusion_tile.hip).  P, Q, S: rows 0..2 of K*[R|T]; Sx, Sy: magnitudes of
 // the terms of h.x, h.y over the grid; M[2]: of c.z.
 void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4], const double Q[4], const double S[4],
-                       double Sx, double Sy, const double M[3], bool general, bool aligned, TileMapRec *out, dmi::WinRec *win) {
+                       double Sx, double Sy, const double M[3], bool general, bool aligned, TileMapRec *out, dmi::WinRec *win,
+                       dmi::FootRec *foot) {
   TileMapRec &t = *out;
+  std::memset(foot, 0, sizeof(*foot));
   std::memset(win, 0, sizeof(*win));
   win->e_abs = std::numeric_limits<float>::infinity();  // no windows unless everything below holds
   win->c1 = dmi::kWinC1;
@@ -478,7 +482,7 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
     // c.z within nl2 of ITS model (two computed values, 8 ulp(M[2]) each, rotated grids twice that), times the window's origin
     const double xmax = (double)(std::max(ctx->W, ctx->H) / 2 + dmi::kValidMargin + 1);
     const double nl2 = 2.0 * nl;
-    const double pwin = 72.0;  // bounds an accepted candidate: |P| < |h| / z + 1/2 <= (kWindowRows - 1/2) * kWinCzRatio + 2
+    const double pwin = (dmi::kWindowRows - 0.5) * dmi::kWinCzRatio + 3.0;  // bounds an accepted candidate: |P| < |h| / z + 1/2
     // the steps as the kernel forms them, fl32(d32 - X0 * c32): each within 2^-23 (|d| + |X0 c|) of the real one; a lane takes up
     // to 7 along i and j and kMaxColumn - 1 along k
     const double steps[3] = {7.0, 7.0, (double)(kMaxColumn - 1)};
@@ -502,6 +506,18 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
       win->cj[0] = (float)c[1]; win->cj[1] = (float)(c[1] * (double)dmi::kWinC1);
       win->ck[0] = (float)c[2]; win->ck[1] = (float)(c[2] * (double)dmi::kWinC1);
       win->e_abs = float_not_below(ew);
+      // the brick's corner voxels relative to its first one (FootRec), for 8- and 16-voxel columns
+      for (int cnr = 0; cnr < 8; ++cnr) {
+        const double ni = (cnr & 1) ? 7.0 : 0.0, nj = (cnr & 2) ? 7.0 : 0.0;
+        for (int v = 0; v < 2; ++v) {
+          const double nk = (cnr & 4) ? (v ? 15.0 : 7.0) : 0.0;
+          float *dst = v ? foot->s16[cnr] : foot->s8[cnr];
+          dst[0] = (float)((ni * d[0][0] + nj * d[1][0]) + nk * d[2][0]);
+          dst[1] = (float)((ni * d[0][1] + nj * d[1][1]) + nk * d[2][1]);
+          dst[2] = (float)((ni * c[0] + nj * c[1]) + nk * c[2]);
+        }
+      }
+      foot->ferr = float_not_below(cerr + xmax * nl2);
     }
   }
   if (per_lane) {
@@ -521,7 +537,7 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
 // pixel selection, and `err`, a bound on the absolute difference between the reference's computed
 // h.x / h.y and the kernel's affine evaluation anywhere in the grid (DESIGN.md "Tiled kernel: proof
 // obligations" derives the 73-ulp budget this bound covers seven times over).
-TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *win) {
+TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *win, dmi::FootRec *foot) {
   TileMapRec t;
   std::memset(&t, 0, sizeof(t));
   const double *rt = r.rt, *k = r.k;
@@ -599,7 +615,7 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *w
   //                                  (Sz * r >= 1 - 2^-39).
   t.errk = (t.err + 65536.0 * t.errz) + 0x1p-22 * Sz * (1.0 + 0x1p-20);
   t.depth = r.depth;
-  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, general, aligned, &t, win);
+  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, general, aligned, &t, win, foot);
   return t;
 }
 
@@ -664,7 +680,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     const int km = classify_k(r.k, r.rt);
     if (km < ctx->k_mode) ctx->k_mode = km;
     dmi::WinRec wrec;
-    TileMapRec t = make_tile_rec(ctx, r, &wrec);
+    dmi::FootRec frec;
+    TileMapRec t = make_tile_rec(ctx, r, &wrec, &frec);
     t.valid = reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.valid_offset + (size_t)m * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H);
     t.vm_c0 = ((float)(ctx->H / 2 + dmi::kValidMargin) - 3.5f) * 0.125f;
     t.vm_w8 = (float)(8 * (ctx->W + 2 * dmi::kValidMargin) - 8);
@@ -679,6 +696,7 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     ctx->h_tile_maps.push_back(t);
     wrec.vbits = t.vbits;
     ctx->h_win_recs.push_back(wrec);
+    ctx->h_foot_recs.push_back(frec);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);
     // pixel selection must be provable for nearly every lane: the error bounds over h.z must stay far below one pixel
@@ -755,9 +773,13 @@ int sync_maps(dmi_context *ctx) {
     ctx->d_tile_maps = nullptr;
     DMI_HIP(ctx, hipMalloc(&ctx->d_tile_maps, cap * sizeof(TileMapRec)));
     if (ctx->d_win_recs) (void)hipFree(ctx->d_win_recs);
+  if (ctx->d_foot_recs) (void)hipFree(ctx->d_foot_recs);
     ctx->d_win_recs = nullptr;
     DMI_HIP(ctx, hipMalloc(&ctx->d_win_recs, cap * sizeof(dmi::WinRec)));
-    ctx->device_bytes += (cap - ctx->d_maps_capacity) * (sizeof(MapRec) + sizeof(TileMapRec) + sizeof(dmi::WinRec));
+    if (ctx->d_foot_recs) (void)hipFree(ctx->d_foot_recs);
+    ctx->d_foot_recs = nullptr;
+    DMI_HIP(ctx, hipMalloc(&ctx->d_foot_recs, cap * sizeof(dmi::FootRec)));
+    ctx->device_bytes += (cap - ctx->d_maps_capacity) * (sizeof(MapRec) + sizeof(TileMapRec) + sizeof(dmi::WinRec) + sizeof(dmi::FootRec));
     ctx->d_maps_capacity = cap;
     ctx->maps_dirty = true;
   }
@@ -782,6 +804,7 @@ int sync_maps(dmi_context *ctx) {
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_tile_maps, ctx->h_tile_maps.data(), n * sizeof(TileMapRec), hipMemcpyHostToDevice,
                                 ctx->stream));
     DMI_HIP(ctx, hipMemcpyAsync(ctx->d_win_recs, ctx->h_win_recs.data(), n * sizeof(dmi::WinRec), hipMemcpyHostToDevice, ctx->stream));
+    DMI_HIP(ctx, hipMemcpyAsync(ctx->d_foot_recs, ctx->h_foot_recs.data(), n * sizeof(dmi::FootRec), hipMemcpyHostToDevice, ctx->stream));
     // h_maps / h_tile_maps are pageable: the copies above are complete for the host when they return
     ctx->maps_dirty = false;
   }
@@ -957,6 +980,7 @@ void dmi_destroy(dmi_context *ctx) {
   if (ctx->d_maps) (void)hipFree(ctx->d_maps);
   if (ctx->d_tile_maps) (void)hipFree(ctx->d_tile_maps);
   if (ctx->d_win_recs) (void)hipFree(ctx->d_win_recs);
+  if (ctx->d_foot_recs) (void)hipFree(ctx->d_foot_recs);
   if (ctx->d_cz_table) (void)hipFree(ctx->d_cz_table);
   if (ctx->d_wg_times) (void)hipFree(ctx->d_wg_times);
   if (ctx->d_queue_heads) (void)hipFree(ctx->d_queue_heads);
@@ -1004,6 +1028,7 @@ int dmi_clear_views(dmi_context *ctx) {
   ctx->h_maps.clear();
   ctx->h_tile_maps.clear();
   ctx->h_win_recs.clear();
+  ctx->h_foot_recs.clear();
   ctx->view_k_mode.clear();
   ctx->view_tile_ok.clear();
   ctx->max_tile_err = 0.0;
@@ -1387,6 +1412,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
         t.win_origin = reinterpret_cast<dmi::WinPair *>(ctx->d_classes + coarse_end);
         t.win_delta = (int64_t)reinterpret_cast<intptr_t>(t.win_origin) - 16 * (int64_t)reinterpret_cast<intptr_t>(t.classes);
         t.win_recs = ctx->d_win_recs;
+        t.foot_recs = ctx->d_foot_recs;
         t.vb_bytes = (int32_t)std::min<int64_t>(dmi::valid_bits_bytes(ctx->W, ctx->H), 0x7fffffff);
         t.vb_rowskip = (dmi::valid_bits_tiles_x(ctx->W) - 1) * 128;
         t.win_cx = dmi::kValidMargin + ctx->W / 2;
@@ -1446,6 +1472,10 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       DMI_HIP(ctx, hipMemsetAsync(ctx->d_wg_times, 0, blocks * 3 * sizeof(unsigned long long), ctx->stream));
       t.wg_times = ctx->d_wg_times;
       t.wg_times_n = (int64_t)blocks;
+    }
+    if (const char *e = std::getenv("DMI_DEBUG_PAIRS")) {  // tools/gpu_pair_cost.sh (results are wrong)
+      if (!std::strcmp(e, "nowin")) t.flags |= dmi::TILE_FLAG_DBG_SKIP_WINDOW_PAIRS;
+      if (!std::strcmp(e, "onlywin")) t.flags |= dmi::TILE_FLAG_DBG_ONLY_WINDOW_PAIRS;
     }
     if (const char *e = std::getenv("DMI_XCD_RUN_WG")) {  // launch-geometry experiments
       t.xcd_run_wg = std::max(1, std::atoi(e));

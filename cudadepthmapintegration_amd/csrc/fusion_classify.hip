@@ -740,8 +740,19 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
   // views [m_lo, m_hi) of this workgroup, in groups of four that start at multiples of 4 (the rows are 64-byte aligned)
   const int m_begin = a.first_map, m_end = a.first_map + a.n_maps;
   const int g_lo = (m_begin & ~3) + blockIdx.y * group_views;
+  // the class bytes of all the workgroup's views at once (a lane's row piece: up to kOriginViews bytes): one trip to memory per
+  // wave instead of one per four views -- the kernel was a chain of those (24 us per wave at cfg 3, profiles/r19b_*)
+  uint32_t held[kOriginViews / 4];
+#pragma unroll
+  for (int g = 0; g < kOriginViews / 4; ++g) {
+    const int m4 = g_lo + 4 * g;
+    held[g] = (eligible && 4 * g < group_views && m4 < m_end) ? *reinterpret_cast<const uint32_t *>(classes + row + m4) : 0u;
+  }
+#pragma unroll 1
   for (int m4 = g_lo; m4 < g_lo + group_views && m4 < m_end; m4 += 4) {  // wave-uniform
-    uint32_t c4 = eligible ? *reinterpret_cast<const uint32_t *>(classes + row + m4) : 0u;
+    uint32_t c4 = held[0];
+#pragma unroll
+    for (int g = 0; g + 1 < kOriginViews / 4; ++g) held[g] = held[g + 1];  // (registers, not an indexed array: the next group moves up)
     const uint32_t before = c4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -755,34 +766,55 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
         if (want) c4 &= ~((uint32_t)CLASS_HAS_WINDOW << (8 * q));
         continue;
       }
-      MapRec mr_u;
-      TileMapRec tr_u;
-#pragma unroll
-      for (int r = 8; r < 12; ++r) mr_u.rt[r] = cload(&src->rt[r]);
-      tr_u.px = cload(&tsrc->px); tr_u.py = cload(&tsrc->py); tr_u.pz = cload(&tsrc->pz); tr_u.p0 = cload(&tsrc->p0);
-      tr_u.qx = cload(&tsrc->qx); tr_u.qy = cload(&tsrc->qy); tr_u.qz = cload(&tsrc->qz); tr_u.q0 = cload(&tsrc->q0);
-      tr_u.err = cload(&tsrc->err);
-      tr_u.cz_err = cload(&tsrc->cz_err);
-      tr_u.errz = 0.0;
+      // Anchor in fp64 -- the centred numerators by the FMA chain over TileMapRec::cpx ..., c.z in the reference's order (cu:172),
+      // at the brick's first voxel --, the eight corner voxels relative to it in fp32 (FootRec: the steps are the view's, the
+      // same for every brick), the footprint from packed fp32 quotients.  Every voxel's reference pixel, counted from the image
+      // centre, lies in [umin - 1/2 - e, umax + 1/2 + e]: the real projective u'' is monotone along the grid's axes (c.z > 0 over
+      // the brick: the class was proven for a box that holds it, 4b.2), so it lies between the real corner values; a computed
+      // corner value is within 2^-20 of the largest corner magnitude `umag` of the model's (anchor, step and sum roundings of
+      // numerator and c.z: 4 * 2^-24 each, times c.z's ratio over the brick <= 1.25; v_rcp_f32's ulp and the product's), the model
+      // within ferr / c.z of the reference's numerator (4e.6; ferr also covers c.z's model, times |u''| <= X_max), the reference's
+      // quotient and rounding as in 4b.2: e = 2 ferr / czmin + 2^-19 umag + 2^-12, twice what is needed.
       uint32_t flag = 0;
       if (want) {
-        const BoxFootprint fp = box_footprint_k<ROT, false>(a, &mr_u, &tr_u, bx * 8, bx * 8 + 7, by * 8, by * 8 + 7, bz * tk, bz * tk + tk - 1);
-        const bool inside = fp.query || (fp.partial && fp.in_margin);
-        // (czmin > 0 comes with `inside`: box_footprint asks for czmin > 4 err; on a rotated grid the range is the widened one)
-        if (inside && fp.rx1 - fp.rx0 < kWindowCols && fp.ry1 - fp.ry0 < kWindowRows && fp.czmin > 0.0 &&
-            fp.czmax <= kWinCzRatio * fp.czmin) {
-          const double cza = row4(mr_u.rt + 8, wxa, wya, wza);  // cu:172 row 2 at the brick's first voxel, the reference's order
-          const double hxa = __builtin_fma(cload(&tsrc->cpx), wxa, __builtin_fma(cload(&tsrc->cpy), wya, __builtin_fma(cload(&tsrc->cpz), wza, cload(&tsrc->cp0))));
-          const double hya = __builtin_fma(cload(&tsrc->cqx), wxa, __builtin_fma(cload(&tsrc->cqy), wya, __builtin_fma(cload(&tsrc->cqz), wza, cload(&tsrc->cq0))));
-          // the window's first pixel counted from the image centre (integers: exact)
-          const double x0c = (double)(fp.rx0 - a.W / 2), y0c = (double)(fp.ry0 - a.H / 2);
-          WinPair wp;
-          wp.origin = (uint32_t)(fp.rx0 + kValidMargin) | ((uint32_t)(fp.ry0 + kValidMargin) << 16);
-          wp.ax = (float)(hxa - x0c * cza);
-          wp.ay = (float)(hya - y0c * cza);
-          wp.acz = (float)cza;
-          origins[row + m] = wp;
-          flag = CLASS_HAS_WINDOW;
+        const FootRec *fr = a.foot_recs + m;
+        const double cza = ((cload(&src->rt[8]) * wxa + cload(&src->rt[9]) * wya) + cload(&src->rt[10]) * wza) + cload(&src->rt[11]);
+        const double hxa = __builtin_fma(cload(&tsrc->cpx), wxa, __builtin_fma(cload(&tsrc->cpy), wya, __builtin_fma(cload(&tsrc->cpz), wza, cload(&tsrc->cp0))));
+        const double hya = __builtin_fma(cload(&tsrc->cqx), wxa, __builtin_fma(cload(&tsrc->cqy), wya, __builtin_fma(cload(&tsrc->cqz), wza, cload(&tsrc->cq0))));
+        const float hx0 = (float)hxa, hy0 = (float)hya, z0 = (float)cza;
+        float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
+        float zmin = __builtin_inff(), zmax = -__builtin_inff();
+        const float(*sc)[4] = tk == 16 ? fr->s16 : fr->s8;  // wave-uniform
+#pragma unroll
+        for (int cnr = 0; cnr < 8; ++cnr) {
+          const float z = z0 + cload(&sc[cnr][2]);
+          const float r = __builtin_amdgcn_rcpf(z);
+          const float u = (hx0 + cload(&sc[cnr][0])) * r, v = (hy0 + cload(&sc[cnr][1])) * r;
+          umin = __builtin_fminf(umin, u), umax = __builtin_fmaxf(umax, u);
+          vmin = __builtin_fminf(vmin, v), vmax = __builtin_fmaxf(vmax, v);
+          zmin = __builtin_fminf(zmin, z), zmax = __builtin_fmaxf(zmax, z);
+        }
+        // (NaN anywhere fails a compare below; |u| < 2^16 keeps the float -> int conversions exact)
+        const float umag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(umin), __builtin_fabsf(umax)), __builtin_fmaxf(__builtin_fabsf(vmin), __builtin_fabsf(vmax)));
+        const float e = 2.0f * cload(&fr->ferr) * __builtin_amdgcn_rcpf(zmin) * (1.0f + 0x1p-20f) + (0x1p-19f * umag + 0x1p-12f);
+        const bool sane = zmin > 0.0f && zmax <= (float)(kWinCzRatio * (1.0 - 0x1p-20)) * zmin && umin > -65536.0f && umax < 65536.0f &&
+                          vmin > -65536.0f && vmax < 65536.0f && e < 0.25f;
+        if (sane) {
+          const int cxc = a.W / 2, cyc = a.H / 2;
+          const int x0 = (int)__builtin_ceilf(umin - 0.5f - e) + cxc, x1 = (int)__builtin_floorf(umax + 0.5f + e) + cxc;
+          const int y0 = (int)__builtin_ceilf(vmin - 0.5f - e) + cyc, y1 = (int)__builtin_floorf(vmax + 0.5f + e) + cyc;
+          // inside the image or its margin of "no depth" (4b.9), and no wider than a window
+          if (x0 >= -kValidMargin && y0 >= -kValidMargin && x1 < a.W + kValidMargin && y1 < a.H + kValidMargin &&
+              x1 - x0 < kWindowCols && y1 - y0 < kWindowRows) {
+            WinPair wp;
+            wp.origin = (uint32_t)(x0 + kValidMargin) | ((uint32_t)(y0 + kValidMargin) << 16);
+            // the window's first pixel counted from the image centre (integers: exact)
+            wp.ax = (float)(hxa - (double)(x0 - cxc) * cza);
+            wp.ay = (float)(hya - (double)(y0 - cyc) * cza);
+            wp.acz = z0;
+            origins[row + m] = wp;
+            flag = CLASS_HAS_WINDOW;
+          }
         }
         c4 = (c4 & ~((uint32_t)CLASS_HAS_WINDOW << (8 * q))) | (flag << (8 * q));
       }

@@ -154,9 +154,18 @@ struct alignas(64) WinRec {
   float c1;               // kWinC1
 };
 static_assert(sizeof(WinRec) == 64, "WinRec is one cache line");
+// What window_origin_kernel adds to a pair's anchor to reach the brick's eight corner voxels (corner c: bit 0 = i, 1 = j, 2 = k):
+// (hx'', hy'', c.z) at voxel (7 or 0, 7 or 0, tk - 1 or 0) minus their values at (0, 0, 0), fp32, for 8- and 16-voxel columns;
+// ferr: the centred rows' error bound cerr (4d.1), rounded up.  Wave-uniform: scalar operands of the kernel's packed adds.
+struct alignas(64) FootRec {
+  float s8[8][4];   // [corner] = (dhx'', dhy'', dcz, unused)
+  float s16[8][4];
+  float ferr, pad[15];
+};
+static_assert(sizeof(FootRec) == 320, "FootRec layout");
 constexpr float kWinC1 = 0.5f - 0x1p-14f;  // what is left of 1/2 after every c.z-proportional rounding of the window column (4e.6)
 // the brick's c.z may vary by this factor at most for the pair to get a window (bounds |hw| by the threshold's own c.z)
-constexpr double kWinCzRatio = 1.0 + 1.0 / 16.0;
+constexpr double kWinCzRatio = 1.25;
 // Per windowed (brick, view) pair, TileArgs::win_origin[brick * class_pitch + view]: the window's first pixel (padded-image
 // coordinates, x0 | y0 << 16) and the fp32 images of hw.x, hw.y and c.z at voxel (0, 0, 0) of the brick
 struct alignas(16) WinPair {
@@ -259,6 +268,7 @@ struct TileArgs {
   WinPair *win_origin;
   int64_t win_delta;  // = win_origin - 16 * classes (as integers): the pair table is indexed like the class table
   const WinRec *win_recs;  // [n_views]
+  const FootRec *foot_recs;  // [n_views]
   int32_t vb_bytes, vb_rowskip;  // as TileMapRec's (the same for every view of a context)
   int32_t win_cx, win_cy;        // kValidMargin + W / 2, kValidMargin + H / 2: the image centre in padded coordinates
 };
@@ -272,7 +282,11 @@ static_assert(offsetof(TileArgs, nx) == 0 && offsetof(TileArgs, nz) == 8 && offs
 enum TileKernelFlags : int32_t {
   TILE_FLAG_NO_INTERIOR = 1,  // tuning / tests: never take the INTERIOR column variant
   TILE_FLAG_XCD_RUNS = 2,     // deal the ordered bricks to the XCDs in runs of xcd_run_wg (round 1's mapping; with TILE_FLAG_COST_ORDER)
-  TILE_FLAG_COST_ORDER = 4    // the bricks are ordered by their number of mixed views (64 levels; small grids: launch_order_bricks)
+  TILE_FLAG_COST_ORDER = 4,   // the bricks are ordered by their number of mixed views (64 levels; small grids: launch_order_bricks)
+  // tuning builds only (DMI_TUNING; results are wrong): what a kind of pair costs -- the window pairs skipped, or every mixed
+  // pair but them (DMI_DEBUG_PAIRS=nowin / onlywin; counters per pair: tools/gpu_pair_cost.sh)
+  TILE_FLAG_DBG_SKIP_WINDOW_PAIRS = 256,
+  TILE_FLAG_DBG_ONLY_WINDOW_PAIRS = 512
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight

@@ -610,6 +610,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // nothing of it stays live across them.
 #ifdef DMI_TUNING
     ++dbg_cols;
+    if (WIN && ((kflags & TILE_FLAG_DBG_SKIP_WINDOW_PAIRS) && (cbyte & CLASS_HAS_WINDOW))) continue;
+    if ((kflags & TILE_FLAG_DBG_ONLY_WINDOW_PAIRS) && !(WIN && (cbyte & CLASS_HAS_WINDOW))) continue;
 #endif
     if constexpr (WIN) {
       if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
@@ -627,7 +629,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // the view's window record: ONE line through one scalar load (WinRec, fusion_kernels.h)
         const kernarg_t kw = KFRESH();
         typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-        const u32x16 R = *reinterpret_cast<const u32x16 __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(kw->win_recs + m));
+        const WinRec *const wrec = kw->win_recs + m;
+        const u32x16 R = *reinterpret_cast<const u32x16 __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(wrec));
+#ifndef DMI_NO_WINREC_PREFETCH
+        // the NEXT view's record on its way into the scalar cache (most of a brick's window views are consecutive): one dword of
+        // its line into a register that is only waited for, after the column (the table has room beyond the last view)
+        int next_rec;
+        asm volatile("s_load_dword %0, %1, 0x40" : "=&s"(next_rec) : "s"(wrec));
+#endif
         const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<uint32_t *>((uintptr_t)R[0] | ((uintptr_t)R[1] << 32)), (short)0, kw->vb_bytes, 0x00020000);
         // byte offset of row Y's dword in tile column tx: ((Y >> 5) * tiles_x + tx) * 128 + (Y & 31) * 4
@@ -736,6 +745,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           }
         }
         consume(TK - WG);
+#ifndef DMI_NO_WINREC_PREFETCH
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(next_rec));
+#endif
         // ---- the voxels in which some lane was not accepted (about 2 % of a wave's): tier 2 (DESIGN.md 4.1-4.5 in centred
         // coordinates), then the reference's own expression for what that leaves; at most one add per voxel and view, after the
         // column and before the next view: every voxel accumulates in view order (cu:211)

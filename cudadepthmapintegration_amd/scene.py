@@ -224,8 +224,41 @@ def make_room_views(n: int, W: int, H: int, seed: int = 0, view_range: tuple | N
     return Views(depth, K4, RT4)
 
 
+# ---- real-world magnitudes: the same scene in a geo-referenced frame --------------------------------------------------
+def to_world_frame(grid: GridDesc, ray: RayPotential, views: "Views", scale: float, offset, focal: float | None = None):
+    """The scene as an SfM pipeline in a projected coordinate system hands it over: world' = scale * world + offset (metres,
+    with eastings / northings of 1e5 .. 1e7 as offsets), camera coordinates scaled alike.  Grid origin and spacing, the ray
+    potential's lengths and the depths scale; R stays, T' = scale * T - R offset (so |T'| ~ |offset| and c = R w + T' cancels
+    seven digits, as in real data: Sources/ReconstructionData.cxx:192-221, Sources/Helper.h:134-165 read such matrices).
+    focal: optionally replace fx = fy by this many pixels (depths are unchanged: it only zooms the image)."""
+    off = np.asarray(offset, dtype=np.float64)
+    g = GridDesc(grid.cell_dims, tuple(float(scale) * np.asarray(grid.origin, dtype=np.float64) + off),
+                 tuple(float(scale) * np.asarray(grid.spacing, dtype=np.float64)), grid.grid_matrix.copy())
+    if not np.allclose(grid.grid_matrix[:3, :3], np.eye(3)) or np.any(grid.grid_matrix[:3, 3] != 0):
+        # a grid matrix G maps p = origin + (idx + 0.5) spacing to the world: w = G3 p + g3; keep w' = scale w + offset by scaling
+        # p (origin, spacing above, without the offset) and moving the offset into the matrix's translation
+        g = GridDesc(grid.cell_dims, tuple(float(scale) * np.asarray(grid.origin, dtype=np.float64)),
+                     tuple(float(scale) * np.asarray(grid.spacing, dtype=np.float64)), grid.grid_matrix.copy())
+        g.grid_matrix[:3, 3] = float(scale) * grid.grid_matrix[:3, 3] + off
+    r = RayPotential(ray.thickness * scale, ray.rho, ray.eta, ray.delta * scale)
+    RT = views.RT4.copy()
+    for m in range(views.n):
+        RT[m, :3, 3] = scale * views.RT4[m, :3, 3] - views.RT4[m, :3, :3] @ off
+    K = views.K4.copy()
+    if focal is not None:
+        K[:, 0, 0] = K[:, 1, 1] = float(focal)
+    d = views.depth
+    valid = np.isfinite(d) & (d != -1.0)
+    depth = np.where(valid, (d * scale).astype(np.float32).astype(np.float64), d)
+    return g, r, Views(depth, K, RT, views.best_cost)
+
+
+GEO_OFFSET = (448262.5, 5411932.25, 312.0)  # an easting / northing / height a UTM-projected survey would carry
+GEO_SCALE = 10.0                            # the cube [-1, 1]^3 becomes 20 m wide: 512^3 voxels of 3.9 cm
+
+
 # ---- scenes as a stereo pipeline hands them over: invalid speckle, noise, holes --------------------------------------
-SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room")
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room", "blobs")
 SPECKLE_THRESHOLD = 0.9  # best cost ~ U[0, 1): "threshold chosen to kill ~10 % of pixels" (SURVEY.md 8d)
 
 
@@ -246,6 +279,8 @@ def make_scene_views(kind: str, n: int, W: int, H: int, seed: int = 0, view_rang
       noisy    speckle + depth noise (every depth += N(0, noise_sigma), in scene units: the bench passes one voxel's
                spacing) + `holes` discs of 8-40 pixels radius without depth per view
       room     a second geometry: cameras INSIDE the grid looking outward at the walls of a room (make_room_views) + the speckle
+      blobs    dense + REGIONAL holes: discs of 8-40 pixels radius without depth, as many as cover about `speckle` of the image
+               (what best-cost filtering leaves of real stereo output: whole patches, not salt and pepper); no best-cost values
     Depths stay f32-representable (the device keeps them as f32 without changing a bit); best cost is f64 as the
     reference's array is.  Views lo .. hi-1 of the n-camera scene when view_range is given."""
     if kind not in SCENE_KINDS:
@@ -261,6 +296,19 @@ def make_scene_views(kind: str, n: int, W: int, H: int, seed: int = 0, view_rang
         return Views(base.depth, base.K4, base.RT4, best), 1.0 - float(speckle)
     base = make_views(n, W, H, seed=seed, layout=layout, dense=(kind != "sparse"), view_range=view_range)
     if kind in ("dense", "sparse"):
+        return base, None
+    if kind == "blobs":
+        lo, hi = (0, n) if view_range is None else (int(view_range[0]), int(view_range[1]))
+        yy, xx = np.ogrid[0:H, 0:W]
+        n_discs = max(1, int(round(float(speckle) * W * H / 2000.0)))  # a disc of radius U[8, 41) covers ~2000 pixels on average
+        for m in range(lo, hi):
+            rng = view_rng(seed, m, 3)
+            d = base.depth[m - lo]
+            for _ in range(n_discs):
+                cx, cy, r = rng.integers(0, W), rng.integers(0, H), rng.integers(8, 41)
+                y0, y1, x0, x1 = max(0, cy - r), min(H, cy + r + 1), max(0, cx - r), min(W, cx + r + 1)
+                sub = d[y0:y1, x0:x1]
+                sub[(xx[:, x0:x1] - cx) ** 2 + (yy[y0:y1] - cy) ** 2 <= r * r] = -1.0
         return base, None
     lo, hi = (0, n) if view_range is None else (int(view_range[0]), int(view_range[1]))
     best = np.empty((hi - lo, H, W), dtype=np.float64)
