@@ -102,6 +102,8 @@ struct dmi_context {
   bool last_fuse_tiled = false;
   bool last_fuse_classes = false;
   int64_t last_class_bricks = 0;  // wave bricks of the last fuse
+  int32_t last_bricks_z = 0, last_tk = 0;
+  const dmi::WinPair *last_win_origin = nullptr;  // the last tiled launch's pair table (nullptr: it had no windows)
   int32_t last_class_pitch = 0, last_first = 0, last_count = 0;
   dmi::PyramidDesc pyramid{};    // geometry of every view's depth min/max pyramid
   uint8_t *d_zero_row = nullptr;  // one row of BRICK_MIXED bytes: the class table of a fuse without classes
@@ -1284,7 +1286,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
   TileArgs t;
   std::memset(&t, 0, sizeof(t));
   if (cfg.use_tile) {
-    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64, !grid_axis_aligned(ctx->grid) || cfg.general_k);
+    const dmi::TileShape sh = dmi::tile_shape(cfg.variant, ctx->depth_f64, !grid_axis_aligned(ctx->grid), cfg.general_k != 0);
     t.nx = a.nx; t.ny = a.ny; t.nz = a.nz; t.W = a.W; t.H = a.H;
     t.first_map = first; t.n_maps = count; t.init_from_grid = a.init_from_grid;
     t.kpad = (a.nz + sh.tk - 1) / sh.tk * sh.tk;
@@ -1389,8 +1391,11 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       // launch then runs the kernel's WIN instantiation, which pays for the window code in every column, fusion_tile.hip)
       bool any_tier1 = false;  // (a launch none of whose views has a window record has no window pair: the plain instantiation serves it)
       for (int32_t m = first; m < first + count && !any_tier1; ++m) any_tier1 = std::isfinite(ctx->h_win_recs[(size_t)m].e_abs);
+      // (and only where no sum can be -0.0 -- the launches the kernel's ZF instantiations serve, fusion_tile.hip -- and the depth
+      // tables are f32: elsewhere the FREE column keeps its gathers)
+      const bool zero_free = (!a.init_from_grid || ctx->grid_free_of_negative_zero) && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS);
       const bool windows = DMI_TIER1 != 0 && !cfg.general_k && !cfg.count_hits && !(cfg.variant & (dmi::VAR_NO_WINDOWS | dmi::VAR_NO_INTERIOR)) &&
-                           (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS)) && any_tier1;
+                           (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS)) && any_tier1 && zero_free && !ctx->depth_f64;
       const size_t cbytes = coarse_end + (windows ? fine_bytes * sizeof(dmi::WinPair) : 0);
       ctx->coarse_offset = fine_bytes;
       if (ctx->classes_capacity < cbytes) {
@@ -1513,6 +1518,9 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
   ctx->last_fuse_tiled = cfg.use_tile != 0;
   ctx->last_fuse_classes = cfg.use_tile != 0 && !(cfg.variant & dmi::VAR_NO_BRICK_CLASSES);
   ctx->last_class_bricks = (int64_t)t.wbricks_x * t.wbricks_y * t.bricks_z;
+  ctx->last_bricks_z = t.bricks_z;
+  ctx->last_tk = t.bricks_z > 0 ? t.kpad / t.bricks_z : 0;
+  ctx->last_win_origin = t.win_origin;
   ctx->last_class_pitch = t.class_pitch;
   ctx->last_first = first;
   ctx->last_count = count;
@@ -1858,16 +1866,19 @@ int dmi_get_window_pair_count(dmi_context *ctx, uint64_t *out) {
   return guarded(ctx, "dmi_get_window_pair_count", [&]() -> int {
   if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_window_pair_count: null argument");
   *out = 0;
-  if (!ctx->last_fuse_classes) return DMI_OK;
+  if (!ctx->last_fuse_classes || !ctx->last_win_origin) return DMI_OK;
   DMI_HIP(ctx, hipSetDevice(ctx->opt.device));
-  const size_t bytes = (size_t)ctx->last_class_bricks * ctx->last_class_pitch;
-  std::vector<uint8_t> host(bytes);
-  DMI_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_classes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  const size_t pairs = (size_t)ctx->last_class_bricks * ctx->last_class_pitch;
+  std::vector<uint8_t> host(pairs);
+  DMI_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_classes, pairs, hipMemcpyDeviceToHost, ctx->stream));
   DMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t per_layer = ctx->last_class_bricks / std::max<int64_t>(1, ctx->last_bricks_z);
   for (int64_t b = 0; b < ctx->last_class_bricks; ++b) {
-    const uint8_t *row = host.data() + (size_t)b * ctx->last_class_pitch + ctx->last_first;
+    const int64_t bz = b / std::max<int64_t>(1, per_layer);
+    if (bz * ctx->last_tk + ctx->last_tk > ctx->grid.cell_dims[2]) continue;  // a brick that sticks out of the top: no windows
+    const size_t base = (size_t)b * ctx->last_class_pitch + ctx->last_first;
     for (int32_t m = 0; m < ctx->last_count; ++m)
-      if ((row[m] & 3) == dmi::BRICK_MIXED && (row[m] & dmi::CLASS_HAS_WINDOW)) *out += 1;
+      if ((host[base + m] & 0x3f) == (dmi::BRICK_MIXED | (dmi::MIXED_FREE_OR_NODEPTH << 2))) *out += 1;  // (no CLASS_NO_WINDOW)
   }
   return DMI_OK;
   });

@@ -712,16 +712,26 @@ __global__ __launch_bounds__(256) void classify_kernel(const TileArgs a, const M
 // A wave is 64 consecutive bricks and walks over kOriginViews views, four class bytes per load; the view is
 // wave-uniform, so its camera record arrives through scalar loads (as in the fine pass), and the lanes that have the class are
 // neighbours in space: all of them or none, mostly.
-constexpr int kOriginViews = 32;  // views per workgroup (a multiple of 4) on large grids; fewer on small ones (launch_window_origins)
+constexpr int kOriginViews = 8;   // views per workgroup (a multiple of 4): a brick's entries of one workgroup are ONE 128-byte line
+constexpr uint32_t kNotWanted = 0xfffffffeu;  // (LDS only) the pair is not of the class: nothing is written for it
 template <bool ROT>
 __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, const MapRec *__restrict__ maps, int tk,
                                                             uint8_t *__restrict__ classes, WinPair *__restrict__ origins,
                                                             int group_views) {
+  // Round 5.  What this kernel's 0.4 ms were NOT: its arithmetic (an fp32 footprint from an fp64 anchor instead of eight fp64
+  // projections: 4 x fewer vector instructions, the same time), the trips to memory for the views' records (fetched once for four
+  // blocks of bricks: the same time), the chain of class-byte loads (all requested at once: the same time; profiles/r19d .. r19g).
+  // What they were: sixteen million 16-byte stores, each to a line of its own (a lane is a brick, and a brick's entries are 4 KB
+  // apart from the next brick's), and as many read-modify-writes of class bytes.  Now the entries of the workgroup's 256 bricks x 8
+  // views go through LDS and leave as whole 128-byte lines (eight lanes = a brick's eight views), and the class table is written
+  // only for the exceptions: CLASS_NO_WINDOW on the few pairs without a window (1 % at cfg 3).
+  __shared__ WinPair tile[kOriginViews][256 + 1];  // [view][brick]; + 1: eight lanes reading a brick's views hit eight bank groups
+  __shared__ int64_t rows[256];
   const int bz_first = 2 * a.sbz_first;
   const int bz_count = min(2 * a.super_z, a.bricks_z - bz_first);
   const int64_t n_bricks = (int64_t)a.wbricks_x * a.wbricks_y * bz_count;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t local = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  const int lane = threadIdx.x & 63;
+  const int64_t local = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool exists = local < n_bricks;
   const int bx = (int)(local % a.wbricks_x);
   const int64_t t = local / a.wbricks_x;
@@ -729,6 +739,7 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
   const int64_t row = (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * a.class_pitch;
   // (a brick that sticks out of the top of the grid takes the column with every test, fusion_tile.hip: no window for it)
   const bool eligible = exists && bz * tk + tk <= a.nz;
+  (void)lane;
   // world position of the brick's voxel (0, 0, 0), as the fusion kernel computes it (cu:78-83, cu:168)
   double wxa, wya, wza;
   {
@@ -737,89 +748,102 @@ __global__ __launch_bounds__(256) void window_origin_kernel(const TileArgs a, co
     const double gz = a.oz + ((bz * tk + a.kz0) + 0.5) * a.sz;
     wxa = row4(a.g + 0, gx, gy, gz), wya = row4(a.g + 4, gx, gy, gz), wza = row4(a.g + 8, gx, gy, gz);
   }
-  // views [m_lo, m_hi) of this workgroup, in groups of four that start at multiples of 4 (the rows are 64-byte aligned)
   const int m_begin = a.first_map, m_end = a.first_map + a.n_maps;
   const int g_lo = (m_begin & ~3) + blockIdx.y * group_views;
-  // the class bytes of all the workgroup's views at once (a lane's row piece: up to kOriginViews bytes): one trip to memory per
-  // wave instead of one per four views -- the kernel was a chain of those (24 us per wave at cfg 3, profiles/r19b_*)
+  rows[threadIdx.x] = row;
   uint32_t held[kOriginViews / 4];
 #pragma unroll
   for (int g = 0; g < kOriginViews / 4; ++g) {
     const int m4 = g_lo + 4 * g;
     held[g] = (eligible && 4 * g < group_views && m4 < m_end) ? *reinterpret_cast<const uint32_t *>(classes + row + m4) : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[4 * g + q][threadIdx.x].origin = kNotWanted;
   }
+#pragma unroll
+  for (int g = 0; g < kOriginViews / 4; ++g) {
+    const int m4 = g_lo + 4 * g;
+    if (4 * g >= group_views || m4 >= m_end) break;  // wave-uniform
+    const uint32_t c4 = held[g];
 #pragma unroll 1
-  for (int m4 = g_lo; m4 < g_lo + group_views && m4 < m_end; m4 += 4) {  // wave-uniform
-    uint32_t c4 = held[0];
-#pragma unroll
-    for (int g = 0; g + 1 < kOriginViews / 4; ++g) held[g] = held[g + 1];  // (registers, not an indexed array: the next group moves up)
-    const uint32_t before = c4;
-#pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = m4 + q;
       const uint8_t c = (uint8_t)(c4 >> (8 * q));
       const bool want = eligible && m >= m_begin && m < m_end && (c & 0x1f) == (uint8_t)(BRICK_MIXED | (MIXED_FREE_OR_NODEPTH << 2));
       if (__builtin_amdgcn_ballot_w64(want) == 0) continue;  // wave-uniform
-      const MapRec *src = maps + m;
-      const TileMapRec *tsrc = a.tile_maps + m;
-      if (!(cload(&a.win_recs[m].e_abs) < __builtin_inff())) {  // the view has no windows (wave-uniform): the class bits stay as they are
-        if (want) c4 &= ~((uint32_t)CLASS_HAS_WINDOW << (8 * q));
-        continue;
-      }
-      // Anchor in fp64 -- the centred numerators by the FMA chain over TileMapRec::cpx ..., c.z in the reference's order (cu:172),
-      // at the brick's first voxel --, the eight corner voxels relative to it in fp32 (FootRec: the steps are the view's, the
-      // same for every brick), the footprint from packed fp32 quotients.  Every voxel's reference pixel, counted from the image
-      // centre, lies in [umin - 1/2 - e, umax + 1/2 + e]: the real projective u'' is monotone along the grid's axes (c.z > 0 over
-      // the brick: the class was proven for a box that holds it, 4b.2), so it lies between the real corner values; a computed
-      // corner value is within 2^-20 of the largest corner magnitude `umag` of the model's (anchor, step and sum roundings of
-      // numerator and c.z: 4 * 2^-24 each, times c.z's ratio over the brick <= 1.25; v_rcp_f32's ulp and the product's), the model
-      // within ferr / c.z of the reference's numerator (4e.6; ferr also covers c.z's model, times |u''| <= X_max), the reference's
-      // quotient and rounding as in 4b.2: e = 2 ferr / czmin + 2^-19 umag + 2^-12, twice what is needed.
-      uint32_t flag = 0;
-      if (want) {
+      WinPair wp;
+      wp.origin = kNotWanted;  // (stays: no window)
+      wp.ax = wp.ay = wp.acz = 0.f;
+      if (cload(&a.win_recs[m].e_abs) < __builtin_inff()) {  // (else the view has no windows: wave-uniform)
+        // the view's records: row 2 of [R|T], the centred rows, the corners' offsets, the bound
+        const MapRec *src = maps + m;
+        const TileMapRec *tsrc = a.tile_maps + m;
         const FootRec *fr = a.foot_recs + m;
-        const double cza = ((cload(&src->rt[8]) * wxa + cload(&src->rt[9]) * wya) + cload(&src->rt[10]) * wza) + cload(&src->rt[11]);
-        const double hxa = __builtin_fma(cload(&tsrc->cpx), wxa, __builtin_fma(cload(&tsrc->cpy), wya, __builtin_fma(cload(&tsrc->cpz), wza, cload(&tsrc->cp0))));
-        const double hya = __builtin_fma(cload(&tsrc->cqx), wxa, __builtin_fma(cload(&tsrc->cqy), wya, __builtin_fma(cload(&tsrc->cqz), wza, cload(&tsrc->cq0))));
-        const float hx0 = (float)hxa, hy0 = (float)hya, z0 = (float)cza;
-        float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
-        float zmin = __builtin_inff(), zmax = -__builtin_inff();
-        const float(*sc)[4] = tk == 16 ? fr->s16 : fr->s8;  // wave-uniform
+        const float(*scp)[4] = tk == 16 ? fr->s16 : fr->s8;  // wave-uniform
+        // Anchor in fp64 -- the centred numerators by the FMA chain over TileMapRec::cpx ..., c.z in the reference's order (cu:172),
+        // at the brick's first voxel --, the eight corner voxels relative to it in fp32 (FootRec: the steps are the view's, the
+        // same for every brick), the footprint from fp32 quotients.  Every voxel's reference pixel, counted from the image
+        // centre, lies in [umin - 1/2 - e, umax + 1/2 + e]: the real projective u'' is monotone along the grid's axes (c.z > 0 over
+        // the brick: the class was proven for a box that holds it, 4b.2), so it lies between the real corner values; a computed
+        // corner value is within 2^-20 of the largest corner magnitude `umag` of the model's (anchor, step and sum roundings of
+        // numerator and c.z: 4 * 2^-24 each, times c.z's ratio over the brick <= 1.25; v_rcp_f32's ulp and the product's), the model
+        // within ferr / c.z of the reference's numerator (4e.6; ferr also covers c.z's model, times |u''| <= X_max), the reference's
+        // quotient and rounding as in 4b.2: e = 2 ferr / czmin + 2^-19 umag + 2^-12, twice what is needed.
+        if (want) {
+          const double cza = ((cload(&src->rt[8]) * wxa + cload(&src->rt[9]) * wya) + cload(&src->rt[10]) * wza) + cload(&src->rt[11]);
+          const double hxa = __builtin_fma(cload(&tsrc->cpx), wxa, __builtin_fma(cload(&tsrc->cpy), wya, __builtin_fma(cload(&tsrc->cpz), wza, cload(&tsrc->cp0))));
+          const double hya = __builtin_fma(cload(&tsrc->cqx), wxa, __builtin_fma(cload(&tsrc->cqy), wya, __builtin_fma(cload(&tsrc->cqz), wza, cload(&tsrc->cq0))));
+          const float hx0 = (float)hxa, hy0 = (float)hya, z0 = (float)cza;
+          float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
+          float zmin = __builtin_inff(), zmax = -__builtin_inff();
 #pragma unroll
-        for (int cnr = 0; cnr < 8; ++cnr) {
-          const float z = z0 + cload(&sc[cnr][2]);
-          const float r = __builtin_amdgcn_rcpf(z);
-          const float u = (hx0 + cload(&sc[cnr][0])) * r, v = (hy0 + cload(&sc[cnr][1])) * r;
-          umin = __builtin_fminf(umin, u), umax = __builtin_fmaxf(umax, u);
-          vmin = __builtin_fminf(vmin, v), vmax = __builtin_fmaxf(vmax, v);
-          zmin = __builtin_fminf(zmin, z), zmax = __builtin_fmaxf(zmax, z);
-        }
-        // (NaN anywhere fails a compare below; |u| < 2^16 keeps the float -> int conversions exact)
-        const float umag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(umin), __builtin_fabsf(umax)), __builtin_fmaxf(__builtin_fabsf(vmin), __builtin_fabsf(vmax)));
-        const float e = 2.0f * cload(&fr->ferr) * __builtin_amdgcn_rcpf(zmin) * (1.0f + 0x1p-20f) + (0x1p-19f * umag + 0x1p-12f);
-        const bool sane = zmin > 0.0f && zmax <= (float)(kWinCzRatio * (1.0 - 0x1p-20)) * zmin && umin > -65536.0f && umax < 65536.0f &&
-                          vmin > -65536.0f && vmax < 65536.0f && e < 0.25f;
-        if (sane) {
-          const int cxc = a.W / 2, cyc = a.H / 2;
-          const int x0 = (int)__builtin_ceilf(umin - 0.5f - e) + cxc, x1 = (int)__builtin_floorf(umax + 0.5f + e) + cxc;
-          const int y0 = (int)__builtin_ceilf(vmin - 0.5f - e) + cyc, y1 = (int)__builtin_floorf(vmax + 0.5f + e) + cyc;
-          // inside the image or its margin of "no depth" (4b.9), and no wider than a window
-          if (x0 >= -kValidMargin && y0 >= -kValidMargin && x1 < a.W + kValidMargin && y1 < a.H + kValidMargin &&
-              x1 - x0 < kWindowCols && y1 - y0 < kWindowRows) {
-            WinPair wp;
-            wp.origin = (uint32_t)(x0 + kValidMargin) | ((uint32_t)(y0 + kValidMargin) << 16);
-            // the window's first pixel counted from the image centre (integers: exact)
-            wp.ax = (float)(hxa - (double)(x0 - cxc) * cza);
-            wp.ay = (float)(hya - (double)(y0 - cyc) * cza);
-            wp.acz = z0;
-            origins[row + m] = wp;
-            flag = CLASS_HAS_WINDOW;
+          for (int cnr = 0; cnr < 8; ++cnr) {
+            const float z = z0 + cload(&scp[cnr][2]);
+            const float r = __builtin_amdgcn_rcpf(z);
+            const float u = (hx0 + cload(&scp[cnr][0])) * r, v = (hy0 + cload(&scp[cnr][1])) * r;
+            umin = __builtin_fminf(umin, u), umax = __builtin_fmaxf(umax, u);
+            vmin = __builtin_fminf(vmin, v), vmax = __builtin_fmaxf(vmax, v);
+            zmin = __builtin_fminf(zmin, z), zmax = __builtin_fmaxf(zmax, z);
+          }
+          // (NaN anywhere fails a compare below; |u| < 2^16 keeps the float -> int conversions exact)
+          const float umag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(umin), __builtin_fabsf(umax)), __builtin_fmaxf(__builtin_fabsf(vmin), __builtin_fabsf(vmax)));
+          const float e = 2.0f * cload(&fr->ferr) * __builtin_amdgcn_rcpf(zmin) * (1.0f + 0x1p-20f) + (0x1p-19f * umag + 0x1p-12f);
+          const bool sane = zmin > 0.0f && zmax <= (float)(kWinCzRatio * (1.0 - 0x1p-20)) * zmin && umin > -65536.0f && umax < 65536.0f &&
+                            vmin > -65536.0f && vmax < 65536.0f && e < 0.25f;
+          if (sane) {
+            const int cxc = a.W / 2, cyc = a.H / 2;
+            const int x0 = (int)__builtin_ceilf(umin - 0.5f - e) + cxc, x1 = (int)__builtin_floorf(umax + 0.5f + e) + cxc;
+            const int y0 = (int)__builtin_ceilf(vmin - 0.5f - e) + cyc, y1 = (int)__builtin_floorf(vmax + 0.5f + e) + cyc;
+            // inside the image or its margin of "no depth" (4b.9), and no wider than a window
+            if (x0 >= -kValidMargin && y0 >= -kValidMargin && x1 < a.W + kValidMargin && y1 < a.H + kValidMargin &&
+                x1 - x0 < kWindowCols && y1 - y0 < kWindowRows) {
+              wp.origin = (uint32_t)(x0 + kValidMargin) | ((uint32_t)(y0 + kValidMargin) << 16);
+              // the window's first pixel counted from the image centre (integers: exact)
+              wp.ax = (float)(hxa - (double)(x0 - cxc) * cza);
+              wp.ay = (float)(hya - (double)(y0 - cyc) * cza);
+              wp.acz = z0;
+            }
           }
         }
-        c4 = (c4 & ~((uint32_t)CLASS_HAS_WINDOW << (8 * q))) | (flag << (8 * q));
+      }
+      if (want) {
+        if (wp.origin != kNotWanted)
+          tile[4 * g + q][threadIdx.x] = wp;
+        else
+          classes[row + m] = (uint8_t)(c | CLASS_NO_WINDOW);  // the exception: a byte store of its own
       }
     }
-    if (c4 != before) *reinterpret_cast<uint32_t *>(classes + row + m4) = c4;
+  }
+  __syncthreads();
+  // a brick's eight entries are one 128-byte line: eight consecutive lanes write it
+  const int v = threadIdx.x & (kOriginViews - 1);
+  const int m = g_lo + v;
+  if (v < group_views && m < m_end) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int b = (threadIdx.x >> 3) + 32 * it;
+      const WinPair wp = tile[v][b];
+      if (wp.origin != kNotWanted) origins[rows[b] + m] = wp;
+    }
   }
 }
 

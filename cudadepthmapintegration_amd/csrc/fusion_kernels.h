@@ -133,10 +133,12 @@ __host__ __device__ inline int64_t valid_map_bytes(int W, int H) {
 __host__ __device__ inline int valid_bits_tiles_x(int W) { return (W + 2 * kValidMargin + 31) / 32 + 1; }
 __host__ __device__ inline int valid_bits_tiles_y(int H) { return (H + 2 * kValidMargin + 31) / 32; }
 __host__ __device__ inline int64_t valid_bits_bytes(int W, int H) { return (int64_t)valid_bits_tiles_x(W) * valid_bits_tiles_y(H) * 128; }
-// the window of the FREE column: kWindowCols x kWindowRows pixels (a dword per lane); a class byte with CLASS_HAS_WINDOW says
-// that TileArgs::win_origin holds the window's first pixel for the pair
+// the window of the FREE column: kWindowCols x kWindowRows pixels (a dword per lane); TileArgs::win_origin holds the window's
+// first pixel for the pair.  A launch with windows gives one to nearly every pair of class MIXED_FREE_OR_NODEPTH (99 % at cfg 3),
+// so the class byte marks the EXCEPTIONS: CLASS_NO_WINDOW, written by window_origin_kernel for the few pairs whose footprint
+// does not fit (until round 5 the bit said "has a window": sixteen million scattered read-modify-writes per fusion)
 constexpr int kWindowCols = 32, kWindowRows = 64;
-constexpr uint8_t CLASS_HAS_WINDOW = 0x20;
+constexpr uint8_t CLASS_NO_WINDOW = 0x20;
 static_assert(sizeof(TileMapRec) == 368, "TileMapRec layout");
 
 // What the window form of the FREE column needs of a view (round 5): ONE 64-byte line, all fp32, fetched with one scalar load per
@@ -260,7 +262,7 @@ struct TileArgs {
   int64_t wg_times_n;
   // brick counters of the persistent workgroups, one per XCD at [16 * xcd]; zeroed by the table kernel of every launch
   int32_t *queue_heads;
-  // Windows of the FREE column (round 4; WinPair since round 5): for a pair whose class byte carries CLASS_HAS_WINDOW,
+  // Windows of the FREE column (round 4; WinPair since round 5): for a pair of class MIXED_FREE_OR_NODEPTH,
   // win_origin[brick * class_pitch + view] holds the first pixel of a kWindowCols x kWindowRows window that holds the reference's
   // pixel of every voxel of the brick, and the window-relative numerators at the brick's first voxel (window_origin_kernel,
   // fusion_classify.hip).  The fusion kernel reaches the entry from the brick's class row: (WinPair *)(win_delta + 16 *
@@ -355,7 +357,7 @@ constexpr int kMaxColumnHeight = 16;  // the tallest column of any tile shape: w
 struct TileShape {
   int tk, wx, wy;  // column height; waves per workgroup along x and y (a wave is 8 x 8 lanes)
 };
-TileShape tile_shape(int variant, bool depth_is_f64, bool rotated_or_general_k);  // those run the two default shapes only
+TileShape tile_shape(int variant, bool depth_is_f64, bool rotated, bool general_k);  // (rotated: the two default shapes; general K: 16-voxel columns)
 
 // Enqueues the general fusion kernel on `stream`.  Returns hipSuccess or the launch error.
 hipError_t launch_fuse(const FuseArgs &args, const FuseConfig &cfg, hipStream_t stream);
@@ -384,7 +386,7 @@ hipError_t launch_upload_views(const void *in, int in_is_f64, const double *best
                                unsigned long long *counters, hipStream_t stream);
 hipError_t launch_build_pyramid_levels(int64_t n_maps, const PyramidDesc &desc, DepthTile *pyramids, hipStream_t stream);
 // window origins of the FREE column for the pairs of class MIXED_FREE_OR_NODEPTH of maps [first_map, first_map + n_maps): fills
-// args.win_origin and marks the class bytes (CLASS_HAS_WINDOW); after launch_classify_bricks
+// args.win_origin and marks the class bytes of those without a window (CLASS_NO_WINDOW); after launch_classify_bricks
 hipError_t launch_window_origins(const TileArgs &args, const MapRec *maps_dev, int tk, uint8_t *classes, int general_k,
                                  hipStream_t stream);
 // classes[brick][map] for maps [first_map, first_map + n_maps): see BrickClass.  tk = column height.

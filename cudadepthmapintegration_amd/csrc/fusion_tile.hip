@@ -285,13 +285,19 @@ constexpr int acc_base(int minw) { return minw >= 8 ? 64 : minw == 7 ? 72 : minw
 // -- what enters the ray potential -- is exact in every instantiation.  Pinhole views run through the same code: for
 // them h.z restates c.z and errz is 0.
 // WIN: the launch has window origins (TileArgs::win_origin: depth maps with holes scattered all over them); pairs marked
-// CLASS_HAS_WINDOW take the window form of the FREE column.  An instantiation of its own: the other launches run the kernel
+// with a window (a WinPair entry with an origin) take the window form of the FREE column.  An instantiation of its own: the other launches run the kernel
 // without a trace of it (its code costs every column scalar registers, i.e. spill traffic, whether or not a pair uses it).
+// ZF: no sum of the launch can be -0.0 and hits are not counted (TileArgs::behind_mask set: the grid started from zeros, or the
+// context owns it and only fusions have written it since its reset) -- what every production launch is.  Adding the
+// +0.0 of "far behind" (cu:115) is then no operation at all, known at compile time: BEHIND pairs are skipped, and the ray
+// potential of a voxel is ONE asm statement whose compares write EXEC themselves (fusion_tile_acc.inc: acc_potential_*), where
+// the general form spends some twenty scalar instructions and four branches per voxel on lane masks.
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool COUNT, bool ROT = false, bool GENK = false,
-          bool STAY = (WX * WY == 1), bool WIN = false>
+          bool STAY = (WX * WY == 1), bool WIN = false, bool ZF = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const TileArgs a) {
   typedef DepthLoad<DepthT> DL;
   static_assert(!WIN || (DMI_TIER1 != 0 && !GENK && !COUNT && WX * WY == 1), "the window column is a tier-1 column without hit counters");
+  static_assert(!ZF || !COUNT, "hit counters take every view singly");
   // The argument block is read where it is needed, straight from the kernarg segment (scalar loads), instead of through
   // the by-value parameter: the view loop below has no scalar registers to spare, and what it does not use must not stay
   // live across it.  KA(f): a plain load (the compiler may keep it); KC(f): a load the compiler cannot hoist or merge
@@ -312,11 +318,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   const int first_map = KA(first_map);
   const int m_end = first_map + KA(n_maps);
   double delta = KA(delta), thick = KA(thick), free_space = KA(free_space), rho_pos = KA(rho_pos), slope = KA(slope);
-  int keep_zero_adds = KA(behind_mask) == 0 ? 1 : 0;
+  int keep_zero_adds = ZF ? 0 : (KA(behind_mask) == 0 ? 1 : 0);
   // Values, not loads: without this the compiler re-reads them from the argument block (a scalar load and a wait) next
   // to every use.  The two thresholds and the slope only ever meet per-lane operands: they live in VGPRs.
   free_space = pinned(free_space), rho_pos = pinned(rho_pos);
-  keep_zero_adds = pinned_word(keep_zero_adds);
+  if constexpr (!ZF) keep_zero_adds = pinned_word(keep_zero_adds);
   asm volatile("" : "+v"(delta), "+v"(thick), "+v"(slope));
   unsigned vW = (unsigned)KA(W), vH = (unsigned)KA(H);
   asm("" : "+v"(vW));
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     }
     // fetched one word ahead: its latency hides behind this word's views.  behind_mask turns BEHIND (2) into SKIP (3)
     // when x + 0.0 == x for every running sum: sums that start at +0.0 never become -0.0
-    const unsigned long long cword = cnext | ((cnext >> 1) & KC(behind_mask));
+    const unsigned long long cword = cnext | ((cnext >> 1) & (ZF ? 0x0101010101010101ull : KC(behind_mask)));
     if (wbase + 8 < m_end) cnext = cload(crow + (wbase >> 3) + 1);
     const unsigned long long nonskip = cword ^ 0x0303030303030303ull;  // a BRICK_SKIP byte becomes 0
     unsigned long long todo = (nonskip | (nonskip >> 1)) & 0x0101010101010101ull;  // bit 8i: view wbase + i needs work
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       for (int q = 0; q < TK; ++q) acc_set<BASE, TK>(q, v);
       n_uniform = -1;
     }
-    const unsigned cbyte = (unsigned)(cword >> vbit) & 0x3fu;  // class in bits 0..1, MixedReason above it, CLASS_HAS_WINDOW
+    const unsigned cbyte = (unsigned)(cword >> vbit) & 0x3fu;  // class in bits 0..1, MixedReason above it
     const unsigned cls = cbyte & 3u;
     if (cls != BRICK_MIXED) {
       // BEHIND: +0 (cu:115; adding 0 turns -0.0 into +0.0 as the reference does); FREE when hits are counted
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       continue;
     }
     // ---- A pair with a WINDOW of validity bits (round 4): the FREE column without a gather per voxel.  The
-    // pair's class byte carries CLASS_HAS_WINDOW: window_origin_kernel has proven that every voxel's reference pixel lies in
+    // pair has a window (its class byte carries no CLASS_NO_WINDOW): window_origin_kernel has proven that every voxel's reference pixel lies in
     // the 32 x 64 pixels that start at (x0, y0) = TileArgs::win_origin[brick][view] (padded-image coordinates).  Lane r fetches
     // row y0 + r of the view's validity bits (two dwords from one or two 128-byte tiles, funnel-shifted to start at x0): two
     // coalesced loads per (brick, view), in flight while the column is set up.  A voxel asks the lane that holds its row with
@@ -608,13 +614,16 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
     // of tier 1 accepts or not (4d.3: any candidate will do).  What it does not accept is redone after the column, in fp64
     // (tier 2), then with the reference's expression.  The whole view is handled here, apart from the other columns, so that
     // nothing of it stays live across them.
+    // (a pair of the FREE column's class of a brick that does not stick out of the top of the grid has a window -- an entry in the
+    // pair table, window_origin_kernel -- unless its class byte says otherwise)
+    [[maybe_unused]] const bool has_window = WIN && cbyte == ((unsigned)MIXED_FREE_OR_NODEPTH << 2 | BRICK_MIXED) && kcount == TK;  // wave-uniform
 #ifdef DMI_TUNING
     ++dbg_cols;
-    if (WIN && ((kflags & TILE_FLAG_DBG_SKIP_WINDOW_PAIRS) && (cbyte & CLASS_HAS_WINDOW))) continue;
-    if ((kflags & TILE_FLAG_DBG_ONLY_WINDOW_PAIRS) && !(WIN && (cbyte & CLASS_HAS_WINDOW))) continue;
+    if ((kflags & TILE_FLAG_DBG_SKIP_WINDOW_PAIRS) && has_window) continue;
+    if ((kflags & TILE_FLAG_DBG_ONLY_WINDOW_PAIRS) && !has_window) continue;
 #endif
     if constexpr (WIN) {
-      if (cbyte & CLASS_HAS_WINDOW) {  // wave-uniform
+      if (has_window) {  // wave-uniform
 #ifdef DMI_TUNING
         ++dbg_win;
         if (dbg_cols == dbg_win) ++dbg_win_early;
@@ -634,8 +643,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
 #ifndef DMI_NO_WINREC_PREFETCH
         // the NEXT view's record on its way into the scalar cache (most of a brick's window views are consecutive): one dword of
         // its line into a register that is only waited for, after the column (the table has room beyond the last view)
+        // (issued once THIS record has arrived -- the unused operand says so --: the wait for it must not cover the next one's trip)
         int next_rec;
-        asm volatile("s_load_dword %0, %1, 0x40" : "=&s"(next_rec) : "s"(wrec));
+        asm volatile("s_load_dword %0, %1, 0x40" : "=&s"(next_rec) : "s"(wrec), "s"(R[15]));
 #endif
         const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<uint32_t *>((uintptr_t)R[0] | ((uintptr_t)R[1] << 32)), (short)0, kw->vb_bytes, 0x00020000);
@@ -1189,6 +1199,19 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             continue;
           }
           const typename DL::raw_t d = dg[q];  // lanes that did not load still hold the sentinel
+          if constexpr (ZF && !FREEONLY) {
+            // cu:105-120 in one statement (no sum can be -0.0: nothing to add where diff > delta).  A lane that did not load holds
+            // the sentinel (no depth, cu:202); in the SURFACE column every lane has a depth, and an unproven lane's is -inf:
+            // diff = +inf > delta, nothing added here, its value by the redo below.
+            if constexpr (std::is_same<DepthT, double>::value) {
+              if constexpr (SURFACE) acc_potential_all_f64<BASE, TK>(kk, d, czg[q], delta, thick, slope, free_space, rho_pos);
+              else acc_potential_f64<BASE, TK>(kk, d, czg[q], delta, thick, slope, free_space, rho_pos);
+            } else {
+              if constexpr (SURFACE) acc_potential_all_f32<BASE, TK>(kk, d, czg[q], delta, thick, slope, free_space, rho_pos);
+              else acc_potential_f32<BASE, TK>(kk, d, czg[q], delta, thick, slope, free_space, rho_pos);
+            }
+            continue;
+          }
           // cu:177, cu:192-197 (not loaded) and cu:202 (no depth) alike; SURFACE: every lane has a depth
           const mask_t m_hit = SURFACE ? ~0ull : ballot(!DL::is_sentinel(d));
           if constexpr (FREEONLY) {
@@ -1358,17 +1381,28 @@ unsigned resident_workgroups(Kernel kernel, int threads) {
   return (unsigned)(per_cu * prop.multiProcessorCount + 7) / 8u * 8u;  // the same number for every XCD
 }
 
+// One launch of the tiled kernel in the given shape.  Which instantiations exist (round 5; 224 of them took five minutes to build):
+//   * the production path -- f32 depth tables, pinhole views, one wave per workgroup -- in both launch forms (persistent / one
+//     workgroup per brick), with the ZF specialisation (no sum can be -0.0, no hit counters: what every fusion from a reset grid
+//     is), its general twin and the counted kernel; the window column (WIN) only with ZF: the host hands out window origins only
+//     to such launches (dmi_capi.hip: the FREE column they refine is not even chosen on a grid that may hold -0.0, 4b.8);
+//   * f64 depth tables (depths that are no f32: DMI_DEPTH_AUTO's promotion) and general K: the persistent form only, plain and
+//     counted -- correct on every input, tuned for none.
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false, bool WIN = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   static_assert(TK <= kMaxColumnHeight, "dmi_multi_z_slab aligns slabs to kMaxColumnHeight");
+  constexpr bool one_wave = WX * WY == 1;
+  constexpr bool rare = std::is_same<DepthT, double>::value || GENK;  // one launch form, no specialisation
+  static_assert(!WIN || (one_wave && !rare), "window launches are production launches");
   // one workgroup per brick: super-bricks padded to a multiple of 8 runs (one run per XCD and round), 32 workgroups each
   // (+ 32: an XCD's eighths of the four levels can add up to four workgroups more than an eighth of the total)
   const int per_round = 8 * a.xcd_run_wg;
   unsigned blocks = (unsigned)((a.super_x * a.super_y * a.super_z * 32 + 32 + per_round - 1) / per_round * per_round);
   const dim3 block(64 * WX * WY);
-  const auto counted = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>;
-  const auto plain = fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, (WX * WY == 1), WIN>;
-  if constexpr (WX * WY == 1) {
+  const bool zf = a.behind_mask != 0 && !cfg.count_hits;  // the production launches: no sum can be -0.0, no hit counters
+  if (WIN && !zf) return hipErrorInvalidValue;            // (the host gives window origins to ZF launches only)
+  bool stay = true;
+  if constexpr (one_wave && !rare) {
     // Persistent workgroups or one workgroup per brick?  Measured per size and scene at the round-4 kernel (both forms of one
     // library, rounds interleaved: profiles/r16f_form_sweep.txt), main kernel, per-brick / persistent:
     //   maps without holes (most bricks light):  128^3 x 64 views 0.100 / 0.162 ms, 256^3 x 64 0.246 / 0.338, 256^3 x 128
@@ -1380,72 +1414,95 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     // (round 3's rule -- persistent from 48 views on every grid of up to 2^18 bricks -- was fitted to a kernel whose light bricks
     // cost twice as much; it had cfg 2's dense scene at 0.34 ms where the per-brick form takes 0.25)
     const int64_t voxels = (int64_t)a.super_x * a.super_y * a.super_z * 32 * 64 * TK;  // of this launch's slab, padding included
-    const bool stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
-                      : (cfg.variant & VAR_PERSISTENT_NEVER) ? false
-                      : (cfg.variant & VAR_NO_BRICK_CLASSES) ? true
-                      : cfg.holes ? (a.n_maps >= 48 && voxels >= (int64_t(1) << 24))
-                                  : (a.n_maps >= kPersistentMinViews && voxels >= (int64_t(1) << 27));
-    if (!stay) {
-      if (cfg.count_hits)
-        hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>), dim3(blocks), block, 0, s, a);
-      else
-        hipLaunchKernelGGL((fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false, WIN>), dim3(blocks), block, 0, s, a);
-      return hipGetLastError();
-    }
-    // persistent one-wave workgroups: as many as the chip holds (asked once per instantiation)
-    static const unsigned resident[2] = {resident_workgroups(plain, 64), resident_workgroups(counted, 64)};
-    blocks = std::min(blocks, resident[cfg.count_hits ? 1 : 0]);
+    stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
+           : (cfg.variant & VAR_PERSISTENT_NEVER) ? false
+           : (cfg.variant & VAR_NO_BRICK_CLASSES) ? true
+           : cfg.holes ? (a.n_maps >= 48 && voxels >= (int64_t(1) << 24))
+                       : (a.n_maps >= kPersistentMinViews && voxels >= (int64_t(1) << 27));
   }
-  if (cfg.count_hits)
-    hipLaunchKernelGGL(counted, dim3(blocks), block, 0, s, a);
-  else
-    hipLaunchKernelGGL(plain, dim3(blocks), block, 0, s, a);
-  return hipGetLastError();
+  // (persistent one-wave workgroups: as many as the chip holds, asked once per instantiation)
+  auto launch = [&](auto kernel, bool persistent) {
+    unsigned n = blocks;
+    if (persistent && one_wave) {
+      static const unsigned resident = resident_workgroups(kernel, 64);
+      n = std::min(n, resident);
+    }
+    hipLaunchKernelGGL(kernel, dim3(n), block, 0, s, a);
+    return hipGetLastError();
+  };
+  if constexpr (!WIN) {
+    if (cfg.count_hits) {
+      if constexpr (one_wave && !rare) {
+        if (!stay) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>, false);
+      }
+      return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>, true);
+    }
+  }
+  if constexpr (one_wave && !rare) {
+    if (zf) {
+      if (!stay) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false, WIN, true>, false);
+      return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, true, WIN, true>, true);
+    }
+  }
+  if constexpr (!WIN) {
+    if constexpr (one_wave && !rare) {
+      if (!stay) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false>, false);
+    }
+    return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>, true);
+  }
+  return hipErrorInvalidValue;
 }
 
 // Shapes 0 and 7 (the two that dmi_fuse picks by grid size) are built for every storage type; the other (tuning)
 // shapes only for f32 depth tables.
+// (the multi-wave shapes 1 .. 6 were round 1's shape sweep; no launch rule has picked one since and they are compiled into
+// tuning builds only -- DMI_TUNING --: elsewhere their variant bits mean the one-wave shape of the same column height)
 int effective_shape(int variant, bool depth_is_f64, bool rotated, bool general_k = false) {
-  const int shape = tile_shape_index(variant);
-  return ((depth_is_f64 || rotated || general_k) && shape != 7) ? 0 : shape;
+  int shape = tile_shape_index(variant);
+#ifndef DMI_TUNING
+  shape = (shape == 1 || shape == 3 || shape == 4 || shape == 7) ? 7 : 0;  // their column height, one wave per workgroup
+#endif
+  if (general_k) return 0;  // general K: 16-voxel columns only (launch_shape: a rare path, one shape, one launch form)
+  return ((depth_is_f64 || rotated) && shape != 7) ? 0 : shape;
+}
+
+// the window launches of the two default shapes (f32 depth tables only: launch_shape)
+template <typename DepthT, typename GridT, int TK, int MINW, bool ROT>
+hipError_t launch_win(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
+  if constexpr (DMI_TIER1 != 0 && std::is_same<DepthT, float>::value)
+    return launch_shape<DepthT, GridT, TK, 1, 1, MINW, 8, ROT, false, true>(a, cfg, s);
+  else
+    return hipErrorInvalidValue;
 }
 
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0, cfg.general_k != 0);
-  // a launch with window origins (dmi_capi.hip: maps with scattered holes, no hit counters, pinhole views): the WIN instantiations
-  // (a -DDMI_TIER1=0 build has no window column: the host allocates no origins then, dmi_capi.hip)
-#if DMI_TIER1
-  const bool win = a.win_origin != nullptr && !cfg.count_hits && !cfg.general_k;
-#define DMI_WIN_SHAPE(...) launch_shape<__VA_ARGS__>(a, cfg, s)
-#else
-  const bool win = false;
-#define DMI_WIN_SHAPE(...) hipErrorInvalidValue
-#endif
+  // a launch with window origins (dmi_capi.hip: maps with scattered holes, no hit counters, pinhole views, f32 depth tables, a
+  // grid free of -0.0): the WIN instantiations.  (A -DDMI_TIER1=0 build has no window column: the host allocates no origins.)
+  const bool win = DMI_TIER1 != 0 && std::is_same<DepthT, float>::value && a.win_origin != nullptr && !cfg.count_hits && !cfg.general_k &&
+                   a.behind_mask != 0;
 #ifdef DMI_FAST_BUILD  // development builds (seconds instead of minutes): the two default shapes, axis-aligned grid, pinhole views
   if (win) {
-    if (shape == 7) return DMI_WIN_SHAPE(DepthT, GridT, 8, 1, 1, 6, 8, false, false, true);
-    return DMI_WIN_SHAPE(DepthT, GridT, 16, 1, 1, 5, 8, false, false, true);
+    if (shape == 7) return launch_win<DepthT, GridT, 8, 6, false>(a, cfg, s);
+    return launch_win<DepthT, GridT, 16, 5, false>(a, cfg, s);
   }
   if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
 #else
-  if (cfg.general_k) {  // a general K among the views: the two default shapes, either kind of grid
-    if (a.rotated) {
-      if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true, true>(a, cfg, s);
-      return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true, true>(a, cfg, s);
-    }
-    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, false, true>(a, cfg, s);
+  if (cfg.general_k) {  // a general K among the views: 16-voxel columns, either kind of grid
+    if (a.rotated) return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true, true>(a, cfg, s);
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, false, true>(a, cfg, s);
   }
   if (a.rotated) {  // rotated grid: the two default shapes
     if (win) {
-      if (shape == 7) return DMI_WIN_SHAPE(DepthT, GridT, 8, 1, 1, 6, 8, true, false, true);
-      return DMI_WIN_SHAPE(DepthT, GridT, 16, 1, 1, 5, 8, true, false, true);
+      if (shape == 7) return launch_win<DepthT, GridT, 8, 6, true>(a, cfg, s);
+      return launch_win<DepthT, GridT, 16, 5, true>(a, cfg, s);
     }
     if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true>(a, cfg, s);
   }
+#ifdef DMI_TUNING
   if constexpr (std::is_same<DepthT, float>::value) {
     switch (shape) {
       case 1: return launch_shape<DepthT, GridT, 8, 2, 2, 6, 8>(a, cfg, s);   // 8-voxel columns, four waves per workgroup
@@ -1457,9 +1514,10 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       default: break;
     }
   }
+#endif
   if (win && (shape == 7 || shape == 0)) {
-    if (shape == 7) return DMI_WIN_SHAPE(DepthT, GridT, 8, 1, 1, 6, 8, false, false, true);
-    return DMI_WIN_SHAPE(DepthT, GridT, 16, 1, 1, 5, 8, false, false, true);
+    if (shape == 7) return launch_win<DepthT, GridT, 8, 6, false>(a, cfg, s);
+    return launch_win<DepthT, GridT, 16, 5, false>(a, cfg, s);
   }
   // 80 + 16 = 96 VGPRs: 5 waves; the whole column is one load group (8 gathers in flight before the first is consumed);
   // one wave per workgroup: an 8 x 8 x 8 brick is the unit of scheduling and of the heaviest-first order
@@ -1467,15 +1525,14 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight); one wave per workgroup
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
 #endif
-#undef DMI_WIN_SHAPE
 }
 
 }  // namespace
 
 int tile_shape_index(int variant) { return (variant & VAR_TILE_SHAPE_MASK) >> VAR_TILE_SHAPE_SHIFT; }
 
-TileShape tile_shape(int variant, bool depth_is_f64, bool rotated) {
-  switch (effective_shape(variant, depth_is_f64, rotated)) {
+TileShape tile_shape(int variant, bool depth_is_f64, bool rotated, bool general_k) {
+  switch (effective_shape(variant, depth_is_f64, rotated, general_k)) {
     case 0: return TileShape{16, 1, 1};
     case 7: return TileShape{8, 1, 1};
     case 1:
@@ -1508,7 +1565,7 @@ hipError_t launch_fuse_tiled(const TileArgs &a, const MapRec *maps_dev, const Fu
     if (e != hipSuccess) return e;
   }
   if (!(cfg.variant & VAR_NO_BRICK_CLASSES)) {
-    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0 || cfg.general_k != 0);
+    const TileShape sh = tile_shape(cfg.variant, cfg.depth_is_f64 != 0, a.rotated != 0, cfg.general_k != 0);
     e = launch_classify_bricks(a, maps_dev, pyramid, sh.tk, const_cast<uint8_t *>(a.classes), coarse_classes, cfg.general_k, stream);
     if (e != hipSuccess) return e;
     e = launch_window_origins(a, maps_dev, sh.tk, const_cast<uint8_t *>(a.classes), cfg.general_k, stream);

@@ -810,7 +810,8 @@ def test_free_column_through_bit_windows(rotated, focal_scale, wh, fits):
         if fits is True:
             assert n_win > (0.5 if variant == 0 else 0.25) * n_free, (focal_scale, counts)
 
-    # onto an uploaded grid (the sums do not start at zero: no uniform prefix, +0 adds kept)
+    # onto an uploaded grid (the sums do not start at zero: no uniform prefix, +0 adds kept; since round 5 such a launch gets no
+    # windows -- they come with the kernel's specialisation for grids free of -0.0 --: its FREE column gathers)
     init = np.random.default_rng(4).normal(size=(64, 80, 96))
     want_init = oracle.fuse(oracle_params_from_scene(grid, rp, speckled), speckled.depth, speckled.K4, speckled.RT4, init_grid=init,
                             n_threads=oracle.max_threads())[0]
@@ -819,7 +820,7 @@ def test_free_column_through_bit_windows(rotated, focal_scale, wh, fits):
         ctx.add_views(speckled)
         ctx.fuse()
         assert bits_equal(ctx.download_grid(), want_init), (rotated, focal_scale)
-        assert ctx.window_pair_count() > 0 or fits is not True
+        assert ctx.window_pair_count() == 0
     # maps with ONE large hole each: not "scattered", so no windows by default; forced, the border and hole pairs get them
     views.depth[:, 60:120, 80:200] = -1.0
     want_one = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
