@@ -1246,16 +1246,27 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
 
   cfg.use_tile = tiled ? 1 : 0;
   cfg.general_k = tiled && general_k ? 1 : 0;
-  {  // Holes scattered over the depth maps (a best-cost threshold's work): most pairs then are per-voxel work, which
-     // decides column height and launch form.  Told from holes in large regions (a silhouette against an empty background:
-     // most bricks stay light, 1024^3 x 64 views of the sparse scene 4.3 against 8.1 ms the other way) by the 8-pixel strips
-     // that hold both a hole and a depth: over half of them at 10 % scattered holes, a per cent along silhouettes.
-    unsigned long long mingled = 0, strips = 0;
+  // Holes SCATTERED over the depth maps (a best-cost threshold's work): from a hole density of a tenth of a per cent on,
+  // nearly every brick's footprint (600 - 1300 pixels) holds one, and the free-space pairs -- most of a fusion's pairs -- are
+  // per-voxel work (the FREE column): that decides the launch.  Measured at cfg 3 (profiles/r19m_hole_sweep.jsonl,
+  // r19n_hole_variants.jsonl; ms per fusion for 8-voxel columns / + windows / 16-voxel columns + windows):
+  //   f = 0.03 %  7.3 / 7.4 / 8.1     0.1 %  10.2 / 9.8 / 10.7     0.5 %  15.0 / 13.4 / 13.2     1 %  15.5 / 13.8 / 13.3
+  // (round 4's one bit -- an eighth of the 8-pixel strips holding both a hole and a depth, f >= 1.7 % -- left 0.5 % and 1 % at
+  // 15 ms, slower than 2 %'s 13.3).  The density is read from the share p of 8-pixel strips that hold both a hole and a depth
+  // (p ~ 8 f); holes in REGIONS (silhouettes against an empty background, patches a filter removed) have mingled strips only
+  // along their borders, many hole pixels per mingled strip, and keep the launch of maps without holes (1024^3 x 64 views of
+  // the sparse scene: 4.3 against 8.1 ms the other way).
+  bool tall_by_holes = false;
+  {
+    unsigned long long mingled = 0, strips = 0, without = 0;
     for (const Batch &bt : ctx->batches) {
       mingled += bt.mingled_strips;
+      without += bt.holes;
       strips += (unsigned long long)bt.n * (unsigned long long)ctx->W * (unsigned long long)(ctx->H / 8);
     }
-    cfg.holes = mingled * 8 > strips ? 1 : 0;
+    const bool scattered = without <= 6 * mingled;     // a scattered hole has its strip to itself; a disc of radius r has ~0.8 r pixels per border strip
+    cfg.holes = scattered && mingled * 160 > strips ? 1 : 0;    // p > 1/160 (f > 0.08 %): windows, persistent workgroups from 48 views on
+    tall_by_holes = scattered && mingled * 40 > strips;         // p > 1/40 (f > 0.3 %): 16-voxel columns from 256^3 on
   }
   // ... and maps that are mostly EMPTY in large regions (a silhouette against nothing: a quarter of the pixels or more without a
   // depth, the holes not mingled with depths): most (brick, view) pairs are skipped and a brick's fixed costs dominate
@@ -1279,7 +1290,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // cfg 3 -2.2 %, cfg 3 with VGA maps -5.6 %, cfg 4's share -5.7 %; 128^3 ties; dense cfg 3 +6.7 %: profiles/r08z_*)
     // Mostly empty maps: 16-voxel columns from 384^3 on (sparse scene, round 4's last build: 512^3 x 256 views 2.36 -> 2.12 ms,
     // 512^3 x 64 0.65 -> 0.57, 384^3 x 128 0.62 -> 0.59; 256^3 x 64 the other way, 0.13 -> 0.15: profiles/r18i_*, r18j_*)
-    if (bricks16 <= 32768 && !(cfg.holes && bricks16 >= 4096) && !(mostly_empty && bricks16 >= 13824))
+    if (bricks16 <= 32768 && !(tall_by_holes && bricks16 >= 4096) && !(mostly_empty && bricks16 >= 13824))
       cfg.variant |= 7 << dmi::VAR_TILE_SHAPE_SHIFT;
   }
 
