@@ -57,7 +57,7 @@ L2_GATHER_PEAK_GBPS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": rows served
 FLOP_PER_PROJECTION = 48.0  # algorithmic fp64 flop per voxel-projection
 MAPREC_BYTES = 208  # per-map camera record read by the kernel (fusion_kernels.h)
 
-SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room", "blobs")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room", "blobs", "geo")  # scene.SCENE_KINDS (scene.py is imported after the argument parser)
 SCENE_SEED = 1000
 
 
@@ -402,6 +402,10 @@ def main():
     cells, maps_per_gpu, W, H = parse_workload(args.workload)
     grid = scene.default_grid(cells)
     ray = scene.default_ray_potential(grid)
+    if args.scene == "geo":
+        args.no_scenes = True  # (the other scene kinds live in the unit cube: they are not timed beside this one)
+    if args.scene == "geo":  # real-world magnitudes: the speckle scene, grid and all, in a geo-referenced frame (scene.to_world_frame)
+        grid, ray = scene.geo_grid(grid, ray)
     n_vox = grid.n_voxels
     grid_bytes = 4 if args.grid_dtype == "f32" else 8
     np_grid = np.float32 if args.grid_dtype == "f32" else np.float64
@@ -614,6 +618,7 @@ def main():
         "brick_classes": hist,
         "mixed_reasons": ctx.mixed_reason_histogram(),
         "window_pairs": ctx.window_pair_count(),
+        "view_paths": ctx.view_paths(),
         # what actually bounds the default path: instruction issue (issue_roofline below)
         "roofline_issue": issue_roofline(issue_counts, main_ms),
         "box_state": {"fp64_vector_tflops_now": fp64_now, "peak": FP64_VECTOR_PEAK_TFLOPS,

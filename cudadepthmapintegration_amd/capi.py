@@ -100,7 +100,7 @@ ABI_SYMBOLS = [
     "dmi_get_brick_class_histogram", "dmi_get_timings", "dmi_get_info", "dmi_alloc_pinned", "dmi_free_pinned", "dmi_pcie_probe", "dmi_fp64_probe", "dmi_abi_version", "dmi_device_count",
     "dmi_color_mesh", "dmi_color_last_error", "dmi_cell_to_point", "dmi_download_point_data_f64",
     "dmi_point_data_device_pointer", "dmi_color_create", "dmi_color_destroy", "dmi_color_add_views",
-    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram", "dmi_get_window_pair_count", "dmi_get_upload_kernel_ms", "dmi_sizeof_info", "dmi_sizeof_timings",
+    "dmi_color_clear_views", "dmi_color_process", "dmi_color_get_kernel_ms", "dmi_get_mixed_reason_histogram", "dmi_get_window_pair_count", "dmi_get_view_paths", "dmi_get_upload_kernel_ms", "dmi_sizeof_info", "dmi_sizeof_timings",
     "dmi_color_set_scratch_budget", "dmi_color_set_vertex_reorder", "dmi_iso_active_cells",
     "dmi_multi_default_options", "dmi_multi_view_shard", "dmi_multi_z_slab", "dmi_multi_slab_ranges", "dmi_multi_peer_chunk", "dmi_multi_create",
     "dmi_multi_get_unique_id", "dmi_multi_create_rank", "dmi_multi_destroy", "dmi_multi_last_error", "dmi_multi_add_views",
@@ -174,6 +174,8 @@ def load() -> ctypes.CDLL:
     L.dmi_get_mixed_reason_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     if hasattr(L, "dmi_get_window_pair_count"):  # (absent from an older prebuilt library loaded for an A/B timing, tools/gpu_exp.py)
         L.dmi_get_window_pair_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    if hasattr(L, "dmi_get_view_paths"):
+        L.dmi_get_view_paths.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     if hasattr(L, "dmi_get_upload_kernel_ms"):
         L.dmi_get_upload_kernel_ms.argtypes = [vp, dp, dp]
     for name in ("dmi_sizeof_info", "dmi_sizeof_timings"):
@@ -481,6 +483,15 @@ class FusionContext:
         i = InfoC()
         self._check(self._lib.dmi_get_info(self._h, ctypes.byref(i)))
         return i
+
+    def view_paths(self) -> dict:
+        """How many resident views take which path (dmi_get_view_paths)."""
+        names = ("general_kernel", "tiled_general_k", "tiled_fp64_selection", "tiled_tier1", "tiled_tier1_per_lane_margin", "with_window_record")
+        if not hasattr(self._lib, "dmi_get_view_paths"):
+            return {}
+        a = (ctypes.c_uint64 * 6)()
+        self._check(self._lib.dmi_get_view_paths(self._h, a))
+        return {k: int(v) for k, v in zip(names, a)}
 
 
 def _grid_c(grid: GridDesc) -> GridDescC:

@@ -392,8 +392,8 @@ float float_not_below(double x) {
 // (TileMapRec::cpx ...), in two tiers (fusion_tile.hip).  P, Q, S: rows 0..2 of K*[R|T]; Sx, Sy: magnitudes of
 // the terms of h.x, h.y over the grid; M[2]: of c.z.
 void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4], const double Q[4], const double S[4],
-                       double Sx, double Sy, const double M[3], bool general, bool aligned, TileMapRec *out, dmi::WinRec *win,
-                       dmi::FootRec *foot) {
+                       double Sx, double Sy, const double M[3], double zabs, double zscale, bool general, bool aligned, TileMapRec *out,
+                       dmi::WinRec *win, dmi::FootRec *foot) {
   TileMapRec &t = *out;
   std::memset(foot, 0, sizeof(*foot));
   std::memset(win, 0, sizeof(*win));
@@ -425,13 +425,13 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
   const double rot = aligned ? 1.0 : 2.0;
   const double Sxc = Sx + cxc * M[2], Syc = Sy + cyc * M[2];
   const double cerr = rot * std::max(Sxc, Syc) * 0x1p-44;
-  t.cerrk = cerr + 0x1p-22 * M[2] * (1.0 + 0x1p-20);
+  t.cerrk = cerr + 0x1p-22 * zabs * (1.0 + 0x1p-20);  // (zabs >= |c.z| over the grid: make_tile_rec)
   t.t1_dhx = (float)t.cdhx;
   t.t1_dhy = (float)t.cdhy;
   const double dcz = t.dhz;  // pinhole: row 2 of [R|T] times the step of the world position per voxel along k
   t.t1_dcz = (float)dcz;
   t.t1_dthr = (float)(dcz * (double)t.t1_c1);
-  if (!(cerr < 0x1p-14)) return;  // (such a view fails the tiled kernel's per-view test anyway)
+  if (!(cerr < 0x1p-12 * zscale)) return;  // (such a view fails the tiled kernel's per-view test anyway)
   // c.z over the voxels of the grid: at least czmin (the real-valued minimum over the box of voxel centres, less the
   // rounding of the computed value)
   // (affine in the voxel indices: the extremes are at the eight corner voxels of the grid, whatever its axes)
@@ -539,7 +539,7 @@ void make_centred_rows(const dmi_context *ctx, const MapRec &r, const double P[4
 // pixel selection, and `err`, a bound on the absolute difference between the reference's computed
 // h.x / h.y and the kernel's affine evaluation anywhere in the grid (DESIGN.md "Tiled kernel: proof
 // obligations" derives the 73-ulp budget this bound covers seven times over).
-TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *win, dmi::FootRec *foot) {
+TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *win, dmi::FootRec *foot, double *zscale_out) {
   TileMapRec t;
   std::memset(&t, 0, sizeof(t));
   const double *rt = r.rt, *k = r.k;
@@ -615,9 +615,35 @@ TileMapRec make_tile_rec(const dmi_context *ctx, const MapRec &r, dmi::WinRec *w
   //   2^16 * errz / h.z              that of h.z, times |u| < 2^16 (beyond that both are outside any map),
   //   2^-22                          the slack of DESIGN.md 4.4, because Sz bounds |h.z| everywhere in the grid
   //                                  (Sz * r >= 1 - 2^-39).
-  t.errk = (t.err + 65536.0 * t.errz) + 0x1p-22 * Sz * (1.0 + 0x1p-20);
+  // Z >= |h.z| over the grid's voxels (and one column above).  General K: the sum of magnitudes.  Pinhole: c.z is affine in the
+  // voxel indices, so its extremes are at the grid's corner voxels -- their computed values, widened by the computed c.z's
+  // distance from the real one (16 ulp of the term magnitudes, twice that on a rotated grid).  (Until round 5 the sum of
+  // magnitudes served both: in a geo-referenced frame, where |T| ~ 1e6 cancels against R w, it overstates |c.z| a millionfold and
+  // the fp64 tier accepted next to nothing.)
+  double zabs = Sz, czlo = std::numeric_limits<double>::infinity(), czhi = -czlo;
+  if (!general) {
+    zabs = 0.0;
+    for (int c = 0; c < 8; ++c) {
+      double w[3];
+      voxel_world(ctx->grid, (c & 1) ? ctx->grid.cell_dims[0] - 1 : 0, (c & 2) ? ctx->grid.cell_dims[1] - 1 : 0,
+                  ctx->opt.z_first + ((c & 4) ? ctx->grid.cell_dims[2] - 1 + kMaxColumn : 0), w);
+      const double cz = ((rt[8] * w[0] + rt[9] * w[1]) + rt[10] * w[2]) + rt[11];
+      zabs = std::max(zabs, std::fabs(cz));
+      czlo = std::min(czlo, cz);
+      czhi = std::max(czhi, cz);
+    }
+    zabs = zabs * (1.0 + 0x1p-20) + (aligned ? 1.0 : 2.0) * 32.0 * 0x1p-52 * M[2];
+    if (!std::isfinite(zabs)) zabs = Sz;
+  }
+  // What "far below a pixel" is measured against: the bounds err, cerr are absolute (units of h.x), a voxel's share of a pixel is
+  // bound / c.z.  zscale: the depth of most of the grid as the view sees it -- its nearest corner, but no less than a sixteenth
+  // of its farthest (a camera inside the volume) and no less than 1.
+  double zscale = 1.0;
+  if (!general && std::isfinite(czlo) && std::isfinite(czhi)) zscale = std::max(1.0, std::max(czlo, czhi / 16.0));
+  t.errk = (t.err + 65536.0 * t.errz) + 0x1p-22 * zabs * (1.0 + 0x1p-20);
   t.depth = r.depth;
-  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, general, aligned, &t, win, foot);
+  make_centred_rows(ctx, r, P, Q, S, Sx, Sy, M, zabs, zscale, general, aligned, &t, win, foot);
+  if (zscale_out) *zscale_out = zscale;
   return t;
 }
 
@@ -683,7 +709,8 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     if (km < ctx->k_mode) ctx->k_mode = km;
     dmi::WinRec wrec;
     dmi::FootRec frec;
-    TileMapRec t = make_tile_rec(ctx, r, &wrec, &frec);
+    double zscale = 1.0;
+    TileMapRec t = make_tile_rec(ctx, r, &wrec, &frec, &zscale);
     t.valid = reinterpret_cast<const uint8_t *>(b.d_pyramid) + b.valid_offset + (size_t)m * (size_t)dmi::valid_map_bytes(ctx->W, ctx->H);
     t.vm_c0 = ((float)(ctx->H / 2 + dmi::kValidMargin) - 3.5f) * 0.125f;
     t.vm_w8 = (float)(8 * (ctx->W + 2 * dmi::kValidMargin) - 8);
@@ -701,9 +728,11 @@ int add_views_impl(dmi_context *ctx, const double *depth64, const float *depth32
     ctx->h_foot_recs.push_back(frec);
     if (!(t.err <= ctx->max_tile_err)) ctx->max_tile_err = t.err;  // NaN-propagating max
     ctx->view_k_mode.push_back((uint8_t)km);
-    // pixel selection must be provable for nearly every lane: the error bounds over h.z must stay far below one pixel
-    // (the centred rows' bound, cerrk, is below err + cxc * |c.z| terms: checked with the same limit)
-    ctx->view_tile_ok.push_back(finite && t.err < 0x1p-14 && 65536.0 * t.errz < 0x1p-14 && t.cerrk < 0x1p-13 ? 1 : 0);
+    // pixel selection must be provable for nearly every lane: the error bounds over h.z must stay far below one pixel at the
+    // depth of most of the grid (zscale, make_tile_rec): err / c.z < 2^-12 pixels sends about a voxel in a thousand to the exact
+    // expression -- a few per cent of a wave's voxels redone, against the general kernel's 6 x.  (Until round 5 the test was
+    // err < 2^-14 whatever the depth: a survey in a UTM frame with a long lens left the tiled kernel at offsets of 1e5.)
+    ctx->view_tile_ok.push_back(finite && t.err < 0x1p-12 * zscale && 65536.0 * t.errz < 0x1p-14 && t.cerrk < 0x1p-11 * zscale ? 1 : 0);
   }
   ctx->maps_dirty = true;
   ctx->timings.last_upload_ms =
@@ -1256,7 +1285,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
   // (p ~ 8 f); holes in REGIONS (silhouettes against an empty background, patches a filter removed) have mingled strips only
   // along their borders, many hole pixels per mingled strip, and keep the launch of maps without holes (1024^3 x 64 views of
   // the sparse scene: 4.3 against 8.1 ms the other way).
-  bool tall_by_holes = false;
+  bool tall_by_holes = false, many_borders = false;
   {
     unsigned long long mingled = 0, strips = 0, without = 0;
     for (const Batch &bt : ctx->batches) {
@@ -1267,6 +1296,9 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     const bool scattered = without <= 6 * mingled;     // a scattered hole has its strip to itself; a disc of radius r has ~0.8 r pixels per border strip
     cfg.holes = scattered && mingled * 160 > strips ? 1 : 0;    // p > 1/160 (f > 0.08 %): windows, persistent workgroups from 48 views on
     tall_by_holes = scattered && mingled * 40 > strips;         // p > 1/40 (f > 0.3 %): 16-voxel columns from 256^3 on
+    // holes in regions, but so many that a tenth of all strips lie on a border (discs over 40 % of the image: 11.5 -> 10.4 ms with
+    // windows, at 20 % a tie, profiles/r19p_hole_variants_blobs.jsonl): windows for the free-space pairs along those borders
+    many_borders = mingled * 10 > strips;
   }
   // ... and maps that are mostly EMPTY in large regions (a silhouette against nothing: a quarter of the pixels or more without a
   // depth, the holes not mingled with depths): most (brick, view) pairs are skipped and a brick's fixed costs dominate
@@ -1406,7 +1438,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
       // tables are f32: elsewhere the FREE column keeps its gathers)
       const bool zero_free = (!a.init_from_grid || ctx->grid_free_of_negative_zero) && !ctx->opt.count_hits && !(cfg.variant & dmi::VAR_KEEP_BEHIND_ADDS);
       const bool windows = DMI_TIER1 != 0 && !cfg.general_k && !cfg.count_hits && !(cfg.variant & (dmi::VAR_NO_WINDOWS | dmi::VAR_NO_INTERIOR)) &&
-                           (cfg.holes || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS)) && any_tier1 && zero_free && !ctx->depth_f64;
+                           (cfg.holes || many_borders || (cfg.variant & dmi::VAR_WINDOWS_ALWAYS)) && any_tier1 && zero_free && !ctx->depth_f64;
       const size_t cbytes = coarse_end + (windows ? fine_bytes * sizeof(dmi::WinPair) : 0);
       ctx->coarse_offset = fine_bytes;
       if (ctx->classes_capacity < cbytes) {
@@ -1868,6 +1900,26 @@ int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]) {
     const uint8_t *row = host.data() + (size_t)b * ctx->last_class_pitch + ctx->last_first;
     for (int32_t m = 0; m < ctx->last_count; ++m)
       if ((row[m] & 3) == dmi::BRICK_MIXED) out[(row[m] >> 2) & 7] += 1;
+  }
+  return DMI_OK;
+  });
+}
+
+int dmi_get_view_paths(dmi_context *ctx, uint64_t out[6]) {
+  return guarded(ctx, "dmi_get_view_paths", [&]() -> int {
+  if (!ctx || !out) return fail(ctx, DMI_ERR_INVALID_ARGUMENT, "dmi_get_view_paths: null argument");
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  const bool possible = tile_eligible(ctx);
+  for (size_t m = 0; m < ctx->h_maps.size(); ++m) {
+    const TileMapRec &t = ctx->h_tile_maps[m];
+    if (!possible || !ctx->view_tile_ok[m]) {
+      out[0] += 1;
+    } else if (ctx->view_k_mode[m] == dmi::K_GENERAL) {
+      out[1] += 1;
+    } else {
+      out[2 + std::min(std::max(t.t1_ok, 0), 2)] += 1;
+      if (t.t1_ok != 0 && std::isfinite(ctx->h_win_recs[m].e_abs)) out[5] += 1;
+    }
   }
   return DMI_OK;
   });

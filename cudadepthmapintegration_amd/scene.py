@@ -257,8 +257,15 @@ GEO_OFFSET = (448262.5, 5411932.25, 312.0)  # an easting / northing / height a U
 GEO_SCALE = 10.0                            # the cube [-1, 1]^3 becomes 20 m wide: 512^3 voxels of 3.9 cm
 
 
+def geo_grid(grid: GridDesc, ray: RayPotential):
+    """Grid and ray potential of the `geo` scene kind: the caller's, moved into the same frame as its views."""
+    empty = Views(np.zeros((0, 1, 1)), np.zeros((0, 4, 4)), np.zeros((0, 4, 4)))
+    g, r, _ = to_world_frame(grid, ray, empty, GEO_SCALE, GEO_OFFSET)
+    return g, r
+
+
 # ---- scenes as a stereo pipeline hands them over: invalid speckle, noise, holes --------------------------------------
-SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room", "blobs")
+SCENE_KINDS = ("dense", "sparse", "speckle", "noisy", "room", "blobs", "geo")
 SPECKLE_THRESHOLD = 0.9  # best cost ~ U[0, 1): "threshold chosen to kill ~10 % of pixels" (SURVEY.md 8d)
 
 
@@ -279,12 +286,22 @@ def make_scene_views(kind: str, n: int, W: int, H: int, seed: int = 0, view_rang
       noisy    speckle + depth noise (every depth += N(0, noise_sigma), in scene units: the bench passes one voxel's
                spacing) + `holes` discs of 8-40 pixels radius without depth per view
       room     a second geometry: cameras INSIDE the grid looking outward at the walls of a room (make_room_views) + the speckle
+      geo      speckle, geo-referenced: world' = 10 world + (448262.5, 5411932.25, 312) -- a 20 m cube of 3.9 cm voxels somewhere in a
+               UTM zone, cameras 30 m away, every translation ~5e6 (use geo_grid for the grid and the ray potential)
       blobs    dense + REGIONAL holes: discs of 8-40 pixels radius without depth, as many as cover about `speckle` of the image
                (what best-cost filtering leaves of real stereo output: whole patches, not salt and pepper); no best-cost values
     Depths stay f32-representable (the device keeps them as f32 without changing a bit); best cost is f64 as the
     reference's array is.  Views lo .. hi-1 of the n-camera scene when view_range is given."""
     if kind not in SCENE_KINDS:
         raise ValueError(f"scene kind {kind!r}: one of {SCENE_KINDS}")
+    if kind == "geo":
+        # the speckle scene in a geo-referenced frame (to_world_frame with GEO_SCALE / GEO_OFFSET): the caller's grid and ray
+        # potential must be moved alike (geo_grid)
+        v, thr = make_scene_views("speckle", n, W, H, seed=seed, view_range=view_range, noise_sigma=noise_sigma, speckle=speckle,
+                                  holes=holes, layout=layout)
+        unit = default_grid(8)
+        _, _, v = to_world_frame(unit, default_ray_potential(unit), v, GEO_SCALE, GEO_OFFSET)
+        return v, thr
     if kind == "room":
         # room: cameras inside the grid looking outward at the walls of a box (depths over an order of magnitude, grazing
         # walls, voxels behind every camera) + the same 10 % speckle as `speckle`

@@ -40,8 +40,9 @@
 extern "C" {
 #endif
 
-#define DMI_ABI_VERSION 4 /* 3: dmi_info grew (pixels_without_depth); dmi_iso_active_cells, DMI_EXCHANGE_PEER_COPY, dmi_multi_peer_chunk
-                           * 4: dmi_get_window_pair_count, dmi_get_upload_kernel_ms, dmi_sizeof_info / dmi_sizeof_timings */
+#define DMI_ABI_VERSION 5 /* 3: dmi_info grew (pixels_without_depth); dmi_iso_active_cells, DMI_EXCHANGE_PEER_COPY, dmi_multi_peer_chunk
+                           * 4: dmi_get_window_pair_count, dmi_get_upload_kernel_ms, dmi_sizeof_info / dmi_sizeof_timings
+                           * 5: dmi_get_view_paths */
 
 typedef struct dmi_context dmi_context;
 
@@ -240,6 +241,16 @@ int dmi_get_mixed_reason_histogram(dmi_context *ctx, uint64_t out[8]);
 /* Diagnostic: how many of the "free space or no depth" pairs (out[7] above) of the last dmi_fuse the fusion kernel served from a
  * window of validity bits (one coalesced fetch per pair) instead of one gather per voxel.  Synchronises. */
 int dmi_get_window_pair_count(dmi_context *ctx, uint64_t *out);
+
+/* Which path each resident view takes through the fusion (decided per view from its K, [R|T] and the grid, at dmi_add_views*):
+ *   out[0] general kernel (the tiled kernel's bounds do not hold for the view: 6 x slower per view at cfg 3)
+ *   out[1] tiled kernel, general K (third row not 0 0 1 0): pixels selected in fp64 only
+ *   out[2] tiled kernel, pinhole, fp64 selection only (tier 1 declined: maps beyond 2^24 pixels, bounds not finite)
+ *   out[3] tiled kernel, tier 1 with one margin for the view
+ *   out[4] tiled kernel, tier 1 with a margin per lane (the camera stands inside or next to the volume)
+ *   out[5] of the views counted in [3] and [4]: those with a window record (the window form of the FREE column can serve them)
+ * INTEGRATION.md "Magnitudes" says at which coordinate magnitudes a view changes rows. */
+int dmi_get_view_paths(dmi_context *ctx, uint64_t out[6]);
 
 /* dmi_get_info / dmi_get_timings fill sizeof(dmi_info) / sizeof(dmi_timings) bytes AS THIS LIBRARY WAS BUILT: a caller compiled
  * against an older header (a shorter struct) must check dmi_abi_version() == DMI_ABI_VERSION -- or compare its own sizeof with

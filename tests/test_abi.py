@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_defaults():
     lib = capi.load()
-    assert lib.dmi_abi_version() == 4
+    assert lib.dmi_abi_version() == 5
     o = capi.OptionsC()
     lib.dmi_default_options(ctypes.byref(o))
     assert (o.device, o.grid_dtype, o.depth_storage, o.count_hits, o.kernel_variant) == (0, capi.DMI_F64, 0, 0, 0)

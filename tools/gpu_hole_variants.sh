@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/${TAG}_hole_variants.jsonl; : > $OUT
 for f in $FR; do
 for v in 0 524288 528384 4096; do
-  timeout -k 10 300 python bench.py --workload cfg3 --scene speckle --hole-fraction $f --variant $v --steps 5 --warmup 2 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end --no-scenes 2> gpurun_out/${TAG}_hv.err | tail -1 > gpurun_out/${TAG}_hv.json || { echo "bench failed at $f $v"; tail -5 gpurun_out/${TAG}_hv.err; exit 1; }
+  timeout -k 10 300 python bench.py --workload cfg3 --scene ${SCENE:-speckle} --hole-fraction $f --variant $v --steps 5 --warmup 2 --no-cpu-baseline --no-ablation --no-coloration --no-end-to-end --no-scenes 2> gpurun_out/${TAG}_hv.err | tail -1 > gpurun_out/${TAG}_hv.json || { echo "bench failed at $f $v"; tail -5 gpurun_out/${TAG}_hv.err; exit 1; }
   python - gpurun_out/${TAG}_hv.json $f $v >> $OUT <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
