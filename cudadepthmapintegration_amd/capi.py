@@ -767,12 +767,21 @@ class ColorContext:
     def clear_views(self):
         self._check(self._lib.dmi_color_clear_views(self._h))
 
-    def process(self, points):
+    def process(self, points, out=None):
+        """(mean [n, 3] u8, median [n, 3] u8, count [n] i32) of the vertices `points` [n, 3] f64.  out: the three arrays to fill
+        (e.g. over pinned memory, pinned_empty -- with `points` pinned too the copies are DMA transfers that overlap the kernels of
+        the neighbouring chunks); else fresh ones."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         nv = pts.shape[0]
-        mean = np.zeros((nv, 3), dtype=np.uint8)
-        median = np.zeros((nv, 3), dtype=np.uint8)
-        count = np.zeros(nv, dtype=np.int32)
+        if out is None:
+            mean = np.zeros((nv, 3), dtype=np.uint8)
+            median = np.zeros((nv, 3), dtype=np.uint8)
+            count = np.zeros(nv, dtype=np.int32)
+        else:
+            mean, median, count = out
+            if (mean.shape, median.shape, count.shape) != ((nv, 3), (nv, 3), (nv,)) or mean.dtype != np.uint8 or median.dtype != np.uint8 \
+                    or count.dtype != np.int32 or not (mean.flags.c_contiguous and median.flags.c_contiguous and count.flags.c_contiguous):
+                raise ValueError("out = (mean [n, 3] u8, median [n, 3] u8, count [n] i32), contiguous")
         u8 = ctypes.POINTER(ctypes.c_uint8)
         self._check(self._lib.dmi_color_process(self._h, _dp(pts), nv, mean.ctypes.data_as(u8), median.ctypes.data_as(u8),
                                                 count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))

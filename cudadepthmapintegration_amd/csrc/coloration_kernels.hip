@@ -146,6 +146,54 @@ __device__ __forceinline__ double from_ordered_bits(unsigned long long u) {
   return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
 }
 
+// pmax[a] = max |p_a| over the chunk's vertices as the bits of a double (non-negative doubles order like their bits; a NaN or
+// an infinity counts as +inf); zeroed by the caller.  With view_margins_kernel this replaces a host loop over every vertex
+// (2 M vertices: 3-4 ms of a 5-6 ms call, round 4) and lets a chunk's kernels start without a trip through the host.
+__global__ __launch_bounds__(256) void chunk_magnitude_kernel(const double *__restrict__ points, int64_t nv, unsigned long long *__restrict__ pmax) {
+  const unsigned long long kInf = 0x7ff0000000000000ull;
+  unsigned long long hi[3] = {0ull, 0ull, 0ull};
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < nv; id += (int64_t)gridDim.x * blockDim.x)
+    for (int a = 0; a < 3; ++a) {
+      const double m = fabs(points[3 * id + a]);
+      unsigned long long u = (unsigned long long)__double_as_longlong(m);
+      if (!(m <= 1.7976931348623157e308)) u = kInf;  // NaN, inf
+      hi[a] = u > hi[a] ? u : hi[a];
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long h2 = __shfl_xor(hi[a], off, 64);
+      hi[a] = h2 > hi[a] ? h2 : hi[a];
+    }
+  __shared__ unsigned long long wave_hi[4][3];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; ++a) wave_hi[wave][a] = hi[a];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    unsigned long long h = wave_hi[0][a];
+    for (int w = 1; w < 4; ++w) h = wave_hi[w][a] > h ? wave_hi[w][a] : h;
+    if (h) atomicMax(&pmax[a], h);
+  }
+}
+
+// ViewMargin of every view for the chunk whose coordinate magnitudes are pmax (the formula of the struct's comment, the host's
+// operation order)
+__global__ __launch_bounds__(256) void view_margins_kernel(const ColorView *__restrict__ views, int n_views, const unsigned long long *__restrict__ pmax,
+                                                           ViewMargin *__restrict__ out) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_views) return;
+  const double pm[4] = {__longlong_as_double((long long)pmax[0]), __longlong_as_double((long long)pmax[1]), __longlong_as_double((long long)pmax[2]), 1.0};
+  double e[3];
+  for (int r = 0; r < 3; ++r) {
+    double sum = 0.0;
+    for (int q = 0; q < 4; ++q) sum += views[m].mag[4 * r + q] * pm[q];
+    e[r] = sum * 0x1p-47 * (1.0 + 0x1p-20);
+  }
+  out[m].ex = e[0] + 65537.0 * e[2];
+  out[m].ey = e[1] + 65537.0 * e[2];
+}
+
 // box[0..2] = min, box[3..5] = max of the finite coordinates, as ordered bits (initialised to ~0 / 0 by the caller)
 __global__ __launch_bounds__(256) void bbox_kernel(const double *__restrict__ points, int64_t nv, unsigned long long *__restrict__ box) {
   unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
@@ -504,13 +552,18 @@ struct dmi_color_context {
   ColorView *d_views = nullptr;
   size_t d_views_capacity = 0;
   bool views_dirty = false;
-  // per-chunk work buffers, grown on demand
-  double *d_points = nullptr;
+  // per-chunk work buffers, grown on demand.  Round 5: the vertices, the three outputs, the chunk's magnitudes and margins exist
+  // TWICE, and a chunk's copy in (h2d stream), kernels (stream) and copies out (d2h stream) overlap its neighbours'
+  double *d_points[2] = {nullptr, nullptr};
   uchar4 *d_scratch = nullptr;
-  uint8_t *d_mean = nullptr, *d_median = nullptr;
-  int32_t *d_count = nullptr;
+  uint8_t *d_mean[2] = {nullptr, nullptr}, *d_median[2] = {nullptr, nullptr};
+  int32_t *d_count[2] = {nullptr, nullptr};
   MedianSeed *d_seeds = nullptr;  // per vertex of a chunk: what the projection pass hands the histogram-median pass
-  ViewMargin *d_margins = nullptr;  // per view, for the chunk being processed
+  ViewMargin *d_margins[2] = {nullptr, nullptr};  // per view, for the chunk being processed
+  unsigned long long *d_pmax[2] = {nullptr, nullptr};  // chunk_magnitude_kernel's three words
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  hipEvent_t up[2] = {nullptr, nullptr}, kdone[2] = {nullptr, nullptr}, down[2] = {nullptr, nullptr};  // copy in done / kernels done / copies out done
+  hipEvent_t k0[2] = {nullptr, nullptr};  // before a chunk's kernels (with kdone: the kernel time)
   size_t margins_capacity = 0;
   // processing order of a chunk: Z-order keys and vertex indices (in / out of the radix sort), its temporary storage,
   // the chunk's bounding box
@@ -587,8 +640,16 @@ int dmi_color_create(int32_t device, dmi_color_context **out) {
   c->device = device;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  for (int b = 0; b < 2; ++b) {
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->up[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->down[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&c->k0[b]);
+    if (e == hipSuccess) e = hipEventCreate(&c->kdone[b]);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     const std::string msg = std::string("dmi_color_create: ") + hipGetErrorString(e);
@@ -603,15 +664,18 @@ int dmi_color_create(int32_t device, dmi_color_context **out) {
 void dmi_color_destroy(dmi_color_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipStream_t st : {c->h2d, c->stream, c->d2h})
+    if (st) (void)hipStreamSynchronize(st);
   for (ColorBatch &b : c->batches) (void)hipFree(b.d_rgba);
-  for (void *p : {(void *)c->d_views, (void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median,
-                  (void *)c->d_count, (void *)c->d_seeds, (void *)c->d_margins, (void *)c->d_stage, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index,
-                  (void *)c->d_perm, c->d_sort_temp, (void *)c->d_box})
+  for (void *p : {(void *)c->d_views, (void *)c->d_points[0], (void *)c->d_points[1], (void *)c->d_scratch, (void *)c->d_mean[0], (void *)c->d_mean[1],
+                  (void *)c->d_median[0], (void *)c->d_median[1], (void *)c->d_count[0], (void *)c->d_count[1], (void *)c->d_seeds, (void *)c->d_margins[0],
+                  (void *)c->d_margins[1], (void *)c->d_pmax[0], (void *)c->d_pmax[1], (void *)c->d_stage, (void *)c->d_keys, (void *)c->d_keys_sorted,
+                  (void *)c->d_index, (void *)c->d_perm, c->d_sort_temp, (void *)c->d_box})
     if (p) (void)hipFree(p);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (hipEvent_t ev : {c->ev0, c->ev1, c->up[0], c->up[1], c->down[0], c->down[1], c->k0[0], c->k0[1], c->kdone[0], c->kdone[1]})
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st : {c->h2d, c->stream, c->d2h})
+    if (st) (void)hipStreamDestroy(st);
   delete c;
 }
 
@@ -746,9 +810,12 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     c->d_views = nullptr;
     c->d_views_capacity = 0;
     DMI_COLOR_HIP(c, hipMalloc(&c->d_views, n_views * sizeof(ColorView)));
-    if (c->d_margins) (void)hipFree(c->d_margins);
-    c->d_margins = nullptr;
-    DMI_COLOR_HIP(c, hipMalloc(&c->d_margins, n_views * sizeof(ViewMargin)));
+    for (int b = 0; b < 2; ++b) {
+      if (c->d_margins[b]) (void)hipFree(c->d_margins[b]);
+      c->d_margins[b] = nullptr;
+      DMI_COLOR_HIP(c, hipMalloc(&c->d_margins[b], n_views * sizeof(ViewMargin)));
+      if (!c->d_pmax[b]) DMI_COLOR_HIP(c, hipMalloc(&c->d_pmax[b], 4 * sizeof(unsigned long long)));
+    }
     c->d_views_capacity = n_views;
     c->views_dirty = true;
   }
@@ -758,26 +825,33 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     c->views_dirty = false;
   }
   const bool coherent = !c->reorder && vertices_in_coherent_order(points, n_points);
-  std::vector<ViewMargin> margins;
-  // vertices per chunk: the scratch table [view][vertex] stays within its budget
+  // vertices per chunk: the scratch table [view][vertex] stays within its budget -- and a call of many vertices is cut into at
+  // least four chunks, so that a chunk's copy in, its kernels and its copies out run beside its neighbours' (with the caller's
+  // arrays in pinned memory, dmi_alloc_pinned, the copies are DMA transfers; from pageable memory they still are correct)
   const size_t budget = c->scratch_budget;
   size_t chunk = std::max<size_t>(256, budget / (n_views * sizeof(uchar4)) / 256 * 256);
   chunk = std::min<size_t>(chunk, ((size_t)n_points + 255) / 256 * 256);
+  if ((size_t)n_points >= (size_t(1) << 18)) chunk = std::min<size_t>(chunk, std::max<size_t>(size_t(1) << 16, (((size_t)n_points + 3) / 4 + 255) / 256 * 256));
   if (c->chunk_capacity < chunk || c->scratch_capacity < chunk * n_views) {
-    for (void *p : {(void *)c->d_points, (void *)c->d_scratch, (void *)c->d_mean, (void *)c->d_median, (void *)c->d_count,
-                    (void *)c->d_seeds, (void *)c->d_keys, (void *)c->d_keys_sorted, (void *)c->d_index, (void *)c->d_perm, c->d_sort_temp})
+    for (hipStream_t st : {c->h2d, c->stream, c->d2h}) DMI_COLOR_HIP(c, hipStreamSynchronize(st));
+    for (void *p : {(void *)c->d_points[0], (void *)c->d_points[1], (void *)c->d_scratch, (void *)c->d_mean[0], (void *)c->d_mean[1], (void *)c->d_median[0],
+                    (void *)c->d_median[1], (void *)c->d_count[0], (void *)c->d_count[1], (void *)c->d_seeds, (void *)c->d_keys, (void *)c->d_keys_sorted,
+                    (void *)c->d_index, (void *)c->d_perm, c->d_sort_temp})
       if (p) (void)hipFree(p);
-    c->d_points = nullptr; c->d_scratch = nullptr; c->d_mean = nullptr; c->d_median = nullptr; c->d_count = nullptr;
+    c->d_scratch = nullptr;
     c->d_seeds = nullptr;
     c->d_keys = c->d_keys_sorted = c->d_index = c->d_perm = nullptr;
     c->d_sort_temp = nullptr;
     c->sort_temp_bytes = 0;
     c->chunk_capacity = c->scratch_capacity = 0;
-    DMI_COLOR_HIP(c, hipMalloc(&c->d_points, chunk * 24));
+    for (int b = 0; b < 2; ++b) {
+      c->d_points[b] = nullptr; c->d_mean[b] = nullptr; c->d_median[b] = nullptr; c->d_count[b] = nullptr;
+      DMI_COLOR_HIP(c, hipMalloc(&c->d_points[b], chunk * 24));
+      DMI_COLOR_HIP(c, hipMalloc(&c->d_mean[b], chunk * 3));
+      DMI_COLOR_HIP(c, hipMalloc(&c->d_median[b], chunk * 3));
+      DMI_COLOR_HIP(c, hipMalloc(&c->d_count[b], chunk * 4));
+    }
     DMI_COLOR_HIP(c, hipMalloc(&c->d_scratch, chunk * n_views * sizeof(uchar4)));
-    DMI_COLOR_HIP(c, hipMalloc(&c->d_mean, chunk * 3));
-    DMI_COLOR_HIP(c, hipMalloc(&c->d_median, chunk * 3));
-    DMI_COLOR_HIP(c, hipMalloc(&c->d_count, chunk * 4));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_seeds, chunk * sizeof(MedianSeed)));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_keys, chunk * 4));
     DMI_COLOR_HIP(c, hipMalloc(&c->d_keys_sorted, chunk * 4));
@@ -791,45 +865,59 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     c->chunk_capacity = chunk;
     c->scratch_capacity = chunk * n_views;
   }
-  for (int64_t v0 = 0; v0 < n_points; v0 += (int64_t)chunk) {
+  // On a failure past the first queued copy nothing may still be writing the caller's arrays when the call returns
+  auto bail = [&](hipError_t he, const char *what) {
+    for (hipStream_t st : {c->h2d, c->stream, c->d2h}) (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    return cfail(c, DMI_ERR_DEVICE, std::string("dmi_color_process: ") + what + ": " + hipGetErrorString(he));
+  };
+#define DMI_COLOR_TRY(call)                         \
+  do {                                              \
+    const hipError_t he_ = (call);                  \
+    if (he_ != hipSuccess) return bail(he_, #call); \
+  } while (0)
+  bool timed[2] = {false, false};
+  auto collect = [&](int b) {  // the kernel time of the chunk that last used buffer set b (its kernels are known to have ended)
+    if (!timed[b]) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->k0[b], c->kdone[b]) == hipSuccess) c->last_kernel_ms += ms; else (void)hipGetLastError();
+    timed[b] = false;
+  };
+  int64_t index = 0;
+  for (int64_t v0 = 0; v0 < n_points; v0 += (int64_t)chunk, ++index) {
+    const int b = (int)(index & 1);
     const int64_t nv = std::min<int64_t>((int64_t)chunk, n_points - v0);
     const unsigned blocks = (unsigned)((nv + 255) / 256);
-    DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_points, points + 3 * v0, (size_t)nv * 24, hipMemcpyHostToDevice, c->stream));
-    {
-      // the chunk's largest coordinate magnitudes bound the error of the pixel selection's shortcut (ViewMargin); a
-      // coordinate that is not finite makes the margins infinite: every pair then takes the reference's expression
-      double pmax[4] = {0.0, 0.0, 0.0, 1.0};
-      for (int64_t i = 0; i < nv; ++i)
-        for (int a = 0; a < 3; ++a) {
-          const double m = std::fabs(points[3 * (v0 + i) + a]);
-          if (!(m <= pmax[a])) pmax[a] = m == m ? m : HUGE_VAL;
-        }
-      margins.resize(n_views);
-      for (size_t m = 0; m < n_views; ++m) {
-        double e[3];
-        for (int r = 0; r < 3; ++r) {
-          double sum = 0.0;
-          for (int q = 0; q < 4; ++q) sum += c->h_views[m].mag[4 * r + q] * pmax[q];
-          e[r] = sum * 0x1p-47 * (1.0 + 0x1p-20);
-        }
-        margins[m].ex = e[0] + 65537.0 * e[2];
-        margins[m].ey = e[1] + 65537.0 * e[2];
-      }
-      // pageable source: the copy has left the host buffer when the call returns
-      DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_margins, margins.data(), n_views * sizeof(ViewMargin), hipMemcpyHostToDevice, c->stream));
+    // copy in, once the kernels of the chunk before last have read this buffer set
+    if (index >= 2) {
+      DMI_COLOR_TRY(hipStreamWaitEvent(c->h2d, c->kdone[b], 0));
+      DMI_COLOR_TRY(hipEventSynchronize(c->kdone[b]));  // (the host reads that chunk's kernel time before the events are re-recorded)
+      collect(b);
     }
-    DMI_COLOR_HIP(c, hipEventRecord(c->ev0, c->stream));
+    DMI_COLOR_TRY(hipMemcpyAsync(c->d_points[b], points + 3 * v0, (size_t)nv * 24, hipMemcpyHostToDevice, c->h2d));
+    DMI_COLOR_TRY(hipEventRecord(c->up[b], c->h2d));
+    // kernels, once the vertices are there and the outputs of the chunk before last have left this buffer set
+    DMI_COLOR_TRY(hipStreamWaitEvent(c->stream, c->up[b], 0));
+    if (index >= 2) DMI_COLOR_TRY(hipStreamWaitEvent(c->stream, c->down[b], 0));
+    DMI_COLOR_TRY(hipEventRecord(c->k0[b], c->stream));
+    // the chunk's largest coordinate magnitudes bound the error of the pixel selection's shortcut (ViewMargin); a coordinate
+    // that is not finite makes the margins infinite: every pair then takes the reference's expression
+    DMI_COLOR_TRY(hipMemsetAsync(c->d_pmax[b], 0, 4 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(chunk_magnitude_kernel, dim3(std::min<unsigned>(blocks, 512u)), dim3(256), 0, c->stream, c->d_points[b], nv, c->d_pmax[b]);
+    hipLaunchKernelGGL(view_margins_kernel, dim3((unsigned)((n_views + 255) / 256)), dim3(256), 0, c->stream, c->d_views, (int)n_views, c->d_pmax[b],
+                       c->d_margins[b]);
+    DMI_COLOR_TRY(hipGetLastError());
     const uint32_t *perm = nullptr;
     if (c->reorder) {
       // the order of work: along a Z-order curve of the chunk's bounding box (see bbox_kernel)
       static const unsigned long long kEmptyBox[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-      DMI_COLOR_HIP(c, hipMemcpyAsync(c->d_box, kEmptyBox, sizeof(kEmptyBox), hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(bbox_kernel, dim3(std::min<unsigned>(blocks, 256u)), dim3(256), 0, c->stream, c->d_points, nv, c->d_box);
-      hipLaunchKernelGGL(morton_key_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, c->d_box, c->d_keys, c->d_index);
-      DMI_COLOR_HIP(c, hipGetLastError());
+      DMI_COLOR_TRY(hipMemcpyAsync(c->d_box, kEmptyBox, sizeof(kEmptyBox), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(bbox_kernel, dim3(std::min<unsigned>(blocks, 256u)), dim3(256), 0, c->stream, c->d_points[b], nv, c->d_box);
+      hipLaunchKernelGGL(morton_key_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_points[b], nv, c->d_box, c->d_keys, c->d_index);
+      DMI_COLOR_TRY(hipGetLastError());
       size_t temp = c->sort_temp_bytes;
-      DMI_COLOR_HIP(c, rocprim::radix_sort_pairs(c->d_sort_temp, temp, c->d_keys, c->d_keys_sorted, c->d_index, c->d_perm, (size_t)nv,
-                                                0, 30, c->stream));
+      DMI_COLOR_TRY(rocprim::radix_sort_pairs(c->d_sort_temp, temp, c->d_keys, c->d_keys_sorted, c->d_index, c->d_perm, (size_t)nv,
+                                              0, 30, c->stream));
       perm = c->d_perm;
     }
     bool histogram_medians = n_views <= 65535;
@@ -840,31 +928,35 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
       // (vertices in a coherent order -- the caller's, a mesh's, or the Z-order pass's -- take the pipelined view loop, scattered
       // ones the plain one)
       if (!perm && !coherent)
-        hipLaunchKernelGGL((project_color_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                           (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
+        hipLaunchKernelGGL((project_color_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points[b], nv, perm, c->d_views,
+                           (int)n_views, c->W, c->H, c->d_scratch, c->d_mean[b], c->d_count[b], c->d_seeds, c->d_margins[b]);
       else
-        hipLaunchKernelGGL((project_color_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                           (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
-      DMI_COLOR_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL((project_color_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->d_points[b], nv, perm, c->d_views,
+                           (int)n_views, c->W, c->H, c->d_scratch, c->d_mean[b], c->d_count[b], c->d_seeds, c->d_margins[b]);
+      DMI_COLOR_TRY(hipGetLastError());
       hipLaunchKernelGGL(median_low_nibble_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
-                         c->d_count, c->d_seeds, c->d_median);
+                         c->d_count[b], c->d_seeds, c->d_median[b]);
     } else {
-      hipLaunchKernelGGL((project_color_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points, nv, perm, c->d_views,
-                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean, c->d_count, c->d_seeds, c->d_margins);
-      DMI_COLOR_HIP(c, hipGetLastError());
+      hipLaunchKernelGGL((project_color_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points[b], nv, perm, c->d_views,
+                         (int)n_views, c->W, c->H, c->d_scratch, c->d_mean[b], c->d_count[b], c->d_seeds, c->d_margins[b]);
+      DMI_COLOR_TRY(hipGetLastError());
       hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
-                         c->d_count, c->d_median);
+                         c->d_count[b], c->d_median[b]);
     }
-    DMI_COLOR_HIP(c, hipGetLastError());
-    DMI_COLOR_HIP(c, hipEventRecord(c->ev1, c->stream));
-    DMI_COLOR_HIP(c, hipMemcpyAsync(mean + 3 * v0, c->d_mean, (size_t)nv * 3, hipMemcpyDeviceToHost, c->stream));
-    DMI_COLOR_HIP(c, hipMemcpyAsync(median + 3 * v0, c->d_median, (size_t)nv * 3, hipMemcpyDeviceToHost, c->stream));
-    DMI_COLOR_HIP(c, hipMemcpyAsync(count + v0, c->d_count, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
-    DMI_COLOR_HIP(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    DMI_COLOR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->last_kernel_ms += ms;
+    DMI_COLOR_TRY(hipGetLastError());
+    DMI_COLOR_TRY(hipEventRecord(c->kdone[b], c->stream));
+    timed[b] = true;
+    // copies out
+    DMI_COLOR_TRY(hipStreamWaitEvent(c->d2h, c->kdone[b], 0));
+    DMI_COLOR_TRY(hipMemcpyAsync(mean + 3 * v0, c->d_mean[b], (size_t)nv * 3, hipMemcpyDeviceToHost, c->d2h));
+    DMI_COLOR_TRY(hipMemcpyAsync(median + 3 * v0, c->d_median[b], (size_t)nv * 3, hipMemcpyDeviceToHost, c->d2h));
+    DMI_COLOR_TRY(hipMemcpyAsync(count + v0, c->d_count[b], (size_t)nv * 4, hipMemcpyDeviceToHost, c->d2h));
+    DMI_COLOR_TRY(hipEventRecord(c->down[b], c->d2h));
   }
+  for (hipStream_t st : {c->h2d, c->stream, c->d2h}) DMI_COLOR_TRY(hipStreamSynchronize(st));
+  collect(0);
+  collect(1);
+#undef DMI_COLOR_TRY
   return DMI_OK;
   });
 }
