@@ -1413,11 +1413,14 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     //     from 48 views on, on grids of 256^3 voxels and more.
     // (round 3's rule -- persistent from 48 views on every grid of up to 2^18 bricks -- was fitted to a kernel whose light bricks
     // cost twice as much; it had cfg 2's dense scene at 0.34 ms where the per-brick form takes 0.25)
+    // Round 5's kernel (a window pair a sixth cheaper), maps with holes, per-brick / persistent: 256^3 x 64 views 0.565 / 0.597,
+    // 256^3 x 128 1.13 / 1.17, 384^3 x 64 1.66 / 1.59, 384^3 x 128 3.32 / 3.15, 512^3 x 256 12.23 / 12.19
+    // (profiles/r19t_form_by_size_speckle.txt): persistent from 384^3 on.
     const int64_t voxels = (int64_t)a.super_x * a.super_y * a.super_z * 32 * 64 * TK;  // of this launch's slab, padding included
     stay = (cfg.variant & VAR_PERSISTENT_ALWAYS) ? true
            : (cfg.variant & VAR_PERSISTENT_NEVER) ? false
            : (cfg.variant & VAR_NO_BRICK_CLASSES) ? true
-           : cfg.holes ? (a.n_maps >= 48 && voxels >= (int64_t(1) << 24))
+           : cfg.holes ? (a.n_maps >= 48 && voxels >= (int64_t(1) << 25))
                        : (a.n_maps >= kPersistentMinViews && voxels >= (int64_t(1) << 27));
   }
   // (persistent one-wave workgroups: as many as the chip holds, asked once per instantiation)
