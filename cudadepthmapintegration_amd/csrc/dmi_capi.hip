@@ -804,7 +804,6 @@ int sync_maps(dmi_context *ctx) {
     ctx->d_tile_maps = nullptr;
     DMI_HIP(ctx, hipMalloc(&ctx->d_tile_maps, cap * sizeof(TileMapRec)));
     if (ctx->d_win_recs) (void)hipFree(ctx->d_win_recs);
-  if (ctx->d_foot_recs) (void)hipFree(ctx->d_foot_recs);
     ctx->d_win_recs = nullptr;
     DMI_HIP(ctx, hipMalloc(&ctx->d_win_recs, cap * sizeof(dmi::WinRec)));
     if (ctx->d_foot_recs) (void)hipFree(ctx->d_foot_recs);
