@@ -332,7 +332,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   // pixel index of the image centre, from which tier 1 counts
   constexpr bool T1 = DMI_TIER1 != 0 && !GENK;
   [[maybe_unused]] const float Wf = __int_as_float(pinned_word(__float_as_int((float)KA(W))));
-  [[maybe_unused]] const int cidx = pinned_word(KA(W) * (KA(H) / 2) + KA(W) / 2);
+  // ... minus what the magic-number candidates carry beside the pixel (0x400000 * W + 0x4B400000, modulo 2^32: see phase A)
+  [[maybe_unused]] const int pix_adj =
+      pinned_word((int)((unsigned)(KA(W) * (KA(H) / 2) + KA(W) / 2) - (0x400000u * (unsigned)KA(W) + 0x4B400000u)));
   double tiny = 0x1p-20;  // the reciprocal seed's residual must stay below this; a value in registers, not a literal
   asm volatile("" : "+v"(tiny));  // rebuilt with two scalar moves next to every voxel's compare
   const int lane = threadIdx.x & 63;
@@ -1002,21 +1004,29 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             }
             f32x2 rr;
             rr.x = rcp_f32_for_asm(cth.x);
-            const f32x2 ua = pk_mul_lo(h, rr);
             f32x2 rp;
-            rp.x = __builtin_rintf(ua.x);
-            rp.y = __builtin_rintf(ua.y);
-            const f32x2 t = pk_fnma_lo(rp, cth, h);
-            const mask_t m_p1 = ballot(max_abs(t.x, t.y) < cth.y);
-            // W*py'' + px'' in one fp32 operation (exact: the host admits tier 1 only while (H + 8) * W + H < 2^24), then the
-            // centre's index; garbage on unaccepted lanes, whose loads the buffer descriptor range-checks
             unsigned pix;
             if constexpr (VMAP) {
+              const f32x2 ua = pk_mul_lo(h, rr);
+              rp.x = __builtin_rintf(ua.x);
+              rp.y = __builtin_rintf(ua.y);
+              // the validity map's byte index in three fp32 operations (exact: the host admits tier 1 only while (H + 8) * W + H
+              // < 2^24); garbage on unaccepted lanes, whose loads the buffer descriptor range-checks
               const float yt = __builtin_rintf(__builtin_fmaf(rp.y, 0.125f, v_c0));
               pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(yt, v_w8, __builtin_fmaf(rp.x, 8.0f, rp.y))) + v_base);
             } else {
-              pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(rp.y, Wf, rp.x)) + cidx);
+              // (round 5) the candidate by the magic number, as the window column forms it: fl32(h'' * rcp + 1.5 * 2^23) is an
+              // integer-valued float whose bit pattern is 0x4B400000 + P -- one packed FMA and one packed subtraction where a
+              // packed multiply and two roundings stood -- and its low 24 bits, 0x400000 + P, give the pixel index W * py'' + px''
+              // in one v_mad_u32_u24 (modulo 2^32, exact on the integers: no fp32 product to keep below 2^24), the constants
+              // folded into pix_adj.  Any candidate will do (4d.3); an accepted one is the reference's pixel, |P| < 2^15.
+              const unsigned long long magic2 = 0x4B4000004B400000ull;
+              const f32x2 rpm = pk_fma_lo_s(h, rr, magic2);
+              rp = pk_sub_s(rpm, magic2);
+              pix = __umul24((unsigned)__float_as_int(rpm.y), vW) + (unsigned)__float_as_int(rpm.x) + (unsigned)pix_adj;
             }
+            const f32x2 t = pk_fnma_lo(rp, cth, h);
+            const mask_t m_p1 = ballot(max_abs(t.x, t.y) < cth.y);
             mask_t m_in, m_und;
             [[maybe_unused]] mask_t m_front = 0;
             if constexpr (INTERIOR) {
@@ -1052,7 +1062,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                 const double yt2 = __builtin_rint(__builtin_fma(rv2, 0.125, (double)v_c0));
                 pix2 = (unsigned)(cvt_saturating(__builtin_fma(yt2, (double)v_w8, __builtin_fma(ru2, 8.0, rv2))) + v_base);
               } else {
-                pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + cidx);
+                pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + (KC(W) * (KC(H) >> 1) + (KC(W) >> 1)));  // (+ the centre's index)
               }
               if (__builtin_amdgcn_inverse_ballot_w64(m_p2)) pix = pix2;
               if constexpr (INTERIOR) {
