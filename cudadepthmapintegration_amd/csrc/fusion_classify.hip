@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void brick_work_kernel(const TileArgs a, int w
       total += a.n_maps;
     }
   for (int off = 32; off > 0; off >>= 1) mixed += __shfl_xor(mixed, off, 64);
-  if (lane == 0) level[slot] = mixed * 2 >= total ? 0 : (mixed * 8 >= total ? 1 : (mixed > 0 ? 2 : 3));
+  if (lane == 0) level[slot] = mixed * 2 >= total ? 0 : (mixed * 4 >= total ? 1 : (mixed * 16 >= total ? 2 : 3));
 }
 
 // ---- stable partition of the slots by level, in three small launches over chunks of 1024 slots --------------------
@@ -1086,7 +1086,11 @@ __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, i
     return;
   }
   if (exists && part == 0)
-    level[slot] = !in_grid ? 255 : (mixed * 2 >= a.n_maps ? 0 : (mixed * 8 >= a.n_maps ? 1 : (mixed > 0 ? 2 : 3)));
+    // Levels by the share of mixed views: >= 1/2, >= 1/4, >= 1/16, less.  (Until round 5: >= 1/2, >= 1/8, > 0, none -- a brick with
+    // 117 of 256 views mixed shared a level with one of 32 and, dealt late, ran 0.46 ms on an emptying chip: the launch spent
+    // 0.36 of its 12.3 ms with under half of its workgroups resident, profiles/r19y_wg_timeline_cfg3_speckle.json.  The bricks
+    // without a mixed view are a few microseconds each: no level of their own.)
+    level[slot] = !in_grid ? 255 : (mixed * 2 >= a.n_maps ? 0 : (mixed * 4 >= a.n_maps ? 1 : (mixed * 16 >= a.n_maps ? 2 : 3)));
 }
 
 // Cost order, second launch: the levels' starts (a scan of the 64 sizes, by every workgroup for itself), then every slot takes
