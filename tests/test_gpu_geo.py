@@ -75,3 +75,39 @@ def test_reference_example_command_line_magnitudes():
         out, vh, mh = capi.fuse_once(grid, rp, views, threshold=thr, kernel_variant=variant)
         assert bits_equal(out, want), variant
         assert np.array_equal(mh, mh_w) and np.array_equal(vh, vh_w), variant
+
+
+def test_view_paths_follow_the_magnitudes():
+    """dmi_get_view_paths: a centred scene and the same scene at offsets of 1e6 run tier 1 with window records; at 1e9 (or with a
+    focal length of 1e14) the per-view bound fails and the general kernel takes the view; a general K is counted as such."""
+    grid = scene.default_grid((48, 40, 32))
+    rp = scene.default_ray_potential(grid)
+    views = scene.make_views(6, 160, 120, seed=3, dense=True)
+    for off, expect_general in ((0.0, 0), (1e6, 0), (1e9, 6)):
+        g, r, v = scene.to_world_frame(grid, rp, views, 10.0, (off, -off, 0.5 * off))
+        with capi.FusionContext(g, r) as ctx:
+            ctx.add_views(v)
+            p = ctx.view_paths()
+        assert p["general_kernel"] == expect_general, (off, p)
+        if not expect_general:
+            assert p["tiled_tier1"] + p["tiled_tier1_per_lane_margin"] == 6 and p["with_window_record"] == 6, (off, p)
+    v2 = scene.Views(views.depth, views.K4.copy(), views.RT4)
+    v2.K4[0, 0, 0] = 1e14      # an absurd focal length: the bound cannot hold
+    v2.K4[1, 2, 0] = 1e-3      # a general third row
+    with capi.FusionContext(grid, rp) as ctx:
+        ctx.add_views(v2)
+        p = ctx.view_paths()
+    assert p["general_kernel"] == 1 and p["tiled_general_k"] == 1 and p["tiled_tier1"] == 4, p
+
+
+def test_regional_holes_bit_exact():
+    """The `blobs` scene kind (holes in discs, as best-cost filtering leaves them) at a size with more bricks than persistent
+    workgroups, default launch and windows forced: the oracle's grid bit for bit."""
+    grid = scene.default_grid((160, 144, 128))
+    rp = scene.default_ray_potential(grid)
+    views, thr = scene.make_scene_views("blobs", 12, 320, 240, seed=9, speckle=0.2)
+    assert thr is None and float((views.depth == -1.0).mean()) > 0.1
+    want = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
+    for variant in (0, W, W | capi.VARIANT_FIXED_TILE_SHAPE):
+        out, _, _ = capi.fuse_once(grid, rp, views, count_hits=False, kernel_variant=variant)
+        assert bits_equal(out, want), variant
