@@ -1523,6 +1523,7 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     if (const char *e = std::getenv("DMI_DEBUG_PAIRS")) {  // tools/gpu_pair_cost.sh (results are wrong)
       if (!std::strcmp(e, "nowin")) t.flags |= dmi::TILE_FLAG_DBG_SKIP_WINDOW_PAIRS;
       if (!std::strcmp(e, "onlywin")) t.flags |= dmi::TILE_FLAG_DBG_ONLY_WINDOW_PAIRS;
+      if (!std::strcmp(e, "nowinloads")) t.flags |= dmi::TILE_FLAG_DBG_NO_WINDOW_LOADS;
     }
     if (const char *e = std::getenv("DMI_XCD_RUN_WG")) {  // launch-geometry experiments
       t.xcd_run_wg = std::max(1, std::atoi(e));

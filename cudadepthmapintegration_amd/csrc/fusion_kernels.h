@@ -288,7 +288,8 @@ enum TileKernelFlags : int32_t {
   // tuning builds only (DMI_TUNING; results are wrong): what a kind of pair costs -- the window pairs skipped, or every mixed
   // pair but them (DMI_DEBUG_PAIRS=nowin / onlywin; counters per pair: tools/gpu_pair_cost.sh)
   TILE_FLAG_DBG_SKIP_WINDOW_PAIRS = 256,
-  TILE_FLAG_DBG_ONLY_WINDOW_PAIRS = 512
+  TILE_FLAG_DBG_ONLY_WINDOW_PAIRS = 512,
+  TILE_FLAG_DBG_NO_WINDOW_LOADS = 1024   // (DMI_DEBUG_PAIRS=nowinloads) the window's two loads dropped: what their latency costs
 };
 
 // What the reference does to EVERY voxel of a brick for one map, when that can be proven from the eight

@@ -654,8 +654,18 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // byte offset of row Y's dword in tile column tx: ((Y >> 5) * tiles_x + tx) * 128 + (Y & 31) * 4
         const unsigned lin = ((unsigned)lane << 2) + ((unsigned)y0p << 2);
         const unsigned off = __umul24(lin >> 7, (unsigned)kw->vb_rowskip) + lin + (((unsigned)x0p >> 5) << 7);
+#ifdef DMI_TUNING
+        uint32_t w_lo, w_hi;
+        if (kflags & TILE_FLAG_DBG_NO_WINDOW_LOADS) {  // timing experiment (wrong results)
+          w_lo = off * 0x9e3779b9u, w_hi = ~w_lo;
+        } else {
+          w_lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)off, 0, 0);
+          w_hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)(off + 128u), 0, 0);
+        }
+#else
         const uint32_t w_lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)off, 0, 0);
         const uint32_t w_hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)(off + 128u), 0, 0);
+#endif
         // the window's first pixel counted from the image centre
         const int x0c = x0p - kw->win_cx, y0c = y0p - kw->win_cy;
         // ---- set-up, all fp32: the window-relative numerators hw = h'' - X0 * c.z, c.z and the acceptance

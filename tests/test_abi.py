@@ -168,3 +168,20 @@ def test_build_accepts_the_library_by_digest_and_says_what_it_did():
     assert os.path.exists(cli) and open(cli + ".digest").read().strip() == b.source_digest()
     # no offload-bundler temporaries next to the sources (they used to be committed by accident)
     assert not [f for f in os.listdir(b.CSRC) if ".so." in f and not f.endswith(".digest")]
+
+
+def test_fp64_only_build_of_the_tiled_kernel_compiles():
+    """-DDMI_TIER1=0 (pixels selected in fp64 only: the A/B build fusion_kernels.h advertises) still compiles: the window
+    instantiations, which are tier-1 columns, are left out of such a build (fusion_tile.hip: launch_win)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from cudadepthmapintegration_amd import build as b
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([hipcc] + b.COMMON_FLAGS + ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector", "-DDMI_FAST_BUILD",
+                            "-DDMI_TIER1=0", "--cuda-device-only", "-c", os.path.join(b.CSRC, "fusion_tile.hip"), "-o", os.path.join(tmp, "t.o")],
+                           capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

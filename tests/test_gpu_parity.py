@@ -927,3 +927,28 @@ def test_more_views_than_the_free_sums_table_holds():
         ctx.fuse(0, 2000)
         ctx.fuse(2000, 2200)
         assert bits_equal(ctx.download_grid(), want)
+
+
+def test_f32_grid_never_stores_negative_zero():
+    """An f32 grid rounds a voxel's fp64 sum once per launch.  A tiny negative sum (here -eta*rho = -3e-162) would round to
+    -0.0f; a later fusion onto that grid drops the +0.0 adds of the pairs far behind every surface, which is only sound while no
+    sum is -0.0 -- so the store writes +0.0f for both zeros (fusion_device.h: stored_sum).  The grid of the first
+    chunk holds no -0.0, and two chunks fused one after the other give the values of one fusion (zeros compared as equal: an f32
+    grid is compared within a tolerance anyway)."""
+    grid = scene.default_grid((48, 40, 32))
+    s = float(max(grid.spacing))
+    rp = scene.RayPotential(thickness=2.5 * s, rho=1e-160, eta=0.03, delta=10.0 * s)
+    views = scene.make_views(8, 160, 120, seed=21, dense=True)
+    with capi.FusionContext(grid, rp, grid_dtype="f32") as ctx:
+        ctx.add_views(views.subset(0, 4))
+        ctx.fuse(0, 4)
+        first = ctx.download_grid(np.float32).copy()
+        assert (first == 0.0).all() and not np.signbit(first).any(), "a -0.0f in the stored grid"
+        ctx.add_views(views.subset(4, 8))
+        ctx.fuse(4, 4)
+        chunked = ctx.download_grid(np.float32).copy()
+    with capi.FusionContext(grid, rp, grid_dtype="f32") as ctx:
+        ctx.add_views(views)
+        ctx.fuse()
+        whole = ctx.download_grid(np.float32)
+    assert not np.signbit(chunked).any() and np.array_equal(chunked, whole)
