@@ -39,6 +39,12 @@
 #include "fusion_kernels.h"
 #include "fusion_device.h"
 
+#ifndef DMI_T1_CHAINS
+#define DMI_T1_CHAINS 4  // voxels whose tier-1 chains are written link by link (struct ordered below): the window column
+#endif
+#ifndef DMI_T1_COLUMN_CHAINS
+#define DMI_T1_COLUMN_CHAINS 2  // ... the gathering columns (four would spill: they hold a group's depths and c.z besides)
+#endif
 // Experiment switches that produce WRONG results exist for timing runs only (tools/exp_list*.txt): they compile in a tuning
 // build (DMI_TUNING, a library of its own) and nowhere else.
 #if !defined(DMI_TUNING) && (defined(DMI_EXP_SKIP_WINDOW_VIEWS) || defined(DMI_EXP_SAME_REC) || defined(DMI_EXP_NO_WINDOW_LOADS) || \
@@ -187,6 +193,43 @@ __device__ __forceinline__ float rcp_f32_for_asm(float x) {
   asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
   return r;
 }
+// The links of a tier-1 chain as ORDERED statements (asm volatile keeps source order): two voxels' chains written link by link,
+// alternately, leave one instruction between every producer and its reader -- the wait state that the compiler otherwise fills
+// with an s_nop after each asm statement (it cannot know whether the statement was a transcendental or wrote half a register), six
+// per voxel when a chain runs on its own.  A candidate built on a stale operand is only a bad candidate: the verification is what
+// the result rests on.
+struct ordered {
+  static __device__ __forceinline__ f32x2 pk_fma_s(unsigned long long a_bits, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(a_bits), "v"(b), "v"(c));
+    return d;
+  }
+  static __device__ __forceinline__ float rcp(float x) {  // (no s_nop of its own: the next link belongs to the other voxel)
+    float r;
+    asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+  }
+  static __device__ __forceinline__ f32x2 pk_fma_lo_s(f32x2 a, f32x2 b, unsigned long long c_bits) {
+    f32x2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "s"(c_bits));
+    return d;
+  }
+  static __device__ __forceinline__ f32x2 pk_sub_s(f32x2 a, unsigned long long c_bits) {
+    f32x2 d;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "s"(c_bits));
+    return d;
+  }
+  static __device__ __forceinline__ f32x2 pk_fnma_lo(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+  }
+  static __device__ __forceinline__ float max_abs(float a, float b) {
+    float d;
+    asm volatile("v_max_f32 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+  }
+};
 __device__ __forceinline__ int cvt_i32_f32(float x) {  // saturating, NaN -> 0
   int r;
   asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
@@ -733,27 +776,55 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   #pragma unroll
         for (int g0 = 0; g0 < TK; g0 += WG) {
           uint32_t wg[WG], cg[WG];
-          // ---- the group's candidates and their verification
+          // ---- the group's candidates and their verification: the four voxels' chains in ONE basic block (the rare "not accepted"
+          // bookkeeping after all four), so that the scheduler interleaves them: every link of a chain is an asm statement, and the
+          // compiler puts a wait state (s_nop) between an asm statement and an immediate reader of its result (it cannot know
+          // whether the statement was a transcendental or wrote half a register) -- six per voxel when a chain runs on its own
+          mask_t m_und[WG];
+          constexpr int IL = DMI_T1_CHAINS;  // voxels whose chains alternate
   #pragma unroll
-          for (int q = 0; q < WG; ++q) {
-            const int kk = g0 + q;
-            f32x2 h = H0, cth = C0;
-            if (kk > 0) {
+          for (int q0 = 0; q0 < WG; q0 += IL) {
+            f32x2 h[IL], cth[IL], rr[IL], rpm[IL], rp[IL], t[IL];
+            float mx[IL];
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) {
+              const int kk = g0 + q0 + u;
               const unsigned long long kbits = (unsigned long long)(unsigned)__float_as_int((float)kk);
-              h = pk_fma_s(kbits, DH, H0);
-              cth = pk_fma_s(kbits, DC, C0);
+              cth[u] = kk > 0 ? ordered::pk_fma_s(kbits, DC, C0) : C0;
             }
-            f32x2 rr;
-            rr.x = rcp_f32_for_asm(cth.x);
-            const f32x2 rpm = pk_fma_lo_s(h, rr, M2);
-            const f32x2 rp = pk_sub_s(rpm, M2);
-            const f32x2 t = pk_fnma_lo(rp, cth, h);
-            const mask_t m_und = ballot(!(max_abs(t.x, t.y) < cth.y));  // (a NaN is not accepted)
-            wg[q] = (unsigned)__float_as_int(rpm.y) << 2;  // the row's lane, as ds_bpermute_b32 addresses it
-            cg[q] = (uint32_t)__float_as_int(rpm.x);
-            if (m_und) {  // wave-uniform, rare
-              or_where(undecided, m_und, 1u << kk);
-              und_kk |= 1u << kk;
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) {
+              const int kk = g0 + q0 + u;
+              const unsigned long long kbits = (unsigned long long)(unsigned)__float_as_int((float)kk);
+              h[u] = kk > 0 ? ordered::pk_fma_s(kbits, DH, H0) : H0;
+            }
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) rr[u].x = ordered::rcp(cth[u].x);
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) rpm[u] = ordered::pk_fma_lo_s(h[u], rr[u], M2);
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) rp[u] = ordered::pk_sub_s(rpm[u], M2);
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) t[u] = ordered::pk_fnma_lo(rp[u], cth[u], h[u]);
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) mx[u] = ordered::max_abs(t[u].x, t[u].y);
+  #pragma unroll
+            for (int u = 0; u < IL; ++u) {
+              m_und[q0 + u] = ballot(!(mx[u] < cth[u].y));  // (a NaN is not accepted)
+              wg[q0 + u] = (unsigned)__float_as_int(rpm[u].y) << 2;  // the row's lane, as ds_bpermute_b32 addresses it
+              cg[q0 + u] = (uint32_t)__float_as_int(rpm[u].x);
+            }
+          }
+          mask_t m_und_any = m_und[0];
+  #pragma unroll
+          for (int q = 1; q < WG; ++q) m_und_any |= m_und[q];
+          if (m_und_any) {  // wave-uniform, rare
+  #pragma unroll
+            for (int q = 0; q < WG; ++q) {
+              if (m_und[q]) {
+                or_where(undecided, m_und[q], 1u << (g0 + q));
+                und_kk |= 1u << (g0 + q);
+              }
             }
           }
           if (g0 == 0)
@@ -993,50 +1064,69 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           }
         }
         // ---- phase A: project the group's voxels and issue their depth loads
+        // ---- tier 1.  In pixel coordinates counted from the image centre, the numerators hx'', hy'',
+        // c.z and the acceptance threshold are affine in the voxel's position kk in its column: fp32 images of all four
+        // come from two packed FMAs.  The candidate pixel P = rne(h'' / c.z) is formed by the magic number, as the window column
+        // forms it: fl32(h'' * rcp + 1.5 * 2^23) is an integer-valued float whose bit pattern is 0x4B400000 + P (v_rcp_f32, one
+        // packed FMA, one packed subtraction), and it is ACCEPTED when |h'' - P * c.z| < c1 * c.z - e1 in both coordinates (one
+        // packed FMA, one maximum, one compare): e1 and c1 cover every rounding on the way -- whatever v_rcp_f32 returned -- and
+        // the bound err of the affine form, so an accepted P is the reference's round(h.x / h.z) - W/2 and no tie.  The ~0.1 % of
+        // lanes that are not accepted are redone: in fp64 (tier 2: the selection every instantiation used to run inline), then,
+        // after the column and if still unproven, with the reference's own expression.
+        // The chains of kChain voxels are written link by link (struct ordered): no wait state between the links.
+        constexpr int kChain = T1 ? DMI_T1_COLUMN_CHAINS : 1;
+        static_assert(kGroup % kChain == 0, "whole chains per group");
   #pragma unroll
-        for (int q = 0; q < kGroup; ++q) {
+        for (int q0 = 0; q0 < kGroup; q0 += kChain) {
+        [[maybe_unused]] f32x2 rpm_c[kChain], rp_c[kChain];
+        [[maybe_unused]] float mx_c[kChain], thr_c[kChain];
+        if constexpr (T1) {
+          f32x2 h[kChain], cth[kChain], rr[kChain], t[kChain];
+          const unsigned long long magic2 = 0x4B4000004B400000ull;
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) {
+            const int kk = g0 + q0 + u;
+            cth[u] = kk > 0 ? ordered::pk_fma_s((unsigned long long)(unsigned)__float_as_int((float)kk), DC, C0) : C0;
+          }
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) {
+            const int kk = g0 + q0 + u;
+            h[u] = kk > 0 ? ordered::pk_fma_s((unsigned long long)(unsigned)__float_as_int((float)kk), DH, H0) : H0;
+          }
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) rr[u].x = ordered::rcp(cth[u].x);
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) rpm_c[u] = ordered::pk_fma_lo_s(h[u], rr[u], magic2);
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) rp_c[u] = ordered::pk_sub_s(rpm_c[u], magic2);
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) t[u] = ordered::pk_fnma_lo(rp_c[u], cth[u], h[u]);
+  #pragma unroll
+          for (int u = 0; u < kChain; ++u) {
+            mx_c[u] = ordered::max_abs(t[u].x, t[u].y);
+            thr_c[u] = cth[u].y;
+          }
+        }
+  #pragma unroll
+        for (int qc = 0; qc < kChain; ++qc) {
+          const int q = q0 + qc;
           const int kk = g0 + q;
           if constexpr (!UNMASKED) dg[q] = DL::sentinel();
           if constexpr (T1) {
-            // ---- tier 1.  In pixel coordinates counted from the image centre, the numerators hx'', hy'',
-            // c.z and the acceptance threshold are affine in the voxel's position kk in its column: fp32 images of all four
-            // come from two packed FMAs.  The candidate pixel P = rne(h'' / c.z) (v_rcp_f32, one packed multiply) is
-            // ACCEPTED when |h'' - P * c.z| < c1 * c.z - e1 in both coordinates (one packed FMA, one maximum, one compare):
-            // e1 and c1 cover every rounding on the way -- whatever v_rcp_f32 returned -- and the bound err of the affine
-            // form, so an accepted P is the reference's round(h.x / h.z) - W/2 and no tie.  The ~0.1 % of lanes that are not
-            // accepted are redone after the column: in fp64 (tier 2: the selection every instantiation used to run inline),
-            // then, if still unproven, with the reference's own expression.
-            f32x2 h = H0, cth = C0;
-            if (kk > 0) {
-              const unsigned long long kbits = (unsigned long long)(unsigned)__float_as_int((float)kk);
-              h = pk_fma_s(kbits, DH, H0);
-              cth = pk_fma_s(kbits, DC, C0);
-            }
-            f32x2 rr;
-            rr.x = rcp_f32_for_asm(cth.x);
-            f32x2 rp;
+            const f32x2 rpm = rpm_c[qc], rp = rp_c[qc];
             unsigned pix;
             if constexpr (VMAP) {
-              const f32x2 ua = pk_mul_lo(h, rr);
-              rp.x = __builtin_rintf(ua.x);
-              rp.y = __builtin_rintf(ua.y);
               // the validity map's byte index in three fp32 operations (exact: the host admits tier 1 only while (H + 8) * W + H
               // < 2^24); garbage on unaccepted lanes, whose loads the buffer descriptor range-checks
               const float yt = __builtin_rintf(__builtin_fmaf(rp.y, 0.125f, v_c0));
               pix = (unsigned)(cvt_i32_f32(__builtin_fmaf(yt, v_w8, __builtin_fmaf(rp.x, 8.0f, rp.y))) + v_base);
             } else {
-              // (round 5) the candidate by the magic number, as the window column forms it: fl32(h'' * rcp + 1.5 * 2^23) is an
-              // integer-valued float whose bit pattern is 0x4B400000 + P -- one packed FMA and one packed subtraction where a
-              // packed multiply and two roundings stood -- and its low 24 bits, 0x400000 + P, give the pixel index W * py'' + px''
-              // in one v_mad_u32_u24 (modulo 2^32, exact on the integers: no fp32 product to keep below 2^24), the constants
-              // folded into pix_adj.  Any candidate will do (4d.3); an accepted one is the reference's pixel, |P| < 2^15.
-              const unsigned long long magic2 = 0x4B4000004B400000ull;
-              const f32x2 rpm = pk_fma_lo_s(h, rr, magic2);
-              rp = pk_sub_s(rpm, magic2);
+              // the candidate's low 24 bits, 0x400000 + P, give the pixel index W * py'' + px'' in one v_mad_u32_u24 (modulo 2^32,
+              // exact on the integers: no fp32 product to keep below 2^24), the constants folded into pix_adj.  Any candidate will
+              // do (4d.3); an accepted one is the reference's pixel, |P| < 2^15.
               pix = __umul24((unsigned)__float_as_int(rpm.y), vW) + (unsigned)__float_as_int(rpm.x) + (unsigned)pix_adj;
             }
-            const f32x2 t = pk_fnma_lo(rp, cth, h);
-            const mask_t m_p1 = ballot(max_abs(t.x, t.y) < cth.y);
+            const mask_t m_p1 = ballot(mx_c[qc] < thr_c[qc]);
             mask_t m_in, m_und;
             [[maybe_unused]] mask_t m_front = 0;
             if constexpr (INTERIOR) {
@@ -1197,6 +1287,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
           }
           // (a scheduling barrier here, keeping the voxels' instruction streams apart, was worth keeping until the
           // workgroups became persistent; without it the kernel is 0.4 % faster now, profiles/r03_exp_v_x.json)
+        }
         }
         // ---- phase B: ray potential of the group (cu:105-120) as EXEC-masked adds.  The scalar unit is what this kernel
         // runs out of, so a class that may be absent is still added (under an empty mask) rather than tested for.
