@@ -737,6 +737,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         const f32x2 C0 = pk_fma_hi0_sv(LJ, pair_of(10), pk_fma_lo0_sv(LJ, pair_of(8), CA));
         const f32x2 DC = vec_of(12);
         const unsigned long long M2 = 0x4B4000004B400000ull;  // (1.5 * 2^23, 1.5 * 2^23)
+        float magic_v = 0x1.8p23f;  // ... in a vector register (a scalar operand would make the FMA above a slower encoding)
+        asm volatile("" : "+v"(magic_v));
         // fp64 values at the column's first voxel for the redo below: the centred h.x, h.y (TileMapRec::cpx ...) and the exact
         // c.z (cu:92, cu:172), as every tier-1 column starts from them
         auto first_voxel = [&](double &hxf, double &hyf, double &czf64) __attribute__((always_inline)) {
@@ -768,9 +770,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   #pragma unroll
           for (int q = 0; q < WG; ++q) {
             // -eta*rho (cu:115) where the pixel holds a depth: sum = fma(1.0 or +0.0, -eta*rho, sum), as the gathering column
-            uint32_t bit;
-            asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(pw[q]), "v"(pc[q]));
-            acc_fma_vs<BASE, TK>(g0 + q, (double)bit, free_space);
+            // (the pixel's bit as 0 / -1, and with it the high word of 1.0 or +0.0: v_bfe_i32 and v_and_b32 cost 4.4 + 2.3 issue
+            // cycles, v_bfe_u32 and v_cvt_f64_u32 4.4 + 5.0 -- tools/microbench/issue_rates.hip)
+            int mbit;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mbit) : "v"(pw[q]), "v"(pc[q]));
+            acc_fma_vs<BASE, TK>(g0 + q, __hiloint2double(mbit & 0x3ff00000, 0), free_space);
           }
         };
   #pragma unroll
@@ -811,7 +815,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   #pragma unroll
             for (int u = 0; u < IL; ++u) {
               m_und[q0 + u] = ballot(!(mx[u] < cth[u].y));  // (a NaN is not accepted)
-              wg[q0 + u] = (unsigned)__float_as_int(rpm[u].y) << 2;  // the row's lane, as ds_bpermute_b32 addresses it
+              // the row's lane as ds_bpermute_b32 addresses it, 4 * row in the low bits: one v_fma_f32 on the row as a float (2.7
+              // issue cycles; a v_lshlrev_b32 of the candidate's bits 5.0)
+              wg[q0 + u] = (unsigned)__float_as_int(__builtin_fmaf(rp[u].y, 4.0f, magic_v));
               cg[q0 + u] = (uint32_t)__float_as_int(rpm[u].x);
             }
           }
