@@ -230,6 +230,18 @@ struct ordered {
     return d;
   }
 };
+// the bit pattern of fl32(S * x + 1.5 * 2^23) = 0x4B400000 + S * x for an integer |S * x| < 2^22: the magic number as the literal of a
+// v_fmaak_f32, in no register
+template <size_t S>
+__device__ __forceinline__ unsigned scaled_column_bits(float x) {
+  static_assert(S == 4 || S == 8, "f32 or f64 depth tables");
+  unsigned r;
+  if constexpr (S == 4)
+    asm("v_fmaak_f32 %0, 4.0, %1, 0x4b400000" : "=v"(r) : "v"(x));
+  else  // (8.0 is no inline constant, and an instruction carries one literal)
+    asm("v_fmaak_f32 %0, 4.0, %1, 0x4b400000" : "=v"(r) : "v"(x + x));
+  return r;
+}
 __device__ __forceinline__ int cvt_i32_f32(float x) {  // saturating, NaN -> 0
   int r;
   asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
@@ -254,6 +266,9 @@ struct DepthLoad<float> {
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned pixel) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(pixel << 2), 0, 0));
   }
+  static __device__ __forceinline__ raw_t load_at(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_offset) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)byte_offset, 0, 0));
+  }
   static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
   static __device__ __forceinline__ bool is_sentinel(raw_t d) { return d == -1.0f; }  // cu:202; f32 holds the f64 exactly
   static __device__ __forceinline__ raw_t sentinel() { return -1.0f; }
@@ -266,6 +281,11 @@ struct DepthLoad<double> {
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned pixel) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(pixel << 3), 0, 0);
+    return __hiloint2double((int)raw.y, (int)raw.x);
+  }
+  static __device__ __forceinline__ raw_t load_at(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_offset) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_offset, 0, 0);
     return __hiloint2double((int)raw.y, (int)raw.x);
   }
   static __device__ __forceinline__ void opaque(raw_t &d) { asm("" : "+v"(d)); }
@@ -376,8 +396,15 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
   constexpr bool T1 = DMI_TIER1 != 0 && !GENK;
   [[maybe_unused]] const float Wf = __int_as_float(pinned_word(__float_as_int((float)KA(W))));
   // ... minus what the magic-number candidates carry beside the pixel (0x400000 * W + 0x4B400000, modulo 2^32: see phase A)
-  [[maybe_unused]] const int pix_adj =
-      pinned_word((int)((unsigned)(KA(W) * (KA(H) / 2) + KA(W) / 2) - (0x400000u * (unsigned)KA(W) + 0x4B400000u)));
+  // (as BYTE offsets into the depth table since round 5: the row pitch in bytes, the column as fl32(4 P.x + 1.5 * 2^23) -- one
+  // v_fma_f32 on the candidate, 2.7 issue cycles, where the shift of the finished index took 5 (tools/microbench/issue_rates.hip)
+  // -- and the constant in a vector register: an add between vector registers issues in 2.4 cycles, with a scalar operand in 5)
+  [[maybe_unused]] const unsigned row_bytes = (unsigned)pinned_word((int)((unsigned)KA(W) * (unsigned)sizeof(DepthT)));
+  [[maybe_unused]] unsigned pix_adj = ((unsigned)(KA(W) * (KA(H) / 2) + KA(W) / 2) - 0x400000u * (unsigned)KA(W)) * (unsigned)sizeof(DepthT) - 0x4B400000u;
+  // (in the 16-voxel kernels, which have the registers: with 8-voxel columns the compiler has 80 and these would be spill slots)
+  constexpr bool kConstantsInVgprs = TK >= 16;
+  if constexpr (T1 && kConstantsInVgprs) asm volatile("" : "+v"(pix_adj));
+  if constexpr (T1 && !kConstantsInVgprs) pix_adj = (unsigned)pinned_word((int)pix_adj);
   double tiny = 0x1p-20;  // the reciprocal seed's residual must stay below this; a value in registers, not a literal
   asm volatile("" : "+v"(tiny));  // rebuilt with two scalar moves next to every voxel's compare
   const int lane = threadIdx.x & 63;
@@ -1012,9 +1039,15 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
       constexpr bool UNMASKED = INTERIOR && !COUNT;
       // the image centre, from which tier 1 counts pixels: read once per column where the in-image test needs it
       [[maybe_unused]] int cxc = 0, cyc = 0;
+      // ... and what turns a candidate's bit pattern 0x4B400000 + P into the pixel counted from the map's corner, in vector registers:
+      // a subtraction with a scalar operand issues in 5 cycles, between vector registers in 2.4 (tools/microbench/issue_rates.hip)
+      [[maybe_unused]] unsigned bias_x = 0, bias_y = 0;
       if constexpr (T1 && !INTERIOR) {
         cxc = KC(W) >> 1;
         cyc = KC(H) >> 1;
+        bias_x = 0x4B400000u - (unsigned)cxc;
+        bias_y = 0x4B400000u - (unsigned)cyc;
+        if constexpr (kConstantsInVgprs) asm volatile("" : "+v"(bias_x), "+v"(bias_y));
       }
       // FREE column of tier 1: the only question per voxel is whether its pixel holds a depth: asked of the view's validity
       // map (TileMapRec::valid: bytes in tiles of eight image rows) instead of the f32 table -- a quarter of the lines and
@@ -1080,7 +1113,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // lanes that are not accepted are redone: in fp64 (tier 2: the selection every instantiation used to run inline), then,
         // after the column and if still unproven, with the reference's own expression.
         // The chains of kChain voxels are written link by link (struct ordered): no wait state between the links.
-        constexpr int kChain = T1 ? DMI_T1_COLUMN_CHAINS : 1;
+        constexpr int kChain = T1 && TK >= 16 ? DMI_T1_COLUMN_CHAINS : 1;  // (8-voxel columns: 80 registers, a second chain would spill)
         static_assert(kGroup % kChain == 0, "whole chains per group");
   #pragma unroll
         for (int q0 = 0; q0 < kGroup; q0 += kChain) {
@@ -1130,7 +1163,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
               // the candidate's low 24 bits, 0x400000 + P, give the pixel index W * py'' + px'' in one v_mad_u32_u24 (modulo 2^32,
               // exact on the integers: no fp32 product to keep below 2^24), the constants folded into pix_adj.  Any candidate will
               // do (4d.3); an accepted one is the reference's pixel, |P| < 2^15.
-              pix = __umul24((unsigned)__float_as_int(rpm.y), vW) + (unsigned)__float_as_int(rpm.x) + (unsigned)pix_adj;
+              pix = __umul24((unsigned)__float_as_int(rpm.y), row_bytes) +
+                    scaled_column_bits<sizeof(DepthT)>(rp.x) + pix_adj;  // (a byte offset)
             }
             const mask_t m_p1 = ballot(mx_c[qc] < thr_c[qc]);
             mask_t m_in, m_und;
@@ -1141,7 +1175,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
             } else {
               m_front = ballot(!(czg[q] < 0.0));  // cu:177, exact (lanes and voxels off the grid: c.z = -inf)
               // cu:192-197 on the integers
-              const int px1 = cvt_i32_f32(rp.x) + cxc, py1 = cvt_i32_f32(rp.y) + cyc;
+              // (the candidate's bits, not its conversion: an unaccepted candidate's are anything, and m_p1 keeps it out)
+              const unsigned px1 = (unsigned)__float_as_int(rpm.x) - bias_x, py1 = (unsigned)__float_as_int(rpm.y) - bias_y;
               m_in = m_front & m_p1 & ballot((unsigned)px1 < vW) & ballot((unsigned)py1 < vH);
               m_und = m_front & ~m_p1;
             }
@@ -1168,7 +1203,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                 const double yt2 = __builtin_rint(__builtin_fma(rv2, 0.125, (double)v_c0));
                 pix2 = (unsigned)(cvt_saturating(__builtin_fma(yt2, (double)v_w8, __builtin_fma(ru2, 8.0, rv2))) + v_base);
               } else {
-                pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + (KC(W) * (KC(H) >> 1) + (KC(W) >> 1)));  // (+ the centre's index)
+                pix2 = (unsigned)(cvt_saturating(__builtin_fma(rv2, Wd, ru2)) + (KC(W) * (KC(H) >> 1) + (KC(W) >> 1))) * (unsigned)sizeof(DepthT);  // (+ the centre's index; in bytes)
               }
               if (__builtin_amdgcn_inverse_ballot_w64(m_p2)) pix = pix2;
               if constexpr (INTERIOR) {
@@ -1187,7 +1222,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                 if (__builtin_amdgcn_inverse_ballot_w64(m_und)) vg[q] = 0;  // the redo below adds this voxel's value
               }
             } else if constexpr (UNMASKED) {
-              dg[q] = DL::load(rsrc, pix);
+              dg[q] = DL::load_at(rsrc, pix);
               if (m_und) {  // wave-uniform branch
                 or_where(undecided, m_und, 1u << kk);
                 und_kk |= 1u << kk;
@@ -1199,7 +1234,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
                 or_where(undecided, m_und, 1u << kk);
                 und_kk |= 1u << kk;
               }
-              if (__builtin_amdgcn_inverse_ballot_w64(m_in)) dg[q] = DL::load(rsrc, pix);  // cu:201
+              if (__builtin_amdgcn_inverse_ballot_w64(m_in)) dg[q] = DL::load_at(rsrc, pix);  // cu:201
             }
             continue;
           }
