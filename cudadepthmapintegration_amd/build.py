@@ -33,7 +33,10 @@ COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-ma
 # -amdgpu-use-amdgpu-trackers: the scheduler measures register pressure with the AMDGPU-specific trackers; the tiled kernel's view
 # body, whose every change shows up as spill traffic, runs 3-4 % faster for it (cfg 3 speckle 13.72 -> 13.29 ms, dense 4.49 -> 4.33;
 # max-ilp scheduling and reversed local assignment cost 3-5 %: profiles/r18c_exp_llvm_flags.json)
-HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector"]
+# (--discard-all at the device link: two thirds of a code object's .symtab are LOCAL symbols -- rocPRIM's mangled names run to
+# kilobytes each --: 0.65 MB of 1.9 in coloration_kernels.hip.o alone.  --strip-all would save 0.15 MB more, but a code object
+# without any .symtab crashes the process at its first kernel launch on ROCm 7.2.)
+HIP_FLAGS = ["--offload-arch=gfx950", "-mllvm", "-disable-promote-alloca-to-vector", "-Xoffload-linker", "--discard-all"]
 # hidden LLVM options: kept only where this hipcc knows them (probed once with an empty translation unit; a toolchain without
 # the option would abort every compile with "Unknown command line argument").  build_record.json lists the flags used.
 OPTIONAL_LLVM_FLAGS = ["-amdgpu-use-amdgpu-trackers=1"]

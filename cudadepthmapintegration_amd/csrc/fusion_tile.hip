@@ -1534,12 +1534,14 @@ unsigned resident_workgroups(Kernel kernel, int threads) {
 }
 
 // One launch of the tiled kernel in the given shape.  Which instantiations exist (round 5; 224 of them took five minutes to build):
-//   * the production path -- f32 depth tables, pinhole views, one wave per workgroup -- in both launch forms (persistent / one
-//     workgroup per brick), with the ZF specialisation (no sum can be -0.0, no hit counters: what every fusion from a reset grid
-//     is), its general twin and the counted kernel; the window column (WIN) only with ZF: the host hands out window origins only
-//     to such launches (dmi_capi.hip: the FREE column they refine is not even chosen on a grid that may hold -0.0, 4b.8);
-//   * f64 depth tables (depths that are no f32: DMI_DEPTH_AUTO's promotion) and general K: the persistent form only, plain and
-//     counted -- correct on every input, tuned for none.
+//   * the production path -- f32 depth tables, pinhole views, one wave per workgroup, no sum can be -0.0, no hit counters (ZF: what
+//     every fusion from a reset grid is) -- in both launch forms (persistent / one workgroup per brick), with and without the window
+//     column (WIN: the host hands out window origins only to such launches, dmi_capi.hip: the FREE column they refine is not even
+//     chosen on a grid that may hold -0.0, 4b.8);
+//   * its general twin (a grid that may hold -0.0) and the counted kernel: the persistent form only;
+//   * f64 depth tables (depths that are no f32: DMI_DEPTH_AUTO's promotion) and general K: 16-voxel columns, the persistent form only,
+//     plain and counted -- correct on every input, tuned for none.
+// 72 instantiations (round 4: 224, five minutes to build; round 5 began with 96).
 template <typename DepthT, typename GridT, int TK, int WX, int WY, int MINW, int GROUP, bool ROT = false, bool GENK = false, bool WIN = false>
 hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
   static_assert(TK <= kMaxColumnHeight, "dmi_multi_z_slab aligns slabs to kMaxColumnHeight");
@@ -1585,13 +1587,8 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     hipLaunchKernelGGL(kernel, dim3(n), block, 0, s, a);
     return hipGetLastError();
   };
-  if constexpr (!WIN) {
-    if (cfg.count_hits) {
-      if constexpr (one_wave && !rare) {
-        if (!stay) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK, false>, false);
-      }
-      return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>, true);
-    }
+  if constexpr (!WIN) {  // hit counters (a diagnostic): the persistent form whatever the size
+    if (cfg.count_hits) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, true, ROT, GENK>, true);
   }
   if constexpr (one_wave && !rare) {
     if (zf) {
@@ -1599,12 +1596,8 @@ hipError_t launch_shape(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, true, WIN, true>, true);
     }
   }
-  if constexpr (!WIN) {
-    if constexpr (one_wave && !rare) {
-      if (!stay) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK, false>, false);
-    }
-    return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>, true);
-  }
+  // a grid that may hold -0.0 (handed out as a device pointer, or uploaded with one in it): the persistent form whatever the size
+  if constexpr (!WIN) return launch(fuse_tile_kernel<DepthT, GridT, TK, WX, WY, MINW, GROUP, false, ROT, GENK>, true);
   return hipErrorInvalidValue;
 }
 
@@ -1617,8 +1610,8 @@ int effective_shape(int variant, bool depth_is_f64, bool rotated, bool general_k
 #ifndef DMI_TUNING
   shape = (shape == 1 || shape == 3 || shape == 4 || shape == 7) ? 7 : 0;  // their column height, one wave per workgroup
 #endif
-  if (general_k) return 0;  // general K: 16-voxel columns only (launch_shape: a rare path, one shape, one launch form)
-  return ((depth_is_f64 || rotated) && shape != 7) ? 0 : shape;
+  if (general_k || depth_is_f64) return 0;  // general K, f64 depth tables: 16-voxel columns only (launch_shape: rare paths, one shape, one launch form)
+  return (rotated && shape != 7) ? 0 : shape;
 }
 
 // the window launches of the two default shapes (f32 depth tables only: launch_shape)
@@ -1632,7 +1625,8 @@ hipError_t launch_win(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
 
 template <typename DepthT, typename GridT>
 hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s) {
-  const int shape = effective_shape(cfg.variant, std::is_same<DepthT, double>::value, a.rotated != 0, cfg.general_k != 0);
+  constexpr bool f32_depth = std::is_same<DepthT, float>::value;  // (f64 depth tables: 16-voxel columns only, effective_shape)
+  const int shape = effective_shape(cfg.variant, !f32_depth, a.rotated != 0, cfg.general_k != 0);
   // a launch with window origins (dmi_capi.hip: maps with scattered holes, no hit counters, pinhole views, f32 depth tables, a
   // grid free of -0.0): the WIN instantiations.  (A -DDMI_TIER1=0 build has no window column: the host allocates no origins.)
   const bool win = DMI_TIER1 != 0 && std::is_same<DepthT, float>::value && a.win_origin != nullptr && !cfg.count_hits && !cfg.general_k &&
@@ -1642,7 +1636,9 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
     if (shape == 7) return launch_win<DepthT, GridT, 8, 6, false>(a, cfg, s);
     return launch_win<DepthT, GridT, 16, 5, false>(a, cfg, s);
   }
-  if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
+  if constexpr (f32_depth) {
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
+  }
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
 #else
   if (cfg.general_k) {  // a general K among the views: 16-voxel columns, either kind of grid
@@ -1654,7 +1650,9 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
       if (shape == 7) return launch_win<DepthT, GridT, 8, 6, true>(a, cfg, s);
       return launch_win<DepthT, GridT, 16, 5, true>(a, cfg, s);
     }
-    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
+    if constexpr (f32_depth) {
+      if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8, true>(a, cfg, s);
+    }
     return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8, true>(a, cfg, s);
   }
 #ifdef DMI_TUNING
@@ -1676,7 +1674,9 @@ hipError_t launch_types(const TileArgs &a, const FuseConfig &cfg, hipStream_t s)
   }
   // 80 + 16 = 96 VGPRs: 5 waves; the whole column is one load group (8 gathers in flight before the first is consumed);
   // one wave per workgroup: an 8 x 8 x 8 brick is the unit of scheduling and of the heaviest-first order
-  if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
+  if constexpr (f32_depth) {
+    if (shape == 7) return launch_shape<DepthT, GridT, 8, 1, 1, 6, 8>(a, cfg, s);
+  }
   // 96 + 32 = 128 VGPRs: 4 waves per SIMD; load groups of 8 (half a column's gathers in flight); one wave per workgroup
   return launch_shape<DepthT, GridT, 16, 1, 1, 5, 8>(a, cfg, s);
 #endif
