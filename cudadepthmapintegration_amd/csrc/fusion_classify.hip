@@ -1065,7 +1065,11 @@ __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, i
   int bx = 0, by = 0, bz = 0;
   const bool exists = slot < n_slots;
   const bool in_grid = exists && slot_to_brick(a, slot + a.slot_base, bx, by, bz);
-  int mixed = 0;
+  // mixed pairs, and among them the "free space or no depth" ones with a window: what the window column takes at well under half
+  // the time of a gathering column (the class byte's low six bits: class, reason, CLASS_NO_WINDOW)
+  int mixed = 0, light = 0;
+  constexpr uint32_t kLight = (uint32_t)BRICK_MIXED | ((uint32_t)MIXED_FREE_OR_NODEPTH << 2);
+  static_assert(BRICK_MIXED == 0, "a mixed pair's low two bits are 00");
   if (in_grid) {
     const uint8_t *row = a.classes + (((int64_t)bz * a.wbricks_y + by) * a.wbricks_x + bx) * (int64_t)a.class_pitch + a.first_map;
     for (int v0 = part * 16; v0 < a.n_maps; v0 += 256) {
@@ -1077,13 +1081,22 @@ __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, i
           const uint32_t c = words[q];
           const uint32_t nz = (c | (c >> 1)) & 0x01010101u;  // a byte whose low two bits are not 00 (BRICK_MIXED)
           mixed += 4 - __builtin_popcount(nz);
+          // a zero byte: class and reason of the window column, and no CLASS_NO_WINDOW (window_origin_kernel has run)
+          const uint32_t y = (c & 0x3f3f3f3fu) ^ (kLight * 0x01010101u);
+          light += 4 - __builtin_popcount((y + 0x7f7f7f7fu) & 0x80808080u);
         }
       } else {
-        for (int v = v0; v < min(v0 + 16, a.n_maps); ++v) mixed += (row[v] & 3) == BRICK_MIXED ? 1 : 0;
+        for (int v = v0; v < min(v0 + 16, a.n_maps); ++v) {
+          mixed += (row[v] & 3) == BRICK_MIXED ? 1 : 0;
+          light += (row[v] & 0x3f) == kLight ? 1 : 0;
+        }
       }
     }
   }
-  for (int off = 8; off > 0; off >>= 1) mixed += __shfl_xor(mixed, off, 64);
+  for (int off = 8; off > 0; off >>= 1) {
+    mixed += __shfl_xor(mixed, off, 64);
+    light += __shfl_xor(light, off, 64);
+  }
   if (a.flags & TILE_FLAG_COST_ORDER) {
     // cost order: level 0 = every view mixed ... 62 = one view in 63 or fewer, 63 = none; the levels' sizes are counted here,
     // one atomic per level present in the wave's four slots
@@ -1103,7 +1116,14 @@ __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, i
     // 117 of 256 views mixed shared a level with one of 32 and, dealt late, ran 0.46 ms on an emptying chip: the launch spent
     // 0.36 of its 12.3 ms with under half of its workgroups resident, profiles/r19y_wg_timeline_cfg3_speckle.json.  The bricks
     // without a mixed view are a few microseconds each: no level of their own.)
-    level[slot] = !in_grid ? 255 : (mixed * 2 >= a.n_maps ? 0 : (mixed * 4 >= a.n_maps ? 1 : (mixed * 16 >= a.n_maps ? 2 : 3)));
+    // (later in round 5: by COST, a window pair counting 1 and every other mixed pair 2.5 -- bricks of 110 to 127 mixed views, half of
+    // them gathering columns, ran 0.5 - 0.6 ms from the 11.6th of 12.2 ms on: profiles/r20a_wg_timeline_cfg3_speckle_new_levels.json)
+    // A launch without windows (maps without holes, hit counters, general K ...) keeps the count of mixed views: every one is a
+    // gathering column there, and the thresholds were fitted to that.
+    {
+      const int cost2 = a.win_origin ? 2 * light + 5 * (mixed - light) : 2 * mixed;  // in halves of a window pair
+      level[slot] = !in_grid ? 255 : (cost2 >= a.n_maps ? 0 : (cost2 * 2 >= a.n_maps ? 1 : (cost2 * 8 >= a.n_maps ? 2 : 3)));
+    }
 }
 
 // Cost order, second launch: the levels' starts (a scan of the 64 sizes, by every workgroup for itself), then every slot takes
