@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(256) void brick_work_kernel_1x1(const TileArgs a, i
   if (a.flags & TILE_FLAG_COST_ORDER) {
     // cost order: level 0 = every view mixed ... 62 = one view in 63 or fewer, 63 = none; the levels' sizes are counted here,
     // one atomic per level present in the wave's four slots
+    // (by the count of mixed views, not by the cost used below: weighted, 256^3 x 64 views with holes took 0.541 instead of 0.528 ms)
     const int lv = !in_grid ? 255 : (mixed == 0 ? kCostLevels - 1 : (kCostLevels - 1) - (mixed * (kCostLevels - 1) + a.n_maps - 1) / a.n_maps);
     if (exists && part == 0) level[slot] = (uint8_t)lv;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(exists && part == 0 && lv < kCostLevels);
