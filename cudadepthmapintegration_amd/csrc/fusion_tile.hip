@@ -763,7 +763,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         CA.y = __builtin_fmaf(acz, __uint_as_float(R[15]), -__uint_as_float(R[14]));
         const f32x2 C0 = pk_fma_hi0_sv(LJ, pair_of(10), pk_fma_lo0_sv(LJ, pair_of(8), CA));
         const f32x2 DC = vec_of(12);
-        const unsigned long long M2 = 0x4B4000004B400000ull;  // (1.5 * 2^23, 1.5 * 2^23)
+        unsigned long long M2 = 0x4B4000004B400000ull;  // (1.5 * 2^23, 1.5 * 2^23)
+        asm volatile("" : "+s"(M2));  // a register pair for the column's life (as a constant its high half was rebuilt for every other voxel)
         float magic_v = 0x1.8p23f;  // ... in a vector register (a scalar operand would make the FMA above a slower encoding)
         asm volatile("" : "+v"(magic_v));
         // fp64 values at the column's first voxel for the redo below: the centred h.x, h.y (TileMapRec::cpx ...) and the exact
@@ -789,6 +790,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void fuse_tile_kernel(const Til
         // window's loads nor a look-up's trip through the LDS crossbar is waited for
         uint32_t pw[WG], pc[WG];             // the previous group's words and columns
         auto consume = [&](int g0) __attribute__((always_inline)) {
+          // (one wait for the group's four look-ups -- they were issued a group of candidates ago --, not one per voxel)
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); vmcnt / expcnt left alone
           if ((und_kk >> g0) & ((1u << WG) - 1u)) {  // wave-uniform, rare: some lane of the group was not accepted
             // the redo below adds that voxel's value: here its word counts as empty
   #pragma unroll
