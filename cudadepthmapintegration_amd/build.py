@@ -63,8 +63,17 @@ _FLAG_CACHE = os.path.join(ROOT, "build", "llvm_flag_probe.json")
 def _optional_flags() -> list:
     import json
 
+    # The toolchain's identity WITHOUT running it: this module is imported by every process that loads the library, and a
+    # process whose GPU is already initialised (any program under `rocprofv3 --pmc`) must not start another one -- the GPU boxes
+    # of this pool refuse that.  Path, size and modification time of the driver and of the clang it ships with.
     try:
-        version = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout
+        parts = []
+        hip = os.path.realpath(hipcc_path())
+        for f in (hip, os.path.realpath(os.path.join(os.path.dirname(hip), "..", "lib", "llvm", "bin", "clang"))):
+            if os.path.exists(f):
+                st = os.stat(f)
+                parts.append("%s:%d:%d" % (f, st.st_size, int(st.st_mtime)))
+        version = ";".join(parts)
     except (OSError, RuntimeError):
         return []
     try:

@@ -185,3 +185,27 @@ def test_fp64_only_build_of_the_tiled_kernel_compiles():
                             "-DDMI_TIER1=0", "--cuda-device-only", "-c", os.path.join(b.CSRC, "fusion_tile.hip"), "-o", os.path.join(tmp, "t.o")],
                            capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_loading_the_package_starts_no_other_program():
+    """A process whose GPU is already initialised (anything under `rocprofv3 --pmc`) must not start another program: the GPU
+    boxes refuse it.  With the flag probe's record in place (build/llvm_flag_probe.json, written by the first import), importing
+    the build module -- which every load of the library does -- runs nothing."""
+    import subprocess as sp
+    import sys
+
+    code = (
+        "import sys\n"
+        "import cudadepthmapintegration_amd.build\n"  # (writes the record if it is missing)
+        "seen = []\n"
+        "sys.addaudithook(lambda ev, a: seen.append(ev) if ev in ('subprocess.Popen', 'os.exec', 'os.posix_spawn', 'os.system') else None)\n"
+        "import importlib\n"
+        "importlib.reload(cudadepthmapintegration_amd.build)\n"
+        "print('SPAWNED' if seen else 'QUIET')\n"
+    )
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = sp.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith("QUIET"), out.stdout + out.stderr
