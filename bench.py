@@ -244,7 +244,7 @@ def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, pcie
     out = capi.pinned_empty((grid.n_voxels,), np_grid)
     times = []
     with capi.FusionContext(grid, ray, grid_dtype=grid_dtype, depth_storage="auto") as c:
-        for rep in range(3):
+        for rep in range(5):  # (the first is the warm-up; one of the others in three runs is 3 ms late: the median of four)
             c.clear_views()
             c.reset_grid()
             c.synchronize()
@@ -263,7 +263,7 @@ def end_to_end_probe(scene, capi, grid, ray, views, host_dtype, grid_dtype, pcie
     return {"host_depth": host_dtype, "grid": grid_dtype, "seconds": dt, "value": grid.n_voxels * n / dt / 1e9,
             "unit": "Gvoxel-projections/s including H2D of every depth table and D2H of the grid",
             "pcie_bytes": moved, "pcie_GBps_if_alone": moved / dt / 1e9, "chunk_views": chunk_views, "download_slabs": download_slabs,
-            "pcie_floor_s": floor, "seconds_over_floor": dt / floor}
+            "pcie_floor_s": floor, "seconds_over_floor": dt / floor, "seconds_of_calls": [round(t, 6) for t in times[1:]]}
 
 
 # ---- launching -------------------------------------------------------------------------------------------------
