@@ -245,6 +245,19 @@ def scratch_sizes(asm_text: str) -> dict:
     return out
 
 
+def wait_state_counts(asm_text: str) -> dict:
+    """s_nop instructions per fuse_tile_kernel instantiation: a canary, not a rule.  hipcc puts a wait state between an asm
+    statement and an immediate reader of its result; the tier-1 chains are written so that few are needed (fusion_tile.hip, struct
+    ordered: 11.95 -> 11.34 ms at cfg 3).  A toolchain that schedules them differently shows here first (the headline kernel of
+    round 5's build: ~300 in 12 000 lines)."""
+    import re
+
+    out = {}
+    for m in re.finditer(r"^(_ZN3dmi\S*fuse_tile_kernel\S*):.*?\.end_amdhsa_kernel", asm_text, re.S | re.M):
+        out[m.group(1)] = len(re.findall(r"^\s*s_nop\b", m.group(0), re.M))
+    return out
+
+
 def _audit_digest() -> str:
     return source_digest([os.path.join(CSRC, "fusion_tile.hip")] + _headers())
 
@@ -283,6 +296,7 @@ def run_accumulator_audit(verbose: bool = False) -> int:
     # five waves per SIMD) a few spill slots are tolerated, bounded here; the counted kernels (an array of hit counters per
     # column), f64 depth tables and general K are the rare paths (launch_shape): listed, not bounded.  A toolchain or source
     # change that makes a production kernel spill is caught here, not in a profile months later.
+    nops = wait_state_counts(text)
     table = {}
     for name, size in scratch.items():
         m = re.search(r"fuse_tile_kernelI(\w)(\w)Li(\d+)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])(?:ELb([01]))?E", name)
@@ -293,7 +307,7 @@ def run_accumulator_audit(verbose: bool = False) -> int:
         production = depth == "f" and count == "0" and genk == "0" and wx == "1" and wy == "1"
         # (a tuning build carries debug counters through the kernel: a few slots are its own)
         limit = None if not production else ((16 if "-DDMI_TUNING" in COMMON_FLAGS else 0) if tk == "16" else 48)
-        table[key] = {"scratch_bytes_per_lane": size, "production": production, "limit": limit}
+        table[key] = {"scratch_bytes_per_lane": size, "production": production, "limit": limit, "s_nop": nops.get(name)}
         if limit is not None and size > limit:
             bad.append(f"{name}: {size} bytes of scratch memory per lane in a production instantiation (limit {limit})")
     if bad:
