@@ -1,3 +1,7 @@
+// CAUTION: run it with instruction names on the command line (profiles/r21d_issue_rates_selected.txt shows a call).  Without
+// names it runs every entry, and on the box of 2026-10-05 one of the entries added last (between `v_lshlrev_b32 v,v` and
+// `v_cvt_u32_f32`; `v_and_b32 literal`, `v_and_b32 sgpr`, `v_fma_f32 4.0,v,v`, `v_mul_f32 4.0`, `v_sub_f32`, `v_min_f32` are cleared) did
+// not come back in the sixteen-wave mode until `timeout` killed the process.
 // Issue cost of the vector instructions the fusion kernel is made of, one wave on one SIMD, independent instructions:
 // cycles (s_memtime) per instruction, relative to v_add_f32.  Build: hipcc --offload-arch=gfx950 -O2 -o issue_rates issue_rates.hip
 #include <hip/hip_runtime.h>
