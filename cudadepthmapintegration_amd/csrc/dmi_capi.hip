@@ -1294,7 +1294,9 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     }
     const bool scattered = without <= 6 * mingled;     // a scattered hole has its strip to itself; a disc of radius r has ~0.8 r pixels per border strip
     cfg.holes = scattered && mingled * 160 > strips ? 1 : 0;    // p > 1/160 (f > 0.08 %): windows, persistent workgroups from 48 views on
-    tall_by_holes = scattered && mingled * 40 > strips;         // p > 1/40 (f > 0.3 %): 16-voxel columns from 256^3 on
+    // (1/40 until the kernel of late round 5: at f = 0.2 % and 0.3 % the 16-voxel columns then took 10.9 and 11.5 ms where the
+    // 8-voxel ones took 11.2 and 12.2, at 0.1 % a tie -- profiles/r21t_hole_variants.jsonl)
+    tall_by_holes = scattered && mingled * 80 > strips;         // p > 1/80 (f > 0.16 %): 16-voxel columns from 256^3 on
     // holes in regions, but so many that a tenth of all strips lie on a border (discs over 40 % of the image: 11.5 -> 10.4 ms with
     // windows, at 20 % a tie, profiles/r19p_hole_variants_blobs.jsonl): windows for the free-space pairs along those borders
     many_borders = mingled * 10 > strips;
