@@ -1297,9 +1297,12 @@ int fuse_run(dmi_context *ctx, int32_t first, int32_t count, int32_t z_first, in
     // (1/40 until the kernel of late round 5: at f = 0.2 % and 0.3 % the 16-voxel columns then took 10.9 and 11.5 ms where the
     // 8-voxel ones took 11.2 and 12.2, at 0.1 % a tie -- profiles/r21t_hole_variants.jsonl)
     tall_by_holes = scattered && mingled * 80 > strips;         // p > 1/80 (f > 0.16 %): 16-voxel columns from 256^3 on
-    // holes in regions, but so many that a tenth of all strips lie on a border (discs over 40 % of the image: 11.5 -> 10.4 ms with
-    // windows, at 20 % a tie, profiles/r19p_hole_variants_blobs.jsonl): windows for the free-space pairs along those borders
-    many_borders = mingled * 10 > strips;
+    // holes in regions, but so many that a twenty-fifth of all strips lie on a border: windows for the free-space pairs along those
+    // borders, and 16-voxel columns.  Discs of 8-40 pixels radius (`--scene blobs`; share of mingled strips 1.7 / 2.7 / 4.8 / 8.5 %
+    // at 5 / 10 / 20 / 40 % of the image): default / windows + 16-voxel columns 6.1 / 6.2, 7.0 / 7.0, 8.5 / 8.1, 11.1 / 9.2 ms
+    // (profiles/r21v_hole_variants_blobs.jsonl; the first rule, a tenth of the strips, never fired on that scene).
+    many_borders = mingled * 25 > strips;
+    tall_by_holes = tall_by_holes || many_borders;
   }
   // ... and maps that are mostly EMPTY in large regions (a silhouette against nothing: a quarter of the pixels or more without a
   // depth, the holes not mingled with depths): most (brick, view) pairs are skipped and a brick's fixed costs dominate
