@@ -105,36 +105,6 @@ __device__ __forceinline__ int cvt_saturating(double x) {
 
 // ---- tier 1 of the pixel selection: packed fp32 (two floats per lane in a register pair), see the kernel --------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// a * b + c on both halves, a = the float in the low dword of a wave-uniform 64-bit value (an SGPR pair)
-__device__ __forceinline__ f32x2 pk_fma_s(unsigned long long a_bits, f32x2 b, f32x2 c) {
-  f32x2 d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(a_bits), "v"(b), "v"(c));
-  return d;
-}
-// a * b.x on both halves (b.y is never read)
-__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-// c - a * b.x on both halves, one rounding each
-__device__ __forceinline__ f32x2 pk_fnma_lo(f32x2 a, f32x2 b, f32x2 c) {
-  f32x2 d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-// a * b.x + c on both halves, c = a wave-uniform pair of floats (an SGPR pair)
-__device__ __forceinline__ f32x2 pk_fma_lo_s(f32x2 a, f32x2 b, unsigned long long c_bits) {
-  f32x2 d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "s"(c_bits));
-  return d;
-}
-// a - c on both halves, c = a wave-uniform pair of floats (an SGPR pair)
-__device__ __forceinline__ f32x2 pk_sub_s(f32x2 a, unsigned long long c_bits) {
-  f32x2 d;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "s"(c_bits));
-  return d;
-}
 // a.lo * b + c on both halves, a = a pair of per-lane floats of which only the low one is read, c = a wave-uniform pair (SGPRs)
 __device__ __forceinline__ f32x2 pk_fma_lo0_vs(f32x2 a, f32x2 b, unsigned long long c_bits) {
   f32x2 d;
@@ -184,15 +154,6 @@ __device__ __forceinline__ float t1_lane_margin(float cz0, float dcz, float hb, 
   return p < 0x1p21f ? __builtin_fmaf(b, p, e1_const) : __builtin_inff();
 }
 
-// v_rcp_f32 whose result an inline-asm instruction may read next.  gfx950 does not interlock a transcendental result against
-// the very next VALU instruction; the compiler inserts the wait state for consumers it generates itself, but it cannot see
-// into an asm statement (found the hard way: the packed multiply below read a stale register in a part of the wave, and
-// only the acceptance test's independence of the reciprocal kept the results right).  s_nop 0 = the one wait state.
-__device__ __forceinline__ float rcp_f32_for_asm(float x) {
-  float r;
-  asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
-  return r;
-}
 // The links of a tier-1 chain as ORDERED statements (asm volatile keeps source order): two voxels' chains written link by link,
 // alternately, leave one instruction between every producer and its reader -- the wait state that the compiler otherwise fills
 // with an s_nop after each asm statement (it cannot know whether the statement was a transcendental or wrote half a register), six
