@@ -927,11 +927,17 @@ int dmi_color_process(dmi_color_context *c, const double *points, int64_t n_poin
     if (histogram_medians) {
       // (vertices in a coherent order -- the caller's, a mesh's, or the Z-order pass's -- take the pipelined view loop, scattered
       // ones the plain one)
+      // (tuning builds: extra dynamic LDS per workgroup, i.e. FEWER resident waves -- what keeping a vertex's values in LDS
+      // instead of the scratch table would cost the view loop: tools/gpu_coloration_occupancy.sh)
+      unsigned extra_lds = 0;
+#ifdef DMI_TUNING
+      if (const char *env = getenv("DMI_DEBUG_COLOR_EXTRA_LDS")) extra_lds = (unsigned)strtoul(env, nullptr, 0);
+#endif
       if (!perm && !coherent)
-        hipLaunchKernelGGL((project_color_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->d_points[b], nv, perm, c->d_views,
+        hipLaunchKernelGGL((project_color_kernel<true, false>), dim3(blocks), dim3(256), extra_lds, c->stream, c->d_points[b], nv, perm, c->d_views,
                            (int)n_views, c->W, c->H, c->d_scratch, c->d_mean[b], c->d_count[b], c->d_seeds, c->d_margins[b]);
       else
-        hipLaunchKernelGGL((project_color_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->d_points[b], nv, perm, c->d_views,
+        hipLaunchKernelGGL((project_color_kernel<true, true>), dim3(blocks), dim3(256), extra_lds, c->stream, c->d_points[b], nv, perm, c->d_views,
                            (int)n_views, c->W, c->H, c->d_scratch, c->d_mean[b], c->d_count[b], c->d_seeds, c->d_margins[b]);
       DMI_COLOR_TRY(hipGetLastError());
       hipLaunchKernelGGL(median_low_nibble_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_scratch, nv, (int)n_views, perm,
