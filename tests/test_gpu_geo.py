@@ -111,3 +111,33 @@ def test_regional_holes_bit_exact():
     for variant in (0, W, W | capi.VARIANT_FIXED_TILE_SHAPE):
         out, _, _ = capi.fuse_once(grid, rp, views, count_hits=False, kernel_variant=variant)
         assert bits_equal(out, want), variant
+
+
+@pytest.mark.gpu
+def test_the_launch_follows_the_hole_layout():
+    """What the maps' holes look like decides the launch (dmi_capi.hip, fuse_run): scattered holes bring the window column from
+    about 0.1 % of the pixels on; holes in regions only when a twenty-fifth of the 8-pixel strips lie on a region's border (discs
+    over 40 % of the image, not over 5 %).  Whatever the rule picks, the oracle's grid bit for bit."""
+    grid = scene.default_grid((96, 96, 64))
+    rp = scene.default_ray_potential(grid)
+
+    def run(views):
+        want = oracle.fuse(oracle_params_from_scene(grid, rp, views), views.depth, views.K4, views.RT4, n_threads=oracle.max_threads())[0]
+        with capi.FusionContext(grid, rp) as ctx:
+            ctx.add_views(views)
+            ctx.fuse()
+            out = ctx.download_grid()
+            n_win = ctx.window_pair_count()
+        assert bits_equal(out, want)
+        return n_win
+
+    discs_few, _ = scene.make_scene_views("blobs", 10, 640, 480, seed=3, speckle=0.05)
+    discs_many, _ = scene.make_scene_views("blobs", 10, 640, 480, seed=3, speckle=0.4)
+    assert run(discs_few) == 0
+    assert run(discs_many) > 0
+    dense = scene.make_views(10, 640, 480, seed=3, dense=True)
+    for share, windows in ((0.0002, False), (0.004, True)):
+        d = dense.depth.copy()
+        d[np.random.default_rng(5).random(d.shape) < share] = -1.0
+        n_win = run(scene.Views(d, dense.K4, dense.RT4))
+        assert (n_win > 0) == windows, (share, n_win)
